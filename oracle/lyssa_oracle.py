@@ -1,0 +1,352 @@
+"""CPU oracle: our own float64 restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is the *checker*: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it.
+Nothing under ``lyssandra_amd/`` imports it; the product path is HIP-only and fails
+loudly when the HIP library is missing.
+
+Parity pinning: the reference's own tests hold **no** golden vector or known-answer test
+for this path, so this restatement is pinned against outputs of the
+reference itself: ``oracle/make_golden.py`` imports the (py3-converted) reference in the
+build container, runs it on seeded inputs and commits inputs+outputs under
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks every function below against
+those vectors (identical supports, <=1e-12 on values).
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+Conventions are the reference's: X is (n_features, n_samples), D is (n_features, n_atoms),
+Z is dense (n_atoms, n_samples), all float64.
+"""
+import numpy as np
+from scipy.linalg import solve_triangular
+
+EPS64 = float(np.finfo(np.float64).eps)
+
+
+# --------------------------------------------------------------------------- math shims
+def fast_dot(a, b):
+    """lyssa/utils/math.py:11-24 -- matrix product (np.dot / ddot)."""
+    return np.dot(a, b)
+
+
+def norm(x):
+    """lyssa/utils/math.py:52-54 -- BLAS nrm2."""
+    return float(np.sqrt(np.dot(x, x)))
+
+
+def frobenius_squared(A):
+    """lyssa/utils/math.py:57-58."""
+    return float(np.sum(np.power(A, 2)))
+
+
+def normalize(x, eps=EPS64):
+    """lyssa/utils/math.py:61-62 -- x / (||x|| + eps)."""
+    return x / (norm(x) + eps)
+
+
+def norm_cols(X, eps=EPS64):
+    """lyssa/utils/math.py:65-71 -- in-place column normalisation with +eps."""
+    norms = np.sqrt(np.einsum('ij,ij->j', X, X)) + eps
+    X /= norms[np.newaxis, :]
+    return X
+
+
+# --------------------------------------------------------------------------- batching
+def gen_even_batches(N, n_batches):
+    """lyssa/utils/__init__.py:166-180 -- n_batches-1 batches of floor(N/n_batches), last takes the rest."""
+    size = int(np.floor(N / float(n_batches)))
+    out, base = [], 0
+    for _ in range(n_batches - 1):
+        out.append(range(base, base + size))
+        base += size
+    out.append(range(base, N))
+    return out
+
+
+def gen_batches(N, batch_size=None):
+    """lyssa/utils/__init__.py:183-201 -- fixed-size batches + remainder; None => one batch."""
+    if batch_size is None:
+        return [range(0, N)]
+    out, base = [], 0
+    for _ in range(int(np.floor(N / float(batch_size)))):
+        out.append(range(base, base + batch_size))
+        base += batch_size
+    if N > base:
+        out.append(range(base, N))
+    return out
+
+
+# --------------------------------------------------------------------------- Batch-OMP
+def batch_omp_signal(a0, G, k, want_gap=False):
+    """One signal of lyssa/sparse_coding.py:310-365.
+
+    Returns (support list in selection order, coefficient array, min relative top1/top2 gap).
+    Greedy loop: argmax|a| (first max wins) :322; break on re-selection :323-325;
+    j==0: z=a0[kk] :360-363; j==1: closed-form 2x2 factor :330-338; j>=2: w=L^-1 g,
+    vs=1-w'w, break if vs<eps :340-349; two triangular solves :353-354; a=a0-G[:,Dx]z :359.
+    The Gram diagonal is *assumed* to be 1 (hard-coded), exactly as the reference does.
+    """
+    K = a0.shape[0]
+    L = np.zeros((k, k))
+    Dx = []
+    z = np.zeros(0)
+    a = a0
+    min_gap = np.inf
+    for j in range(k):
+        absa = np.abs(a)
+        kk = int(np.argmax(absa))
+        if want_gap and K > 1:
+            top = absa[kk]
+            tmp = absa.copy()
+            tmp[kk] = -1.0
+            second = tmp.max()
+            gap = (top - second) / top if top > 0 else 0.0
+            if kk not in Dx:
+                min_gap = min(min_gap, gap)
+        if kk in Dx:
+            break
+        if j == 0:
+            Dx.append(kk)
+            z = a0[Dx].copy()
+        else:
+            g = G[Dx, kk]
+            if j == 1:
+                w = float(g[0])
+                vs = 1.0 - w * w
+                if vs < EPS64:
+                    break
+                L[0, 0] = 1.0
+                L[1, 0] = w
+                L[1, 1] = np.sqrt(vs)
+            else:
+                w = solve_triangular(L[:j, :j], g, lower=True, check_finite=False)
+                vs = 1.0 - float(np.dot(w, w))
+                if vs < EPS64:
+                    break
+                L[j, :j] = w
+                L[j, j] = np.sqrt(vs)
+            Dx.append(kk)
+            Ltc = solve_triangular(L[:j + 1, :j + 1], a0[Dx], lower=True)
+            z = solve_triangular(L[:j + 1, :j + 1], Ltc, trans=1, lower=True)
+        a = a0 - np.dot(G[:, Dx], z)
+    return Dx, z, (min_gap if np.isfinite(min_gap) else 0.0)
+
+
+def batch_omp(X, Alpha, D, Gram, n_nonzero_coefs=None, tol=None):
+    """lyssa/sparse_coding.py:302-367 -- dense Z (n_atoms, n_samples). X, D only give shapes; tol unused."""
+    n_samples = X.shape[1]
+    n_atoms = D.shape[1]
+    Z = np.zeros((n_atoms, n_samples))
+    for i in range(n_samples):
+        Dx, z, _ = batch_omp_signal(Alpha[:, i], Gram, n_nonzero_coefs)
+        Z[Dx, i] = z
+    return Z
+
+
+def bomp_encode(X, D, k):
+    """sparse_encoder.__call__, 'bomp' branch: lyssa/sparse_coding.py:629-635 + :718-720 (n_jobs=1)."""
+    Gram = fast_dot(D.T, D)
+    Alpha = fast_dot(D.T, X)
+    return batch_omp(X, Alpha, D, Gram, n_nonzero_coefs=k)
+
+
+def bomp_encode_sparse(X, D, k):
+    """Same computation, returned as the sparse triplet the HIP engine produces.
+
+    idx (N,k) int32 selection order, -1 padded; coef (N,k) float64, 0 padded; nnz (N,) int32 = len(Dx);
+    gap (N,) float64 = min relative top-1/top-2 gap along the greedy path (tie classifier).
+    """
+    Gram = fast_dot(D.T, D)
+    Alpha = fast_dot(D.T, X)
+    N = X.shape[1]
+    idx = -np.ones((N, k), dtype=np.int32)
+    coef = np.zeros((N, k))
+    nnz = np.zeros(N, dtype=np.int32)
+    gap = np.zeros(N)
+    for i in range(N):
+        Dx, z, g = batch_omp_signal(Alpha[:, i], Gram, k, want_gap=True)
+        m = len(Dx)
+        idx[i, :m] = Dx
+        coef[i, :m] = z
+        nnz[i] = m
+        gap[i] = g
+    return idx, coef, nnz, gap
+
+
+def densify(idx, coef, nnz, K):
+    """Sparse triplet -> dense float64 Z (K, N), the reference's return type (sparse_coding.py:365)."""
+    N = idx.shape[0]
+    Z = np.zeros((K, N))
+    for i in range(N):
+        m = int(nnz[i])
+        Z[idx[i, :m], i] = coef[i, :m]
+    return Z
+
+
+# --------------------------------------------------------------------------- dictionary helpers
+def approx_error(D, Z, X):
+    """lyssa/dict_learning/utils.py:14-19 -- ||X - DZ||_F^2."""
+    return frobenius_squared(X - fast_dot(D, Z))
+
+
+def average_mutual_coherence(D):
+    """lyssa/dict_learning/utils.py:7-11 -- mean off-diagonal |D'D|."""
+    K = D.shape[1]
+    G = np.abs(np.dot(D.T, D))
+    np.fill_diagonal(G, 0)
+    return float(np.sum(G) / float(K * (K - 1)))
+
+
+def init_dictionary(X, n_atoms, method='data', return_unused_data=False, normalize=True):
+    """lyssa/dict_learning/utils.py:49-70 ('data' method only).
+
+    Candidates = columns with energy > 1e-6; np.random.choice on the GLOBAL RNG, no replacement;
+    D = X[:, chosen] (copy) optionally norm_cols'ed; unused_data = remaining candidates (list).
+    """
+    if method != 'data':
+        raise ValueError("oracle restates only method='data'")
+    n_samples = X.shape[1]
+    idxs = [i for i in range(n_samples) if np.sum(X[:, i] ** 2) > 1e-6]
+    if len(idxs) < n_atoms:
+        raise ValueError("not enough datapoints to initialize the dictionary")
+    subset = np.random.choice(len(idxs), size=n_atoms, replace=False)
+    subset_idxs = np.array(idxs).astype(int)[subset]
+    D = X[:, subset_idxs]
+    if normalize:
+        D = norm_cols(D)
+    if return_unused_data:
+        s = set(subset_idxs)
+        return D, [x for x in idxs if x not in s]
+    return D
+
+
+# --------------------------------------------------------------------------- approximate K-SVD
+def approx_ksvd(Y, D, X, n_cycles=1):
+    """lyssa/dict_learning/ksvd.py:98-126.  Mutates D and X in place; returns (D, X, unused_atoms).
+
+    R = Y - DX :103; atoms visited in order 0..K-1 (Gauss-Seidel through R) :105-106;
+    omega = X[k,:]!=0, skip+record when empty :111-115; Rk = R[:,omega] + d_k x_k :116;
+    d_k = normalize(Rk x_k) :118-119; x_k = Rk' d_k :121; R[:,omega] = Rk - d_k x_k :123.
+    """
+    n_atoms = D.shape[1]
+    unused = []
+    R = Y - fast_dot(D, X)
+    for _ in range(n_cycles):
+        for k in range(n_atoms):
+            omega = X[k, :] != 0
+            if not np.any(omega):
+                unused.append(k)
+                continue
+            xk = X[k, omega]
+            Rk = R[:, omega] + np.outer(D[:, k], xk)
+            D[:, k] = normalize(np.dot(Rk, xk))
+            X[k, omega] = np.dot(Rk.T, D[:, k])
+            R[:, omega] = Rk - np.outer(D[:, k], X[k, omega])
+    return D, X, unused
+
+
+def ksvd_dict_learn(X, n_atoms, init_dict='data', encode=None, max_iter=20, n_cycles=1, verbose=True,
+                    trace=None):
+    """lyssa/dict_learning/ksvd.py:129-231, approx=True, eta=None path.
+
+    ``encode(X, D) -> dense Z`` plays the role of ``sparse_coder``.  Reproduces the host control
+    flow including the patience quirk (:222-229): error_prev is only refreshed when verbose, and
+    then *before* the test, so patience increments on every iteration it>0 and the loop stops
+    after 11 iterations whatever max_iter is.  Unused atoms are replaced from ``unused_data``
+    using the GLOBAL numpy RNG (:199-207).  ``trace`` (list) receives per-iteration dicts.
+    """
+    unused_data = []
+    if isinstance(init_dict, str) and init_dict == 'data':
+        D, unused_data = init_dictionary(X, n_atoms, method='data', return_unused_data=True)
+    else:
+        D = np.copy(init_dict)
+    max_patience = 10
+    error_curr = 0
+    error_prev = 0
+    it = 0
+    patience = 0
+    Z = np.zeros((n_atoms, X.shape[1]))
+    while it < max_iter and patience < max_patience:
+        Z = encode(X, D)
+        D, _, unused_atoms = approx_ksvd(X, D, Z, n_cycles=n_cycles)
+        for j in range(len(unused_atoms)):
+            if len(unused_data) == 0:
+                break
+            idx = np.random.choice(unused_data, size=1)[0]
+            D[:, unused_atoms[j]] = X[:, idx]
+            D[:, unused_atoms[j]] = normalize(D[:, unused_atoms[j]])
+            unused_data.remove(idx)
+        error_curr = approx_error(D, Z, X)
+        if trace is not None:
+            trace.append(dict(it=it, D=D.copy(), error=error_curr, unused_atoms=list(unused_atoms)))
+        if verbose:
+            error_prev = error_curr
+        if (it > 0) and (error_curr > 0.9 * error_prev or error_curr > error_prev):
+            patience += 1
+        it += 1
+    return D, Z
+
+
+# --------------------------------------------------------------------------- online dictionary learning
+def odl_batch_update(D, A, B, X_batch, Z_batch, beta_i, non_neg=False):
+    """One mini-batch of lyssa/dict_learning/online_dict_learn.py:84-98.
+
+    A = beta*A + ZZ' :84; B = beta*B + XZ' :85; DA = D A computed ONCE :91;
+    d_k += (B_k - DA_k)/(A_kk+eps) for every k (Jacobi-style) :93-94; clip :96-97; norm_cols :98.
+    Returns new (D, A, B); D is updated in place like the reference.
+    """
+    A = beta_i * A + fast_dot(Z_batch, Z_batch.T)
+    B = beta_i * B + fast_dot(X_batch, Z_batch.T)
+    DA = fast_dot(D, A)
+    for k in range(D.shape[1]):
+        D[:, k] = (1 / (A[k, k] + EPS64)) * (B[:, k] - DA[:, k]) + D[:, k]
+    if non_neg:
+        D[D < 0] = 0
+    D = norm_cols(D)
+    return D, A, B
+
+
+def online_dict_learn(X, n_atoms, encode=None, batch_size=None, A=None, B=None, D_init=None,
+                      beta=None, n_epochs=1, verbose=False, non_neg=False, trace=None):
+    """lyssa/dict_learning/online_dict_learn.py:18-124 (host control flow + batch update).
+
+    beta=None => linspace(0,1,n_iter) restarted every epoch (:65-67,79) -- beta[0]=0 wipes A,B.
+    Epoch-end error pass and the same patience quirk as K-SVD (:101-118).
+    """
+    n_features, n_samples = X.shape
+    if D_init is None:
+        D, _ = init_dictionary(X, n_atoms, method='data', return_unused_data=True)
+    else:
+        D = D_init
+    batch_idx = gen_batches(n_samples, batch_size=batch_size)
+    n_iter = len(batch_idx)
+    if A is None and B is None:
+        A = np.zeros((n_atoms, n_atoms))
+        B = np.zeros((n_features, n_atoms))
+    if beta is None:
+        beta = np.linspace(0, 1, num=n_iter)
+    else:
+        beta = np.zeros(n_iter) + beta
+    max_patience = 10
+    error_curr = 0
+    error_prev = 0
+    patience = 0
+    for e in range(n_epochs):
+        for i, batch in zip(range(n_iter), batch_idx):
+            Xb = X[:, batch]
+            Zb = encode(Xb, D)
+            D, A, B = odl_batch_update(D, A, B, Xb, Zb, beta[i], non_neg=non_neg)
+            if trace is not None:
+                trace.append(dict(epoch=e, batch=i, D=D.copy(), A=A.copy(), B=B.copy()))
+        if e < n_epochs - 1:
+            if patience >= max_patience:
+                return D, A, B
+            error_curr = 0
+            for i, batch in zip(range(n_iter), batch_idx):
+                Xb = X[:, batch]
+                Zb = encode(Xb, D)
+                error_curr += approx_error(D, Zb, Xb)
+            if verbose:
+                error_prev = error_curr
+            if (e > 0) and (error_curr > 0.9 * error_prev or error_curr > error_prev):
+                patience += 1
+    return D, A, B

@@ -1,0 +1,241 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (imported via oracle/ref_import.py).
+
+TEST INFRASTRUCTURE ONLY; runs only in the build container where /root/reference is mounted.
+The fixtures hold data only (seeded inputs + the reference's outputs), never reference source.
+
+Inputs are float32-representable (randn -> float32 -> float64) so that the float64 reference,
+the float64 oracle and the fp32 HIP engine all see bit-identical input values.
+
+Fixtures:
+  F1  bomp  n=64  K=256  k=5   N=512      (config-1 shape, mini)
+  F2  bomp  n=64  K=1024 k=10  N=512      (metric shape, mini)
+  F3  bomp  n=256 K=512  k=20  N=128      (config-3-like: large n, large k)
+  F4  bomp edge cases: duplicate atoms, exact 2-atom signals, zero signal, k=1, k=K=4/n=10,
+      N<100 with n_jobs=4 (empty batches in the reference's process map), non-unit-norm D
+  F5  approx K-SVD n=64 K=128 k=5 N=2000, given D0: D / Z / error / unused atoms after each of 3
+      hand-driven iterations + one full ksvd_dict_learn(max_iter=50) run (patience quirk, RNG use)
+  F6  online DL, same data, batch 500, 1 and 2 epochs, beta=None and beta=0.9: D at every encode
+      call, final D, A, B
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle.ref_import import load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def make_dict(rs, n, K):
+    D = rs.randn(n, K)
+    D /= (np.sqrt((D * D).sum(0)) + np.finfo(float).eps)
+    return f32(D)
+
+
+def quiet(fn, *a, **kw):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        return fn(*a, **kw)
+
+
+def dense_to_triplet(Z, k):
+    """Dense Z (K,N) -> (idx sorted ascending, coef, nnz).  Selection ORDER is not observable in the
+    reference's dense output, so golden supports are stored sorted."""
+    K, N = Z.shape
+    idx = -np.ones((N, k), dtype=np.int32)
+    coef = np.zeros((N, k))
+    nnz = np.zeros(N, dtype=np.int32)
+    for i in range(N):
+        nz = np.flatnonzero(Z[:, i])
+        assert len(nz) <= k
+        idx[i, :len(nz)] = nz
+        coef[i, :len(nz)] = Z[nz, i]
+        nnz[i] = len(nz)
+    return idx, coef, nnz
+
+
+def main():
+    lyssa = load_reference()
+    from lyssa.sparse_coding import sparse_encoder
+    from lyssa.dict_learning import ksvd as ref_ksvd
+    from lyssa.dict_learning import online_dict_learn as ref_odl
+    from lyssa.dict_learning.utils import approx_error as ref_approx_error
+    from oracle import lyssa_oracle as orc
+    os.makedirs(OUT, exist_ok=True)
+
+    def ref_bomp(X, D, k, n_jobs=1):
+        se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, n_jobs=n_jobs, verbose=False)
+        return quiet(se.encode, X, D)
+
+    # ---------------- F1..F3
+    for name, seed, n, K, k, N in [("F1", 101, 64, 256, 5, 512), ("F2", 102, 64, 1024, 10, 512),
+                                   ("F3", 103, 256, 512, 20, 128)]:
+        rs = np.random.RandomState(seed)
+        D = make_dict(rs, n, K)
+        X = f32(rs.randn(n, N))
+        Z = ref_bomp(X, D, k)
+        idx, coef, nnz = dense_to_triplet(Z, k)
+        _, _, _, gap = orc.bomp_encode_sparse(X, D, k)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), X=X.astype(np.float32), D=D.astype(np.float32),
+                            k=k, idx=idx, coef=coef, nnz=nnz, gap=gap)
+        print(name, "nnz hist", np.bincount(nnz), "min gap", gap.min())
+
+    # ---------------- F4 edge cases
+    rs = np.random.RandomState(104)
+    cases = {}
+    # (a) duplicate atoms: columns 4 and 5 identical
+    D = make_dict(rs, 32, 64)
+    D[:, 5] = D[:, 4]
+    X = f32(rs.randn(32, 40))
+    cases["dup"] = (X, D, 6)
+    # (b) exactly representable signals: 2-atom combinations, then a zero signal
+    D = make_dict(rs, 32, 64)
+    X = np.zeros((32, 24))
+    for i in range(23):
+        a, b = rs.choice(64, 2, replace=False)
+        X[:, i] = 2.0 * D[:, a] - 1.5 * D[:, b]
+    X = f32(X)  # last column stays exactly zero
+    cases["exact2"] = (X, D, 5)
+    # (c) k=1
+    D = make_dict(rs, 16, 48)
+    cases["k1"] = (f32(rs.randn(16, 30)), D, 1)
+    # (d) k=K=4, n=10, uniform data (shape of the reference's test_dictionary_learn)
+    D = f32(rs.rand(10, 4))
+    D /= np.sqrt((D * D).sum(0))
+    D = f32(D)
+    cases["k4K4"] = (f32(rs.rand(10, 100)), D, 4)
+    # (e) N < 100 through the reference's process pool (n_jobs=4): 99 empty batches + one of 37
+    D = make_dict(rs, 24, 80)
+    cases["pool37"] = (f32(rs.randn(24, 37)), D, 4)
+    # (f) non-unit-norm dictionary: reference hard-codes a unit Gram diagonal
+    D = make_dict(rs, 24, 80) * f32(0.5 + rs.rand(80))[None, :]
+    D = f32(D)
+    cases["nonunit"] = (f32(rs.randn(24, 50)), D, 4)
+    # (g) K not a multiple of 64, n odd
+    D = make_dict(rs, 17, 100)
+    cases["ragged"] = (f32(rs.randn(17, 33)), D, 7)
+    out = {}
+    for cname, (X, D, k) in cases.items():
+        Z = ref_bomp(X, D, k, n_jobs=4 if cname == "pool37" else 1)
+        idx, coef, nnz = dense_to_triplet(Z, k)
+        _, _, _, gap = orc.bomp_encode_sparse(X, D, k)
+        out[cname + "_X"] = X.astype(np.float32)
+        out[cname + "_D"] = D.astype(np.float32)
+        out[cname + "_k"] = k
+        out[cname + "_Z"] = Z
+        out[cname + "_gap"] = gap
+        print("F4", cname, "nnz hist", np.bincount(nnz, minlength=k + 1))
+    np.savez_compressed(os.path.join(OUT, "F4.npz"), **out)
+
+    # ---------------- F5 approx K-SVD
+    rs = np.random.RandomState(105)
+    n, K, k, N = 64, 128, 5, 2000
+    # structured data so that learning is meaningful: sparse combinations of a hidden dictionary + noise
+    Dtrue = make_dict(rs, n, K)
+    X = np.zeros((n, N))
+    for i in range(N):
+        s = rs.choice(K, k, replace=False)
+        X[:, i] = Dtrue[:, s] @ rs.randn(k)
+    X = f32(X + 0.05 * rs.randn(n, N))
+    D0 = make_dict(rs, n, K)
+    out = dict(X=X.astype(np.float32), D0=D0.astype(np.float32), k=k)
+    D = D0.copy()
+    for it in range(3):
+        Z = ref_bomp(X, D, k)
+        idx0, coef0, nnz0 = dense_to_triplet(Z, k)
+        D, Z, unused = quiet(ref_ksvd.approx_ksvd, X, D, Z, n_cycles=1)
+        idx1, coef1, nnz1 = dense_to_triplet(Z, k)
+        err = ref_approx_error(D, Z, X, n_jobs=1)
+        out["it%d_D" % it] = D.copy()
+        out["it%d_idx" % it] = idx1
+        out["it%d_coef_in" % it] = coef0
+        out["it%d_coef" % it] = coef1
+        out["it%d_nnz" % it] = nnz1
+        out["it%d_err" % it] = err
+        out["it%d_unused" % it] = np.array(unused, dtype=np.int32)
+        assert np.array_equal(idx0, idx1)
+        print("F5 it", it, "err", err, "unused", unused)
+    # n_cycles=2 single call from D0
+    D = D0.copy()
+    Z = ref_bomp(X, D, k)
+    D, Z, unused = quiet(ref_ksvd.approx_ksvd, X, D, Z, n_cycles=2)
+    out["cyc2_D"] = D.copy()
+    out["cyc2_err"] = ref_approx_error(D, Z, X, n_jobs=1)
+    # full driver: patience quirk + global RNG; count encode calls
+    calls = []
+
+    class counting_coder(object):
+        def __init__(self):
+            self.se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, n_jobs=1, verbose=False)
+            self.verbose = False
+            self.mmap = False
+
+        def __call__(self, X_, D_):
+            calls.append(1)
+            return self.se.encode(X_, D_)
+
+    for verbose in (True, False):
+        del calls[:]
+        np.random.seed(1234)
+        Dl, Zl = quiet(ref_ksvd.ksvd_dict_learn, X[:, :600], 32, init_dict='data', sparse_coder=counting_coder(),
+                       max_iter=50, approx=True, n_cycles=1, verbose=verbose)
+        tag = "full_v%d" % int(verbose)
+        out[tag + "_D"] = Dl
+        out[tag + "_ncalls"] = len(calls)
+        out[tag + "_rng_after"] = np.random.randint(0, 2 ** 31 - 1)
+        print("F5", tag, "encode calls", len(calls))
+    # ndarray init_dict, few iterations
+    del calls[:]
+    Dl, Zl = quiet(ref_ksvd.ksvd_dict_learn, X[:, :600], 128, init_dict=D0.copy(), sparse_coder=counting_coder(),
+                   max_iter=2, approx=True, n_cycles=1, verbose=False)
+    out["init_nd_D"] = Dl
+    i_, c_, z_ = dense_to_triplet(Zl, k)
+    out["init_nd_idx"], out["init_nd_coef"], out["init_nd_nnz"] = i_, c_, z_
+    np.savez_compressed(os.path.join(OUT, "F5.npz"), **out)
+
+    # ---------------- F6 online dictionary learning
+    out = dict(k=k, batch_size=500)  # X and D0 are F5.npz's (not duplicated)
+
+    class recording_coder(object):
+        def __init__(self, log):
+            self.se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, n_jobs=1, verbose=False)
+            self.verbose = False
+            self.log = log
+
+        def __call__(self, X_, D_):
+            self.log.append(np.array(D_, copy=True))
+            return self.se.encode(X_, D_)
+
+    for tag, n_epochs, beta in [("e1", 1, None), ("e2", 2, None), ("e1b", 1, 0.9)]:
+        log = []
+        Dl, Al, Bl = quiet(ref_odl.online_dict_learn, X, K, sparse_coder=recording_coder(log), batch_size=500,
+                           D_init=D0.copy(), beta=beta, n_epochs=n_epochs, verbose=False)
+        out[tag + "_D"] = Dl
+        out[tag + "_A"] = Al
+        out[tag + "_B"] = Bl
+        out[tag + "_ncalls"] = len(log)
+        out[tag + "_Dlog"] = np.stack(log[:3])
+        print("F6", tag, "encode calls", len(log))
+    # warm start through the class API: fit twice (A,B fed back, D_init not refreshed)
+    coder = ref_odl.online_dictionary_coder(n_atoms=K, sparse_coder=recording_coder([]), batch_size=500,
+                                            D_init=D0.copy(), beta=0.5, n_epochs=1)
+    quiet(coder.fit, X[:, :1000])
+    quiet(coder.fit, X[:, 1000:])
+    out["warm_D"], out["warm_A"], out["warm_B"] = coder.D, coder.A, coder.B
+    np.savez_compressed(os.path.join(OUT, "F6.npz"), **out)
+
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden bytes:", tot)
+
+
+if __name__ == "__main__":
+    main()

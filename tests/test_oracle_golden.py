@@ -1,0 +1,167 @@
+"""Pin the CPU oracle (oracle/lyssa_oracle.py) against outputs of the reference itself.
+
+The golden vectors under tests/golden/ were produced by oracle/make_golden.py, which imports the
+reference (py3-converted) in the build container.  Bar: identical supports, values within 1e-12.
+"""
+import numpy as np
+import pytest
+
+from oracle import lyssa_oracle as orc
+from conftest import load_golden
+
+
+def _triplet_sorted(Z, k):
+    N = Z.shape[1]
+    idx = -np.ones((N, k), dtype=np.int32)
+    coef = np.zeros((N, k))
+    nnz = np.zeros(N, dtype=np.int32)
+    for i in range(N):
+        nz = np.flatnonzero(Z[:, i])
+        idx[i, :len(nz)] = nz
+        coef[i, :len(nz)] = Z[nz, i]
+        nnz[i] = len(nz)
+    return idx, coef, nnz
+
+
+@pytest.mark.parametrize("name", ["F1", "F2", "F3"])
+def test_bomp_matches_reference(name):
+    g = load_golden(name)
+    X = g["X"].astype(np.float64).copy()
+    D = g["D"].astype(np.float64).copy()
+    k = int(g["k"])
+    Z = orc.bomp_encode(X, D, k)
+    idx, coef, nnz = _triplet_sorted(Z, k)
+    assert np.array_equal(idx, g["idx"])
+    assert np.array_equal(nnz, g["nnz"])
+    assert np.max(np.abs(coef - g["coef"])) <= 1e-12
+    # the sparse-triplet form of the oracle agrees with its own dense form
+    si, sc, sn, gap = orc.bomp_encode_sparse(X, D, k)
+    assert np.array_equal(orc.densify(si, sc, sn, D.shape[1]), Z)
+    assert np.allclose(gap, g["gap"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", ["dup", "exact2", "k1", "k4K4", "pool37", "nonunit", "ragged"])
+def test_bomp_edge_cases_match_reference(case):
+    g = load_golden("F4")
+    X = g[case + "_X"].astype(np.float64)
+    D = g[case + "_D"].astype(np.float64)
+    k = int(g[case + "_k"])
+    Z = orc.bomp_encode(X, D, k)
+    Zr = g[case + "_Z"]
+    assert Z.shape == Zr.shape
+    if case == "exact2":
+        # once the residual is ~1e-16 relative the selection is rounding noise:
+        # compare the significant part only, the noise part must be tiny in both.
+        big = np.abs(Zr) > 1e-10
+        assert np.array_equal(np.abs(Z) > 1e-10, big)
+        assert np.max(np.abs(Z[big] - Zr[big])) <= 1e-12
+        assert np.max(np.abs(Z[~big])) < 1e-12 and np.max(np.abs(Zr[~big])) < 1e-12
+        assert np.all(Z[:, -1] == 0)  # zero signal -> zero column
+    else:
+        assert np.array_equal(Z != 0, Zr != 0)
+        assert np.max(np.abs(Z - Zr)) <= 1e-12
+
+
+def test_approx_ksvd_matches_reference():
+    g = load_golden("F5")
+    X = g["X"].astype(np.float64)
+    D = g["D0"].astype(np.float64).copy()
+    k = int(g["k"])
+    for it in range(3):
+        Z = orc.bomp_encode(X, D, k)
+        D, Z, unused = orc.approx_ksvd(X, D, Z, n_cycles=1)
+        idx, coef, nnz = _triplet_sorted(Z, k)
+        assert np.array_equal(idx, g["it%d_idx" % it])
+        assert np.max(np.abs(coef - g["it%d_coef" % it])) <= 1e-10
+        assert np.max(np.abs(D - g["it%d_D" % it])) <= 1e-10
+        assert list(unused) == list(g["it%d_unused" % it])
+        assert abs(orc.approx_error(D, Z, X) - float(g["it%d_err" % it])) <= 1e-8 * float(g["it%d_err" % it])
+    D = g["D0"].astype(np.float64).copy()
+    Z = orc.bomp_encode(X, D, k)
+    D, Z, _ = orc.approx_ksvd(X, D, Z, n_cycles=2)
+    assert np.max(np.abs(D - g["cyc2_D"])) <= 1e-10
+
+
+@pytest.mark.parametrize("verbose", [True, False])
+def test_ksvd_driver_matches_reference(verbose):
+    """Host control flow: patience quirk (11 encode calls for max_iter=50) and global-RNG consumption."""
+    g = load_golden("F5")
+    X = g["X"].astype(np.float64)[:, :600]
+    k = int(g["k"])
+    calls = []
+
+    def enc(X_, D_):
+        calls.append(1)
+        return orc.bomp_encode(X_, D_, k)
+
+    np.random.seed(1234)
+    D, Z = orc.ksvd_dict_learn(X, 32, init_dict='data', encode=enc, max_iter=50, verbose=verbose)
+    tag = "full_v%d" % int(verbose)
+    assert len(calls) == int(g[tag + "_ncalls"]) == 11
+    assert np.max(np.abs(D - g[tag + "_D"])) <= 1e-9
+    assert np.random.randint(0, 2 ** 31 - 1) == int(g[tag + "_rng_after"])
+
+
+def test_ksvd_driver_ndarray_init():
+    g = load_golden("F5")
+    X = g["X"].astype(np.float64)[:, :600]
+    k = int(g["k"])
+    D, Z = orc.ksvd_dict_learn(X, 128, init_dict=g["D0"].astype(np.float64),
+                               encode=lambda X_, D_: orc.bomp_encode(X_, D_, k), max_iter=2, verbose=False)
+    assert np.max(np.abs(D - g["init_nd_D"])) <= 1e-10
+    idx, coef, nnz = _triplet_sorted(Z, k)
+    assert np.array_equal(idx, g["init_nd_idx"])
+    assert np.max(np.abs(coef - g["init_nd_coef"])) <= 1e-10
+
+
+@pytest.mark.parametrize("tag,n_epochs,beta", [("e1", 1, None), ("e2", 2, None), ("e1b", 1, 0.9)])
+def test_online_dict_learn_matches_reference(tag, n_epochs, beta):
+    g5 = load_golden("F5")
+    g = load_golden("F6")
+    X = g5["X"].astype(np.float64)
+    D0 = g5["D0"].astype(np.float64)
+    k = int(g["k"])
+    log = []
+
+    def enc(X_, D_):
+        log.append(np.array(D_, copy=True))
+        return orc.bomp_encode(X_, D_, k)
+
+    D, A, B = orc.online_dict_learn(X, D0.shape[1], encode=enc, batch_size=int(g["batch_size"]),
+                                    D_init=D0.copy(), beta=beta, n_epochs=n_epochs)
+    assert len(log) == int(g[tag + "_ncalls"])
+    for i, Dl in enumerate(g[tag + "_Dlog"]):
+        assert np.max(np.abs(log[i] - Dl)) <= 1e-10
+    assert np.max(np.abs(D - g[tag + "_D"])) <= 1e-9
+    assert np.max(np.abs(A - g[tag + "_A"])) <= 1e-9 * max(1.0, np.abs(g[tag + "_A"]).max())
+    assert np.max(np.abs(B - g[tag + "_B"])) <= 1e-9 * max(1.0, np.abs(g[tag + "_B"]).max())
+
+
+def test_batching_helpers():
+    # lyssa/utils/__init__.py:166-201 (behaviour recorded in SURVEY appendix A)
+    b = orc.gen_even_batches(37, 100)
+    assert len(b) == 100 and all(len(x) == 0 for x in b[:99]) and list(b[99]) == list(range(37))
+    b = orc.gen_even_batches(250, 100)
+    assert [len(x) for x in b] == [2] * 99 + [52]
+    assert [list(x) for x in orc.gen_batches(7, 3)] == [[0, 1, 2], [3, 4, 5], [6]]
+    assert [list(x) for x in orc.gen_batches(6, 3)] == [[0, 1, 2], [3, 4, 5]]
+    assert [list(x) for x in orc.gen_batches(5, None)] == [[0, 1, 2, 3, 4]]
+
+
+def test_omp_invariants():
+    """Algebraic properties of OMP (independent of the reference): |support|<=k, coefficients = least
+    squares on the support, residual orthogonal to the selected atoms."""
+    rs = np.random.RandomState(7)
+    n, K, k, N = 24, 60, 5, 40
+    D = rs.randn(n, K)
+    D /= np.sqrt((D * D).sum(0))
+    X = rs.randn(n, N)
+    idx, coef, nnz, _ = orc.bomp_encode_sparse(X, D, k)
+    for i in range(N):
+        m = nnz[i]
+        assert m == k and len(set(idx[i, :m])) == m
+        S = idx[i, :m]
+        ls = np.linalg.lstsq(D[:, S], X[:, i], rcond=None)[0]
+        assert np.allclose(coef[i, :m], ls, atol=1e-10)
+        r = X[:, i] - D[:, S] @ coef[i, :m]
+        assert np.max(np.abs(D[:, S].T @ r)) < 1e-10
