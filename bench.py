@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- Batch-OMP encode throughput on MI355X (the metric of BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--signals S] [--no-cpu-baseline]
+
+One *step* = one pass of the hot path (`lys_bomp_encode`: alpha0 = X D MFMA GEMM + wave-per-signal greedy /
+Cholesky kernel, sparse-triplet output) over one batch of S synthetic Gaussian 64-dim patches per GPU against a
+1024-atom dictionary with k = 10 -- the encode step of configs[1] ("Approx-K-SVD 1M 8x8 patches, 1024 atoms,
+k=10"), the configuration the metric is quoted on.  Inputs are resident in HBM when the timed region starts.
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the signal batch is sharded: every rank encodes
+its own S patches against the replicated dictionary, no data-path collective (weak scaling);
+value = N*S*K_steps / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     -- dominant kernel (greedy/Cholesky stage) priced against the fp32 MFMA/VALU peak with HIP-event
+                  durations taken inside the timed region; also the GEMM stage and the whole step
+  cpu_baseline -- the float64 numpy port of the reference path (oracle/) timed on this host's cores on a bounded
+                  sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FEATURES, N_ATOMS, K_NNZ = 64, 1024, 10
+PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_signal(n, K, k):
+    """F = 2nK (alpha0) + K k (k+1) (correlation updates) + k^3 (Cholesky/solves)."""
+    return 2 * n * K, K * k * (k + 1) + k ** 3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--signals", type=int, default=1 << 20, help="patches per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from lyssandra_amd import _lib, engine
+    lib = _lib.load()
+
+    n, K, k, S = N_FEATURES, N_ATOMS, K_NNZ, args.signals
+    # synthetic Gaussian patches (fp32, signal-major) and a unit-norm Gaussian dictionary, generated on the device.
+    # every rank draws a different shard of the global batch; the dictionary is the same everywhere.
+    gd = torch.Generator(device=dev).manual_seed(1234)
+    Dt = torch.randn((n, K), device=dev, generator=gd)
+    Dt = Dt / (Dt.norm(dim=0, keepdim=True) + float(np.finfo(np.float64).eps))
+    gx = torch.Generator(device=dev).manual_seed(1000 + rank)
+    Xs = torch.randn((S, n), device=dev, generator=gx)
+    dd = engine.DeviceDictionary(n, K, dev)
+    dd.set(Dt)
+    dd.gram()
+    out = (torch.empty((S, k), dtype=torch.int32, device=dev), torch.empty((S, k), dtype=torch.float32, device=dev),
+           torch.empty((S,), dtype=torch.int32, device=dev))
+
+    def step():
+        engine.bomp_encode(Xs, dd, k, out=out)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _lib.check(lib.lys_profile_enable(1), "lys_profile_enable")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    g_ms, o_ms = ctypes.c_double(), ctypes.c_double()
+    launches, psig = ctypes.c_int(), ctypes.c_int64()
+    _lib.check(lib.lys_profile_collect(ctypes.byref(g_ms), ctypes.byref(o_ms), ctypes.byref(launches),
+                                       ctypes.byref(psig)), "lys_profile_collect")
+    _lib.check(lib.lys_profile_enable(0), "lys_profile_enable")
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_patches = float(S) * world * args.steps
+    value = total_patches / elapsed
+    f_gemm, f_omp = flops_per_signal(n, K, k)
+    result = None
+    if rank == 0:
+        nl = max(1, launches.value)
+        sig_per_launch = psig.value / nl
+        omp_avg_ms = o_ms.value / nl
+        gemm_avg_ms = g_ms.value / nl
+        omp_tf = f_omp * sig_per_launch / (omp_avg_ms * 1e-3) / 1e12 if omp_avg_ms > 0 else 0.0
+        gemm_tf = f_gemm * sig_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms > 0 else 0.0
+        step_tf = (f_gemm + f_omp) * (value / world) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bomp_wave_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "patches/sec Batch-OMP (1024 atoms, k=10, 64-dim)",
+            "value": value,
+            "unit": "patches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Batch-OMP encode step of configs[1] (approx-K-SVD 1M 8x8 patches): n=64, K=1024 "
+                                   "atoms, k=10, %d Gaussian patches per GPU per step, device-resident sparse output" % S,
+                       "signals_per_gpu": S, "n_features": n, "n_atoms": K, "n_nonzero_coefs": k,
+                       "sharding": "signals sharded over %d rank(s), dictionary replicated, no data-path collective"
+                                   % world},
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "bomp_wave_kernel<16,10> (greedy argmax + progressive Cholesky, one wave per signal)",
+                "achieved": omp_tf,
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": omp_tf / PEAK_FP32_TFLOPS,
+                "traffic": traffic,
+                "flop_per_patch": f_omp,
+                "patches_per_launch": sig_per_launch,
+                "avg_launch_ms": omp_avg_ms,
+                "launches_timed": launches.value,
+                "gemm_stage": {"kernel": "gemm_nt_f32_kernel (alpha0 = X D, v_mfma_f32_32x32x2_f32)",
+                               "achieved": gemm_tf, "frac": gemm_tf / PEAK_FP32_TFLOPS, "flop_per_patch": f_gemm,
+                               "avg_launch_ms": gemm_avg_ms},
+                "whole_step": {"achieved": step_tf, "frac": step_tf / PEAK_FP32_TFLOPS,
+                               "flop_per_patch": f_gemm + f_omp},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(Xs, Dt, k, args.cpu_sample)
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def cpu_baseline(Xs, Dt, k, sample):
+    """The reference CPU path (float64 numpy/scipy port in oracle/, same per-signal structure as
+    lyssa/sparse_coding.py:302-367 + :629-635, n_jobs=1) on a bounded sample of the SAME patches."""
+    import numpy as np
+    from oracle import lyssa_oracle as orc
+    X = Xs[:sample].t().contiguous().double().cpu().numpy()
+    D = Dt.double().cpu().numpy()
+    t0 = time.perf_counter()
+    Z = orc.bomp_encode(X, D, k)
+    dt = time.perf_counter() - t0
+    assert Z.shape == (D.shape[1], X.shape[1])
+    return {"value": X.shape[1] / dt, "unit": "patches/s", "cores": 1, "kind": "port",
+            "sample": "first %d patches of rank 0's batch, float64 numpy/scipy port of batch_omp (n_jobs=1), %.1f s"
+                      % (X.shape[1], dt),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

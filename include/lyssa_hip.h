@@ -1,0 +1,162 @@
+/*
+ * lyssa_hip.h -- C-ABI of the MI355X (gfx950) sparse-coding engine.
+ *
+ * The reference (ektormak/Lyssandra, pure Python 2 + numpy/OpenBLAS) has NO native interface for
+ * this path: its only FFI is ctypes -> libopenblas (lyssa/utils/config.py:36-45).  The boundary a
+ * maintainer binds is therefore this header, loaded with ctypes.CDLL exactly like the reference
+ * loads libopenblas; INTEGRATION.md shows the stub.  Each entry point cites the reference lines
+ * whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  All pointers are DEVICE pointers unless the
+ *     name ends in _host.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - layouts (fp32, row-major):
+ *       X    signal-major [N][ldx]   (ldx >= n)          one 64-dim patch = one 256-B row
+ *       D    atom-major   [Kp][ldd]  (Kp = lys_padded_atoms(K), ldd = lys_padded_features(n)),
+ *            rows >= K and columns >= n are ZERO (lys_pack_dictionary builds it)
+ *       G    [Kp][Kp] Gram matrix of the packed dictionary
+ *       Z    sparse triplet: idx int32 [N][k] (selection order, -1 padded), coef fp32 [N][k]
+ *            (0 padded), nnz int32 [N] (= number of selected atoms, the reference's len(Dx))
+ *   - every function returns 0 on success, a negative LYS_E* code on failure; the message is
+ *     available from lys_last_error() (thread-local).  Nothing throws or aborts across the ABI.
+ *   - calls are asynchronous on `stream` unless stated otherwise; the caller owns all buffers.
+ */
+#ifndef LYSSA_HIP_H
+#define LYSSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LYS_OK 0
+#define LYS_EINVAL (-1)   /* bad argument                                   */
+#define LYS_EHIP (-2)     /* HIP runtime error (message has the HIP string) */
+#define LYS_ENOSUP (-3)   /* shape outside what the kernels support         */
+#define LYS_EWORKSPACE (-4) /* workspace too small                          */
+
+const char* lys_last_error(void);
+int lys_version(void);
+/* number of visible HIP devices, name and CU count of device `dev` (host strings) */
+int lys_device_info(int dev, char* name_host, int name_cap, int* n_cu_host, size_t* hbm_bytes_host);
+
+/* ---- shape helpers (host, pure) --------------------------------------------------------------- */
+int lys_padded_atoms(int K);     /* next of {64,128,256,512,1024} or multiple of 1024 above      */
+int lys_padded_features(int n);  /* next multiple of 8                                            */
+
+/* ---- dictionary ------------------------------------------------------------------------------- */
+/* Pack a dictionary given atom-major [K][n] (dense, ld = n) into the padded layout [Kp][ldd]. */
+int lys_pack_dictionary(const float* D_src, int n, int K, float* D_packed, void* stream);
+/* G = D'D  -- replaces `Gram = fast_dot(D.T, D)` lyssa/sparse_coding.py:630 (fp32 MFMA GEMM). */
+int lys_gram(const float* D_packed, int n, int K, float* G, void* stream);
+
+/* ---- Batch-OMP encode ------------------------------------------------------------------------- */
+/* Bytes of scratch lys_bomp_encode needs for at most `N` signals per call (alpha0 tile buffer). */
+size_t lys_bomp_workspace_bytes(int n, int K, int k, int64_t N);
+/*
+ * Batch-OMP of N signals -- replaces `Alpha = fast_dot(D.T, X)` (sparse_coding.py:631) and the
+ * per-signal loop `batch_omp` (sparse_coding.py:302-367): greedy argmax|a| with lowest-index
+ * tie-break, break on re-selection, unit-diagonal incremental Cholesky with the `1 - w'w < eps`
+ * break, coefficients by the two triangular solves.  fp32 throughout.
+ * Signals are processed in tiles that fit `workspace`; results are written as the sparse triplet.
+ */
+int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const float* G,
+                    int n, int K, int k, int64_t N,
+                    int32_t* idx, float* coef, int32_t* nnz,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* Only the alpha0 = X D GEMM of the above (timing / MFMA-stage measurement). alpha0 is [N][Kp]. */
+int lys_alpha0(const float* X, int64_t ldx, const float* D_packed, int n, int K, int64_t N,
+               float* alpha0, void* stream);
+/* Only the greedy/Cholesky stage, from a precomputed alpha0 [N][Kp] (timing / tests). */
+int lys_bomp_from_alpha0(const float* alpha0, const float* G, int K, int k, int64_t N,
+                         int32_t* idx, float* coef, int32_t* nnz, void* stream);
+
+/* ---- residual / error -------------------------------------------------------------------------- */
+/*
+ * R = X - D Z (signal-major [N][ldr]) and err = ||X - D Z||_F^2 accumulated in fp64 into *err_dev
+ * (which the caller zeroes).  Replaces `R = Y - fast_dot(D, X)` lyssa/dict_learning/ksvd.py:103 and
+ * `approx_error` lyssa/dict_learning/utils.py:14-19.  R may be NULL (error only); err_dev may be NULL.
+ */
+int lys_residual(const float* X, int64_t ldx, const float* D_packed, int n, int K, int k, int64_t N,
+                 const int32_t* idx, const float* coef, const int32_t* nnz,
+                 float* R, int64_t ldr, double* err_dev, void* stream);
+
+/* ---- atom-major index of the non-zeros (CSR by atom) ------------------------------------------ */
+/* Scratch bytes for lys_csr_by_atom. */
+size_t lys_csr_workspace_bytes(int K, int k, int64_t N);
+/*
+ * Deterministic counting sort of the N*k (signal, slot) entries by atom id, signals ascending
+ * inside an atom.  Entries with slot >= nnz or coef == 0 are dropped: this is the reference's
+ * `omega_k = X[k, :] != 0` (ksvd.py:111).  row_ptr int32 [K+1]; entry int32 [N*k] holds
+ * signal*k + slot.
+ */
+int lys_csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N,
+                    int32_t* row_ptr, int32_t* entry, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- approximate K-SVD atom update (ksvd.py:105-123) ------------------------------------------ */
+/*
+ * Phase 1 for atom `atom`: s[f] += sum_{i in omega} R_i[f] * x_i  and  s[n] += sum x_i^2, fp64
+ * atomics into sbuf[atom][n+1] (caller zeroes sbuf once per cycle).  In a multi-GPU run the caller
+ * all-reduces sbuf[atom] between phase 1 and phase 2.
+ */
+int lys_ksvd_atom_accumulate(int atom, const float* R, int64_t ldr, int n, int k,
+                             const int32_t* row_ptr, const int32_t* entry, const float* coef,
+                             double* sbuf, void* stream);
+/*
+ * Phase 2: d_new = normalize(s + d_old * sumsq) (x/(||x||+eps), utils/math.py:61-62);
+ * x_i <- R_i'd_new + x_i (d_old'd_new); R_i <- R_i + d_old x_i_old - d_new x_i; d_new -> D_next[atom].
+ * D (packed) is read-only here; lys_ksvd_commit copies D_next rows of used atoms into D.
+ */
+int lys_ksvd_atom_apply(int atom, float* R, int64_t ldr, int n, int k,
+                        const int32_t* row_ptr, const int32_t* entry, float* coef,
+                        const double* sbuf, const float* D_packed, float* D_next, void* stream);
+/* Whole cycle on one GPU (atoms 0..K-1 in order, both phases, then commit); sbuf is zeroed inside. */
+int lys_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k,
+                   const int32_t* row_ptr, const int32_t* entry, float* coef,
+                   double* sbuf, float* D_packed, float* D_next, void* stream);
+int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, float* D_packed, void* stream);
+
+/* ---- online dictionary learning (online_dict_learn.py:84-98) ---------------------------------- */
+/*
+ * dA = Z Z' (K x K, ld = Kp), dB = X Z' stored atom-major [Kp][ldd] -- the per-batch increments of
+ * `A = beta*A + fast_dot(Z, Z.T)`, `B = beta*B + fast_dot(X, Z.T)` (:84-85), computed from the
+ * sparse triplet through the CSR-by-atom index.  In a multi-GPU run dA|dB are all-reduced.
+ */
+int lys_odl_increments(const float* X, int64_t ldx, int n, int K, int k,
+                       const int32_t* idx, const float* coef, const int32_t* nnz,
+                       const int32_t* row_ptr, const int32_t* entry,
+                       float* dA, float* dB, void* stream);
+/* y = beta*y + x over `count` floats (the beta*A + dA of :84-85). */
+int lys_axpby(float* y, float beta, const float* x, int64_t count, void* stream);
+/*
+ * Dictionary update of one mini-batch (:91-98): DA = D A once (MFMA GEMM), d_k += (B_k - DA_k) /
+ * (A_kk + eps) for all k, optional clipping to >= 0, column normalisation x/(||x||+eps).
+ * scratch: 2*Kp*ldd floats.
+ */
+int lys_odl_update(float* D_packed, const float* A, const float* B, int n, int K, int non_neg,
+                   float* scratch, void* stream);
+
+/* ---- small utilities --------------------------------------------------------------------------- */
+/* Column normalisation of the packed dictionary, x/(||x||+eps) (utils/math.py:65-71). */
+int lys_norm_atoms(float* D_packed, int n, int K, void* stream);
+/* Sparse triplet -> dense fp64 Z (K x N, row-major, the reference's return type, sparse_coding.py:365). */
+int lys_densify_f64(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N,
+                    double* Z, void* stream);
+/*
+ * Per-stage HIP-event profile of lys_bomp_encode: when enabled, every tile records events before the
+ * alpha0 GEMM, between GEMM and greedy kernel, and after the greedy kernel, on the caller's stream.
+ * lys_profile_collect synchronises on them, returns the summed kernel durations (ms), the number of
+ * launches per stage and the signals they covered, and resets the counters.
+ */
+int lys_profile_enable(int on);
+int lys_profile_collect(double* gemm_ms_host, double* omp_ms_host, int* launches_host, int64_t* signals_host);
+/* HIP-event timing helpers (events live inside the library; ids 0..63). */
+int lys_event_record(int id, void* stream);
+int lys_event_elapsed_ms(int id_start, int id_stop, float* ms_host); /* synchronises on id_stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LYSSA_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of liblyssa_hip.so (the C-ABI declared in include/lyssa_hip.h).
+
+Mirrors how the reference reaches its only native library (ctypes.cdll.LoadLibrary of libopenblas,
+lyssa/utils/config.py:36-45) -- but unlike the reference, a missing library is a hard error: there is
+no CPU fallback anywhere in this package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("LYSSA_HIP_LIB", os.path.join(_HERE, "liblyssa_hip.so"))
+
+c_i32p = ctypes.c_void_p
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+_Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol of include/lyssa_hip.h
+SIGNATURES = {
+    "lys_last_error": (ctypes.c_char_p, []),
+    "lys_version": (_I, []),
+    "lys_device_info": (_I, [_I, ctypes.c_char_p, _I, ctypes.POINTER(_I), ctypes.POINTER(_Z)]),
+    "lys_padded_atoms": (_I, [_I]),
+    "lys_padded_features": (_I, [_I]),
+    "lys_pack_dictionary": (_I, [_P, _I, _I, _P, _P]),
+    "lys_gram": (_I, [_P, _I, _I, _P, _P]),
+    "lys_bomp_workspace_bytes": (_Z, [_I, _I, _I, _L]),
+    "lys_bomp_encode": (_I, [_P, _L, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P, _Z, _P]),
+    "lys_alpha0": (_I, [_P, _L, _P, _I, _I, _L, _P, _P]),
+    "lys_bomp_from_alpha0": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P]),
+    "lys_residual": (_I, [_P, _L, _P, _I, _I, _I, _L, _P, _P, _P, _P, _L, _P, _P]),
+    "lys_csr_workspace_bytes": (_Z, [_I, _I, _L]),
+    "lys_csr_by_atom": (_I, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _Z, _P]),
+    "lys_ksvd_atom_accumulate": (_I, [_I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
+    "lys_ksvd_atom_apply": (_I, [_I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "lys_ksvd_sweep": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "lys_ksvd_commit": (_I, [_I, _I, _P, _P, _P, _P]),
+    "lys_odl_increments": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "lys_axpby": (_I, [_P, _F, _P, _L, _P]),
+    "lys_odl_update": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "lys_norm_atoms": (_I, [_P, _I, _I, _P]),
+    "lys_densify_f64": (_I, [_P, _P, _P, _I, _I, _L, _P, _P]),
+    "lys_profile_enable": (_I, [_I]),
+    "lys_profile_collect": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                 ctypes.POINTER(_I), ctypes.POINTER(_L)]),
+    "lys_event_record": (_I, [_I, _P]),
+    "lys_event_elapsed_ms": (_I, [_I, _I, ctypes.POINTER(_F)]),
+}
+
+
+class LyssaHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises LyssaHipError if it is missing: no fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LyssaHipError(
+            "HIP engine library not found at %s -- build it with `python -m lyssandra_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise LyssaHipError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().lys_last_error().decode("utf-8", "replace")
+        raise LyssaHipError("%s failed (code %d): %s" % (what or "liblyssa_hip call", rc, msg))
+
+
+def padded_atoms(K):
+    return load().lys_padded_atoms(int(K))
+
+
+def padded_features(n):
+    return load().lys_padded_features(int(n))

@@ -1,0 +1,314 @@
+// extern "C" surface of liblyssa_hip.so -- see include/lyssa_hip.h for the contract.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace lys {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int num_cus() {
+    static thread_local int cached_dev = -1;
+    static thread_local int cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cached_dev = dev;
+        cached_cus = prop.multiProcessorCount;
+    }
+    return cached_cus > 0 ? cached_cus : 256;
+}
+
+// implemented in the kernel translation units
+int gemm_nt(const float*, int64_t, const float*, int64_t, float*, int64_t, int64_t, int, int, hipStream_t);
+int pack_dictionary(const float*, int, int, float*, hipStream_t);
+bool bomp_has_wave_kernel(int Kp, int k);
+size_t bomp_generic_scratch_bytes(int Kp, int k);
+int bomp_from_alpha0(const float*, const float*, int, int, int64_t, int32_t*, float*, int32_t*, float*, hipStream_t);
+int residual(const float*, int64_t, const float*, int, int, int, int64_t, const int32_t*, const float*, const int32_t*,
+             float*, int64_t, double*, hipStream_t);
+size_t csr_workspace_bytes(int, int, int64_t);
+int csr_by_atom(const int32_t*, const float*, const int32_t*, int, int, int64_t, int32_t*, int32_t*, void*, size_t,
+                hipStream_t);
+int ksvd_atom_accumulate(int, const float*, int64_t, int, int, const int32_t*, const int32_t*, const float*, double*,
+                         hipStream_t);
+int ksvd_atom_apply(int, float*, int64_t, int, int, const int32_t*, const int32_t*, float*, const double*,
+                    const float*, float*, hipStream_t);
+int ksvd_commit(int, int, const int32_t*, const float*, float*, hipStream_t);
+int ksvd_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
+               hipStream_t);
+int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const float*, const int32_t*, const int32_t*,
+                   const int32_t*, float*, float*, hipStream_t);
+int axpby(float*, float, const float*, int64_t, hipStream_t);
+int odl_update(float*, const float*, const float*, int, int, int, float*, hipStream_t);
+int norm_atoms(float*, int, int, hipStream_t);
+int densify_f64(const int32_t*, const float*, const int32_t*, int, int, int64_t, double*, hipStream_t);
+
+// alpha0 tile: how many signals per GEMM+OMP round.  ~128 MiB of alpha0 keeps the producer->consumer
+// hand-off inside the 256 MiB Infinity Cache instead of HBM.
+static int64_t tile_signals(int Kp) {
+    const int64_t bytes = 128ll << 20;
+    int64_t t = bytes / ((int64_t)Kp * 4);
+    t = (t / 512) * 512;
+    return t < 512 ? 512 : t;
+}
+
+static hipEvent_t g_events[64];
+static bool g_event_made[64];
+
+// ---- optional per-stage HIP-event profile of lys_bomp_encode (bench.py's roofline object) --------------
+struct StageProfile {
+    bool on = false;
+    static constexpr int CAP = 3 * 4096;
+    hipEvent_t ev[CAP];
+    int made = 0;  // events created so far
+    int used = 0;  // events recorded since the last collect (3 per tile: before GEMM, after GEMM, after OMP)
+    int64_t signals = 0;
+};
+static StageProfile g_prof;
+
+static int prof_mark(hipStream_t stream) {
+    if (g_prof.used >= StageProfile::CAP) return LYS_OK;  // silently stop profiling, never fail the encode
+    if (g_prof.used >= g_prof.made) {
+        LYS_CHECK_HIP(hipEventCreate(&g_prof.ev[g_prof.made]));
+        g_prof.made++;
+    }
+    LYS_CHECK_HIP(hipEventRecord(g_prof.ev[g_prof.used], stream));
+    g_prof.used++;
+    return LYS_OK;
+}
+
+}  // namespace lys
+
+using namespace lys;
+
+#define STREAM(s) (static_cast<hipStream_t>(s))
+
+extern "C" {
+
+const char* lys_last_error(void) { return g_err; }
+int lys_version(void) { return 100; }
+
+int lys_device_info(int dev, char* name_host, int name_cap, int* n_cu_host, size_t* hbm_bytes_host) {
+    int count = 0;
+    LYS_CHECK_HIP(hipGetDeviceCount(&count));
+    LYS_REQUIRE(dev >= 0 && dev < count, "device %d out of range (%d visible)", dev, count);
+    hipDeviceProp_t prop;
+    LYS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name_host && name_cap > 0) {
+        snprintf(name_host, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (n_cu_host) *n_cu_host = prop.multiProcessorCount;
+    if (hbm_bytes_host) *hbm_bytes_host = prop.totalGlobalMem;
+    return count;
+}
+
+int lys_padded_atoms(int K) { return padded_atoms(K); }
+int lys_padded_features(int n) { return padded_features(n); }
+
+int lys_pack_dictionary(const float* D_src, int n, int K, float* D_packed, void* stream) {
+    LYS_REQUIRE(D_src && D_packed && n > 0 && K > 0, "pack_dictionary: bad arguments");
+    return pack_dictionary(D_src, n, K, D_packed, STREAM(stream));
+}
+
+int lys_gram(const float* D_packed, int n, int K, float* G, void* stream) {
+    LYS_REQUIRE(D_packed && G && n > 0 && K > 0, "gram: bad arguments");
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    return gemm_nt(D_packed, ldd, D_packed, ldd, G, Kp, Kp, Kp, ldd, STREAM(stream));
+}
+
+size_t lys_bomp_workspace_bytes(int n, int K, int k, int64_t N) {
+    const int Kp = padded_atoms(K);
+    int64_t t = tile_signals(Kp);
+    if (N < t) t = (N < 1) ? 1 : N;
+    size_t bytes = (size_t)t * (size_t)Kp * sizeof(float);
+    if (!bomp_has_wave_kernel(Kp, k)) bytes += bomp_generic_scratch_bytes(Kp, k);
+    return bytes;
+}
+
+int lys_alpha0(const float* X, int64_t ldx, const float* D_packed, int n, int K, int64_t N, float* alpha0,
+               void* stream) {
+    LYS_REQUIRE(X && D_packed && alpha0 && n > 0 && K > 0 && N >= 0 && ldx >= n, "alpha0: bad arguments");
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    // the dictionary is zero-padded to ldd columns, so reading the first n columns of X is all that is needed
+    return gemm_nt(X, ldx, D_packed, ldd, alpha0, Kp, N, Kp, n, STREAM(stream));
+}
+
+int lys_bomp_from_alpha0(const float* alpha0, const float* G, int K, int k, int64_t N, int32_t* idx, float* coef,
+                         int32_t* nnz, void* stream) {
+    LYS_REQUIRE(alpha0 && G && idx && coef && nnz && K > 0 && N >= 0, "bomp_from_alpha0: bad arguments");
+    const int Kp = padded_atoms(K);
+    LYS_REQUIRE(k >= 1 && k <= 64, "n_nonzero_coefs must be in [1,64], got %d", k);
+    if (!bomp_has_wave_kernel(Kp, k)) {
+        set_error("bomp_from_alpha0: (K=%d,k=%d) needs the generic kernel; use lys_bomp_encode", K, k);
+        return LYS_ENOSUP;
+    }
+    return bomp_from_alpha0(alpha0, G, Kp, k, N, idx, coef, nnz, nullptr, STREAM(stream));
+}
+
+int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K, int k, int64_t N,
+                    int32_t* idx, float* coef, int32_t* nnz, void* workspace, size_t workspace_bytes, void* stream) {
+    LYS_REQUIRE(X && D_packed && G && idx && coef && nnz, "bomp_encode: null pointer");
+    LYS_REQUIRE(n > 0 && K > 0 && N >= 0 && ldx >= n, "bomp_encode: bad shape n=%d K=%d N=%lld ldx=%lld", n, K,
+                (long long)N, (long long)ldx);
+    LYS_REQUIRE(k >= 1 && k <= 64, "n_nonzero_coefs must be in [1,64], got %d", k);
+    if (N == 0) return LYS_OK;
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    const bool wave = bomp_has_wave_kernel(Kp, k);
+    const size_t gen_bytes = wave ? 0 : bomp_generic_scratch_bytes(Kp, k);
+    if (workspace == nullptr || workspace_bytes <= gen_bytes ||
+        (workspace_bytes - gen_bytes) < (size_t)Kp * sizeof(float)) {
+        set_error("bomp_encode: workspace too small (%zu bytes)", workspace_bytes);
+        return LYS_EWORKSPACE;
+    }
+    float* gen = wave ? nullptr : static_cast<float*>(workspace);
+    float* alpha0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + gen_bytes);
+    int64_t tile = (int64_t)((workspace_bytes - gen_bytes) / ((size_t)Kp * sizeof(float)));
+    const int64_t pref = tile_signals(Kp);
+    if (tile > pref) tile = pref;
+    for (int64_t s0 = 0; s0 < N; s0 += tile) {
+        const int64_t cnt = (N - s0 < tile) ? N - s0 : tile;
+        const bool prof = g_prof.on && g_prof.used + 3 <= StageProfile::CAP;
+        int rc;
+        if (prof && (rc = prof_mark(STREAM(stream)))) return rc;
+        rc = gemm_nt(X + s0 * ldx, ldx, D_packed, ldd, alpha0, Kp, cnt, Kp, n, STREAM(stream));
+        if (rc) return rc;
+        if (prof && (rc = prof_mark(STREAM(stream)))) return rc;
+        rc = bomp_from_alpha0(alpha0, G, Kp, k, cnt, idx + s0 * k, coef + s0 * k, nnz + s0, gen, STREAM(stream));
+        if (rc) return rc;
+        if (prof) {
+            if ((rc = prof_mark(STREAM(stream)))) return rc;
+            g_prof.signals += cnt;
+        }
+    }
+    return LYS_OK;
+}
+
+int lys_residual(const float* X, int64_t ldx, const float* D_packed, int n, int K, int k, int64_t N,
+                 const int32_t* idx, const float* coef, const int32_t* nnz, float* R, int64_t ldr, double* err_dev,
+                 void* stream) {
+    LYS_REQUIRE(X && D_packed && idx && coef && nnz, "residual: null pointer");
+    LYS_REQUIRE(R == nullptr || ldr >= n, "residual: ldr < n");
+    return residual(X, ldx, D_packed, n, K, k, N, idx, coef, nnz, R, ldr, err_dev, STREAM(stream));
+}
+
+size_t lys_csr_workspace_bytes(int K, int k, int64_t N) { return csr_workspace_bytes(K, k, N); }
+
+int lys_csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N,
+                    int32_t* row_ptr, int32_t* entry, void* workspace, size_t workspace_bytes, void* stream) {
+    LYS_REQUIRE(idx && coef && nnz && row_ptr && entry && workspace, "csr_by_atom: null pointer");
+    return csr_by_atom(idx, coef, nnz, K, k, N, row_ptr, entry, workspace, workspace_bytes, STREAM(stream));
+}
+
+int lys_ksvd_atom_accumulate(int atom, const float* R, int64_t ldr, int n, int k, const int32_t* row_ptr,
+                             const int32_t* entry, const float* coef, double* sbuf, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && coef && sbuf && (ldr % 4) == 0, "ksvd_atom_accumulate: bad arguments");
+    return ksvd_atom_accumulate(atom, R, ldr, n, k, row_ptr, entry, coef, sbuf, STREAM(stream));
+}
+
+int lys_ksvd_atom_apply(int atom, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,
+                        float* coef, const double* sbuf, const float* D_packed, float* D_next, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && coef && sbuf && D_packed && D_next && (ldr % 4) == 0,
+                "ksvd_atom_apply: bad arguments");
+    return ksvd_atom_apply(atom, R, ldr, n, k, row_ptr, entry, coef, sbuf, D_packed, D_next, STREAM(stream));
+}
+
+int lys_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
+                   float* coef, double* sbuf, float* D_packed, float* D_next, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && coef && sbuf && D_packed && D_next && (ldr % 4) == 0,
+                "ksvd_sweep: bad arguments");
+    return ksvd_sweep(R, ldr, n, K, k, row_ptr, entry, coef, sbuf, D_packed, D_next, STREAM(stream));
+}
+
+int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, float* D_packed, void* stream) {
+    LYS_REQUIRE(row_ptr && D_next && D_packed, "ksvd_commit: null pointer");
+    return ksvd_commit(n, K, row_ptr, D_next, D_packed, STREAM(stream));
+}
+
+int lys_odl_increments(const float* X, int64_t ldx, int n, int K, int k, const int32_t* idx, const float* coef,
+                       const int32_t* nnz, const int32_t* row_ptr, const int32_t* entry, float* dA, float* dB,
+                       void* stream) {
+    LYS_REQUIRE(X && idx && coef && nnz && row_ptr && entry && dA && dB, "odl_increments: null pointer");
+    return odl_increments(X, ldx, n, K, k, idx, coef, nnz, row_ptr, entry, dA, dB, STREAM(stream));
+}
+
+int lys_axpby(float* y, float beta, const float* x, int64_t count, void* stream) {
+    LYS_REQUIRE(y && x, "axpby: null pointer");
+    return axpby(y, beta, x, count, STREAM(stream));
+}
+
+int lys_odl_update(float* D_packed, const float* A, const float* B, int n, int K, int non_neg, float* scratch,
+                   void* stream) {
+    LYS_REQUIRE(D_packed && A && B && scratch, "odl_update: null pointer");
+    return odl_update(D_packed, A, B, n, K, non_neg, scratch, STREAM(stream));
+}
+
+int lys_norm_atoms(float* D_packed, int n, int K, void* stream) {
+    LYS_REQUIRE(D_packed, "norm_atoms: null pointer");
+    return norm_atoms(D_packed, n, K, STREAM(stream));
+}
+
+int lys_densify_f64(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, double* Z,
+                    void* stream) {
+    LYS_REQUIRE(idx && coef && nnz && Z, "densify: null pointer");
+    return densify_f64(idx, coef, nnz, K, k, N, Z, STREAM(stream));
+}
+
+int lys_profile_enable(int on) {
+    g_prof.on = (on != 0);
+    if (!on) {
+        g_prof.used = 0;
+        g_prof.signals = 0;
+    }
+    return LYS_OK;
+}
+
+int lys_profile_collect(double* gemm_ms_host, double* omp_ms_host, int* launches_host, int64_t* signals_host) {
+    double g = 0.0, o = 0.0;
+    const int tiles = g_prof.used / 3;
+    for (int t = 0; t < tiles; ++t) {
+        float a = 0.f, b = 0.f;
+        LYS_CHECK_HIP(hipEventSynchronize(g_prof.ev[3 * t + 2]));
+        LYS_CHECK_HIP(hipEventElapsedTime(&a, g_prof.ev[3 * t], g_prof.ev[3 * t + 1]));
+        LYS_CHECK_HIP(hipEventElapsedTime(&b, g_prof.ev[3 * t + 1], g_prof.ev[3 * t + 2]));
+        g += a;
+        o += b;
+    }
+    if (gemm_ms_host) *gemm_ms_host = g;
+    if (omp_ms_host) *omp_ms_host = o;
+    if (launches_host) *launches_host = tiles;
+    if (signals_host) *signals_host = g_prof.signals;
+    g_prof.used = 0;
+    g_prof.signals = 0;
+    return LYS_OK;
+}
+
+int lys_event_record(int id, void* stream) {
+    LYS_REQUIRE(id >= 0 && id < 64, "event id out of range");
+    if (!g_event_made[id]) {
+        LYS_CHECK_HIP(hipEventCreate(&g_events[id]));
+        g_event_made[id] = true;
+    }
+    LYS_CHECK_HIP(hipEventRecord(g_events[id], STREAM(stream)));
+    return LYS_OK;
+}
+
+int lys_event_elapsed_ms(int id_start, int id_stop, float* ms_host) {
+    LYS_REQUIRE(id_start >= 0 && id_start < 64 && id_stop >= 0 && id_stop < 64 && ms_host, "event id out of range");
+    LYS_REQUIRE(g_event_made[id_start] && g_event_made[id_stop], "event not recorded");
+    LYS_CHECK_HIP(hipEventSynchronize(g_events[id_stop]));
+    LYS_CHECK_HIP(hipEventElapsedTime(ms_host, g_events[id_start], g_events[id_stop]));
+    return LYS_OK;
+}
+
+}  // extern "C"

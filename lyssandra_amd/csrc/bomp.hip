@@ -1,0 +1,405 @@
+// Batch-OMP greedy stage for gfx950 -- restates lyssa/sparse_coding.py:302-367 (`batch_omp`).
+//
+// One 64-lane wavefront per signal.  The K correlations a[] live in registers (R = Kp/64 per lane), the
+// selected-atom state is kept in the *progressive* (orthogonalised) form so that no triangular solve and
+// no re-read of earlier Gram rows is needed inside the loop:
+//
+//     step j:  kk   = argmax |a|                      (first maximum wins, like np.argmax :322)
+//              stop if kk was selected before          (:323-325)
+//              w_i  = p_i[kk]              (i<j)       == L^-1 G[Dx,kk]            (:341 / :331)
+//              vs   = 1 - sum w_i^2 ; stop if vs<eps   unit Gram diagonal is HARD-CODED (:333-335,343-346)
+//              rho  = sqrt(vs)                         new Cholesky row is [w, rho]  (:337-338,348-349)
+//              t_j  = a[kk] / rho                      == (L^-1 a0[Dx])_j           (:353)
+//              p_j  = (G[kk,:] - sum_i w_i p_i) / rho  == column j of G[:,Dx] L^-T
+//              a   -= t_j p_j                          == a0 - G[:,Dx] z             (:359)
+//     end:     z    = L^-T t                           second triangular solve       (:354)
+//
+// Algebraically identical to the reference for ANY dictionary (also non-normalised ones: the reference's
+// L is the Cholesky factor of G[Dx,Dx] with its diagonal replaced by 1, and so is ours), but only j FMAs per
+// correlation per step and one 4-KB Gram row read per step.  Register budget at K=1024, k=10:
+// (k+1)*16 = 176 VGPRs of vectors -> 2 waves/SIMD.
+//
+// Element r = c*V + e of lane l holds atom c*64*V + l*V + e  (V = min(R,4): one coalesced dwordx4 per chunk).
+#include "common.h"
+
+namespace lys {
+
+template <int R>
+struct Lay {
+    static constexpr int V = (R >= 4) ? 4 : R;
+    static constexpr int C = R / V;
+    static constexpr int Kp = 64 * R;
+    __device__ static __forceinline__ int atom(int r, int lane) { return (r / V) * (64 * V) + lane * V + (r % V); }
+    __device__ static __forceinline__ int lane_of(int atom) { return (atom / V) & 63; }
+    __device__ static __forceinline__ int reg_of(int atom) { return (atom / (64 * V)) * V + (atom % V); }
+};
+
+template <int R>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int lane, float (&v)[R]) {
+    using L = Lay<R>;
+    if constexpr (L::V == 4) {
+#pragma unroll
+        for (int c = 0; c < L::C; ++c) {
+            const float4 t = reinterpret_cast<const float4*>(row)[c * 64 + lane];
+            v[4 * c + 0] = t.x;
+            v[4 * c + 1] = t.y;
+            v[4 * c + 2] = t.z;
+            v[4 * c + 3] = t.w;
+        }
+    } else if constexpr (L::V == 2) {
+        const float2 t = reinterpret_cast<const float2*>(row)[lane];
+        v[0] = t.x;
+        v[1] = t.y;
+    } else {
+        v[0] = row[lane];
+    }
+}
+
+// Uniform extraction  w[i] = p[i][rr](lane L)  for i < J, with rr only known at run time (wave-uniform):
+// an if-chain over rr keeps every register index static (dynamic VGPR indexing would go to scratch).
+template <int R, int KMAX, int J, int RR>
+__device__ __forceinline__ void extract_case(const float (&p)[KMAX][R], int rr, int L, float (&w)[KMAX]) {
+    if constexpr (RR < R) {
+        if (rr == RR) {
+#pragma unroll
+            for (int i = 0; i < J; ++i) w[i] = readlane_f(p[i][RR], L);
+        } else {
+            extract_case<R, KMAX, J, RR + 1>(p, rr, L, w);
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ bool wave_argmax(const float (&a)[R], int lane, int& kk, float& akk, int& Lown, int& rown) {
+    using L = Lay<R>;
+    float best = fabsf(a[0]);
+#pragma unroll
+    for (int r = 1; r < R; ++r) best = fmaxf(best, fabsf(a[r]));
+    const float m = wave_max_f(best);
+    const unsigned long long bal = __ballot(best == m);
+    if (bal == 0ull) return false;  // NaN correlations: nothing sensible to select
+    const unsigned mbits = __builtin_bit_cast(unsigned, m);
+    if (__popcll(bal) == 1) {
+        // common case: a single lane owns the maximum -> resolve its register with scalar compares
+        const int Lo = __builtin_ctzll(bal);
+        int rsel = 0;
+        unsigned vsel = 0;
+#pragma unroll
+        for (int r = R - 1; r >= 0; --r) {
+            const unsigned sv = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, a[r]), Lo);
+            const bool hit = (sv & 0x7fffffffu) == mbits;
+            rsel = hit ? r : rsel;
+            vsel = hit ? sv : vsel;
+        }
+        Lown = Lo;
+        rown = rsel;
+        kk = L::atom(rsel, Lo);
+        akk = __builtin_bit_cast(float, vsel);
+        return true;
+    }
+    // ties across lanes (duplicate atoms, all-zero signal): lowest atom index wins, exactly like np.argmax
+    int cand = 0x7fffffff;
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+        const bool hit = fabsf(a[r]) == m;
+        cand = hit ? L::atom(r, lane) : cand;
+    }
+    kk = wave_min_i(cand);
+    Lown = L::lane_of(kk);
+    rown = L::reg_of(kk);
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) v = (r == rown) ? a[r] : v;
+    akk = readlane_f(v, Lown);
+    return true;
+}
+
+template <int R, int KMAX>
+struct OmpState {
+    float a[R];         // current correlations
+    float p[KMAX][R];   // orthogonalised Gram columns
+    float Lrow[KMAX];   // Lrow[j] lane i (<j) = L[j][i]
+    float tv;           // lane j = t_j
+    float rinv;         // lane j = 1/rho_j
+    int dxv;            // lane j = Dx[j]
+    int nsel;
+};
+
+// Steps J..KMAX-1 as a compile-time recursion (a loop with early exits around the convergent cross-lane
+// operations is not unrolled by the compiler, which would push p[][] to scratch).
+template <int R, int KMAX, int J>
+__device__ __forceinline__ void omp_steps(OmpState<R, KMAX>& s, const float* __restrict__ G, int k, int lane) {
+    using L = Lay<R>;
+    if constexpr (J < KMAX) {
+        if (J >= k) return;
+        int kk, Lown, rown;
+        float akk;
+        if (!wave_argmax<R>(s.a, lane, kk, akk, Lown, rown)) return;
+        // re-selection => stop (sparse_coding.py:323-325)
+        if (__ballot(lane < J && s.dxv == kk) != 0ull) return;
+        // Gram row of the new atom (G is symmetric: row kk == column kk), issued before the scalar work
+        float g[R];
+        load_row<R>(G + (int64_t)kk * L::Kp, lane, g);
+
+        float w[KMAX];
+        extract_case<R, KMAX, J, 0>(s.p, rown, Lown, w);
+        float vs = 1.f;
+#pragma unroll
+        for (int i = 0; i < J; ++i) vs = fmaf(-w[i], w[i], vs);
+        if (J > 0 && vs < EPS32_F) return;  // reference: vs < eps (:335,345); the fp32 engine uses fp32 eps
+        const float rho = sqrtf(vs);
+        const float inv = 1.f / rho;
+        const float t = akk * inv;
+
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc = g[r];
+#pragma unroll
+            for (int i = 0; i < J; ++i) acc = fmaf(-w[i], s.p[i][r], acc);
+            acc *= inv;
+            s.p[J][r] = acc;
+            s.a[r] = fmaf(-t, acc, s.a[r]);
+        }
+        float lr = 0.f;
+#pragma unroll
+        for (int i = 0; i < J; ++i) lr = writelane_f(w[i], i, lr, lane);
+        s.Lrow[J] = lr;
+        s.tv = writelane_f(t, J, s.tv, lane);
+        s.rinv = writelane_f(inv, J, s.rinv, lane);
+        s.dxv = writelane_i(kk, J, s.dxv, lane);
+        s.nsel = J + 1;
+        omp_steps<R, KMAX, J + 1>(s, G, k, lane);
+    }
+}
+
+template <int R, int KMAX, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void bomp_wave_kernel(const float* __restrict__ alpha0,
+                                                                        const float* __restrict__ G, int64_t N, int k,
+                                                                        int32_t* __restrict__ idx_out,
+                                                                        float* __restrict__ coef_out,
+                                                                        int32_t* __restrict__ nnz_out) {
+    using L = Lay<R>;
+    const int lane = threadIdx.x & 63;
+    const int64_t sig = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sig >= N) return;
+
+    OmpState<R, KMAX> s;
+    load_row<R>(alpha0 + sig * L::Kp, lane, s.a);
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) s.Lrow[j] = 0.f;
+    s.tv = 0.f;
+    s.rinv = 0.f;
+    s.dxv = -1;
+    s.nsel = 0;
+    omp_steps<R, KMAX, 0>(s, G, k, lane);
+    const int nsel = s.nsel;
+
+    // z = L^-T t  (second triangular solve, sparse_coding.py:354), column-oriented over lanes
+    float zv = s.tv, zout = 0.f;
+#pragma unroll
+    for (int i = KMAX - 1; i >= 0; --i) {
+        if (i < nsel) {
+            const float zi = readlane_f(zv, i) * readlane_f(s.rinv, i);
+            zout = (lane == i) ? zi : zout;
+            zv = fmaf(-zi, s.Lrow[i], zv);
+        }
+    }
+    if (lane < k) {
+        idx_out[sig * k + lane] = (lane < nsel) ? s.dxv : -1;
+        coef_out[sig * k + lane] = (lane < nsel) ? zout : 0.f;
+    }
+    if (lane == 0) nnz_out[sig] = nsel;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic kernel: any Kp (multiple of 64) and any k <= 64.  One 256-thread workgroup per signal, the
+// correlations and the p-vectors live in a per-workgroup global scratch slab (L2-resident), L in LDS.
+// Same arithmetic, used for K > 1024 (config 3: K=4096, k=20) and for k beyond the register kernels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restrict__ alpha0,
+                                                            const float* __restrict__ G, int Kp, int64_t N, int k,
+                                                            float* __restrict__ scratch,  // [grid][(k+1)*Kp]
+                                                            int32_t* __restrict__ idx_out,
+                                                            float* __restrict__ coef_out,
+                                                            int32_t* __restrict__ nnz_out) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    __shared__ float s_w[64];
+    __shared__ float s_L[64 * 64];
+    __shared__ float s_t[64], s_rinv[64], s_z[64];
+    __shared__ int s_dx[64];
+    __shared__ float s_akk;
+    __shared__ int s_kk, s_stop;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float* a = scratch + (int64_t)blockIdx.x * (int64_t)(k + 1) * Kp;
+    float* P = a + Kp;  // P[i][Kp]
+
+    for (int64_t sig = blockIdx.x; sig < N; sig += gridDim.x) {
+        for (int x = tid; x < Kp; x += 256) a[x] = alpha0[sig * Kp + x];
+        if (tid == 0) s_stop = 0;
+        __syncthreads();
+        int nsel = 0;
+        for (int j = 0; j < k; ++j) {
+            // ---- argmax |a| with lowest-index tie-break
+            float best = -1.f;
+            int bi = 0x7fffffff;
+            for (int x = tid; x < Kp; x += 256) {
+                const float v = fabsf(a[x]);
+                if (v > best) {
+                    best = v;
+                    bi = x;
+                }
+            }
+            const float m = wave_max_f(best);
+            const int ci = wave_min_i((best == m) ? bi : 0x7fffffff);
+            if (lane == 0) {
+                s_val[wid] = m;
+                s_idx[wid] = ci;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float mm = s_val[0];
+                int kk = s_idx[0];
+                for (int q = 1; q < 4; ++q) {
+                    if (s_val[q] > mm || (s_val[q] == mm && s_idx[q] < kk)) {
+                        mm = s_val[q];
+                        kk = s_idx[q];
+                    }
+                }
+                bool stop = !(mm == mm) || kk == 0x7fffffff;
+                for (int i = 0; i < j && !stop; ++i) stop = (s_dx[i] == kk);
+                s_kk = kk;
+                s_stop = stop ? 1 : 0;
+                if (!stop) s_akk = a[kk];
+            }
+            __syncthreads();
+            if (s_stop) break;
+            const int kk = s_kk;
+            // ---- w_i = p_i[kk]
+            if (tid < j) s_w[tid] = P[(int64_t)tid * Kp + kk];
+            __syncthreads();
+            if (tid == 0) {
+                float vs = 1.f;
+                for (int i = 0; i < j; ++i) vs = fmaf(-s_w[i], s_w[i], vs);
+                if (j > 0 && vs < EPS32_F) {
+                    s_stop = 1;
+                } else {
+                    const float rho = sqrtf(vs);
+                    const float inv = 1.f / rho;
+                    s_rinv[j] = inv;
+                    s_t[j] = s_akk * inv;
+                    s_dx[j] = kk;
+                    for (int i = 0; i < j; ++i) s_L[j * 64 + i] = s_w[i];
+                }
+            }
+            __syncthreads();
+            if (s_stop) break;
+            const float inv = s_rinv[j], t = s_t[j];
+            float* pj = P + (int64_t)j * Kp;
+            const float* grow = G + (int64_t)kk * Kp;
+            for (int x = tid; x < Kp; x += 256) {
+                float acc = grow[x];
+                for (int i = 0; i < j; ++i) acc = fmaf(-s_w[i], P[(int64_t)i * Kp + x], acc);
+                acc *= inv;
+                pj[x] = acc;
+                a[x] = fmaf(-t, acc, a[x]);
+            }
+            nsel = j + 1;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = nsel - 1; i >= 0; --i) {
+                float zi = s_t[i];
+                for (int mI = i + 1; mI < nsel; ++mI) zi = fmaf(-s_L[mI * 64 + i], s_z[mI], zi);
+                s_z[i] = zi * s_rinv[i];
+            }
+            nnz_out[sig] = nsel;
+        }
+        __syncthreads();
+        if (tid < k) {
+            idx_out[sig * k + tid] = (tid < nsel) ? s_dx[tid] : -1;
+            coef_out[sig * k + tid] = (tid < nsel) ? s_z[tid] : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int R, int KMAX>
+static int launch_wave(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
+                       hipStream_t stream) {
+    constexpr int regs = (KMAX + 2) * R + KMAX + 40;
+    constexpr int W = (regs > 256) ? 1 : (regs > 168) ? 2 : (regs > 128) ? 3 : (regs > 96) ? 4 : 5;
+    const int64_t blocks = (N + 3) / 4;
+    if (blocks > 0x7fffffffLL) {
+        set_error("bomp: too many signals per launch (%lld)", (long long)N);
+        return LYS_ENOSUP;
+    }
+    hipLaunchKernelGGL((bomp_wave_kernel<R, KMAX, W>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N, k,
+                       idx, coef, nnz);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+template <int R>
+static int dispatch_k(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
+                      hipStream_t stream) {
+    if (k <= 5) return launch_wave<R, 5>(alpha0, G, N, k, idx, coef, nnz, stream);
+    if (k <= 10) return launch_wave<R, 10>(alpha0, G, N, k, idx, coef, nnz, stream);
+    if constexpr (R <= 8) {
+        if (k <= 20) return launch_wave<R, 20>(alpha0, G, N, k, idx, coef, nnz, stream);
+    }
+    if constexpr (R <= 4) {
+        if (k <= 32) return launch_wave<R, 32>(alpha0, G, N, k, idx, coef, nnz, stream);
+    }
+    return 1;  // not covered by a register kernel
+}
+
+// true when (K,k) is served by a register-resident wave kernel
+bool bomp_has_wave_kernel(int Kp, int k) {
+    if (Kp > 1024) return false;
+    const int R = Kp / 64;
+    if (k <= 10) return true;
+    if (k <= 20) return R <= 8;
+    if (k <= 32) return R <= 4;
+    return false;
+}
+
+size_t bomp_generic_scratch_bytes(int Kp, int k) {
+    const int grid = num_cus() * 4;
+    return (size_t)grid * (size_t)(k + 1) * (size_t)Kp * sizeof(float);
+}
+
+int bomp_from_alpha0(const float* alpha0, const float* G, int Kp, int k, int64_t N, int32_t* idx, float* coef,
+                     int32_t* nnz, float* generic_scratch, hipStream_t stream) {
+    if (N <= 0) return LYS_OK;
+    if (k < 1 || k > 64) {
+        set_error("bomp: n_nonzero_coefs must be in [1,64], got %d", k);
+        return LYS_ENOSUP;
+    }
+    int rc = 1;
+    if (bomp_has_wave_kernel(Kp, k)) {
+        switch (Kp / 64) {
+            case 1: rc = dispatch_k<1>(alpha0, G, N, k, idx, coef, nnz, stream); break;
+            case 2: rc = dispatch_k<2>(alpha0, G, N, k, idx, coef, nnz, stream); break;
+            case 4: rc = dispatch_k<4>(alpha0, G, N, k, idx, coef, nnz, stream); break;
+            case 8: rc = dispatch_k<8>(alpha0, G, N, k, idx, coef, nnz, stream); break;
+            case 16: rc = dispatch_k<16>(alpha0, G, N, k, idx, coef, nnz, stream); break;
+            default: rc = 1;
+        }
+    }
+    if (rc != 1) return rc;
+    if (generic_scratch == nullptr) {
+        set_error("bomp: generic kernel needs scratch (K=%d, k=%d)", Kp, k);
+        return LYS_EWORKSPACE;
+    }
+    const int grid = (int)((N < (int64_t)num_cus() * 4) ? N : (int64_t)num_cus() * 4);
+    hipLaunchKernelGGL(bomp_generic_kernel, dim3(grid), dim3(256), 0, stream, alpha0, G, Kp, N, k, generic_scratch,
+                       idx, coef, nnz);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+}  // namespace lys

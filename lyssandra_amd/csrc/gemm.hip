@@ -1,0 +1,179 @@
+// fp32 MFMA "NT" GEMM for gfx950:  C[M x Nc] = A[M x Kin] * B[Nc x Kin]^T   (all row-major).
+//
+// Used for   G      = D'D      (A = B = packed dictionary)            lyssa/sparse_coding.py:630
+//            alpha0 = X D      (A = signals, B = packed dictionary)    lyssa/sparse_coding.py:631
+//            DA     = A_odl D  (A = A_odl, B = D^T feature-major)      lyssa/dict_learning/online_dict_learn.py:91
+//
+// v_mfma_f32_32x32x2_f32: exact fp32 (bitwise a k-ordered fmaf chain), 64 FLOP/clk/SIMD.
+// Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 2 x 2 MFMA tiles
+// (64 accumulator registers).  K is consumed in slabs of 32 staged through LDS with a row stride of
+// 36 floats: a lane reads its operand as ONE ds_read_b128 (4 consecutive k) which feeds 4 MFMAs, and
+// 36 = 4 (mod 32) makes the 16-lane ds_read_b128 groups conflict-free (MI355X_MICROARCH.md, LDS).
+// The k-pairing inside an MFMA is (8q+e, 8q+4+e): any pairing is valid because the sum runs over all k.
+#include "common.h"
+
+namespace lys {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GM_BM = 128, GM_BN = 128, GM_BK = 32, GM_LD = GM_BK + 4;
+
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int64_t lda,
+                                                           const float* __restrict__ B, int64_t ldb,
+                                                           float* __restrict__ C, int64_t ldc,
+                                                           int64_t M, int Nc, int Kin) {
+    __shared__ __attribute__((aligned(16))) float As[GM_BM * GM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[GM_BN * GM_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    // column tiles are the fast grid dimension so that consecutive blocks share the A (signal) tile
+    const int n_ct = (Nc + GM_BN - 1) / GM_BN;
+    const int64_t bm = (int64_t)(blockIdx.x / n_ct) * GM_BM;
+    const int bn = (blockIdx.x % n_ct) * GM_BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lrow = tid >> 3;        // 0..31
+    const int lc4 = (tid & 7) * 4;    // 0,4,..,28
+    const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+
+    for (int k0 = 0; k0 < Kin; k0 += GM_BK) {
+        // ---- stage A and B slabs (coalesced: 8 threads x 16 B = one 128-B row segment)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lrow + 32 * i;
+            const int kc = k0 + lc4;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            const int64_t ga = bm + r;
+            if (ga < M) {
+                const float* p = A + ga * lda + kc;
+                if (a_vec && kc + 3 < Kin) {
+                    va = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (kc + 0 < Kin) va.x = p[0];
+                    if (kc + 1 < Kin) va.y = p[1];
+                    if (kc + 2 < Kin) va.z = p[2];
+                    if (kc + 3 < Kin) va.w = p[3];
+                }
+            }
+            const int gb = bn + r;
+            if (gb < Nc) {
+                const float* p = B + (int64_t)gb * ldb + kc;
+                if (b_vec && kc + 3 < Kin) {
+                    vb = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (kc + 0 < Kin) vb.x = p[0];
+                    if (kc + 1 < Kin) vb.y = p[1];
+                    if (kc + 2 < Kin) vb.z = p[2];
+                    if (kc + 3 < Kin) vb.w = p[3];
+                }
+            }
+            *reinterpret_cast<float4*>(&As[r * GM_LD + lc4]) = va;
+            *reinterpret_cast<float4*>(&Bs[r * GM_LD + lc4]) = vb;
+        }
+        __syncthreads();
+        // ---- MFMA over the slab
+        const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int q = 0; q < GM_BK / 8; ++q) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + l31) * GM_LD + q * 8 + h * 4]);
+                b[i] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + i * 32 + l31) * GM_LD + q * 8 + h * 4]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+    const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M && col < Nc) C[row * ldc + col] = acc[i][j][r];
+            }
+        }
+}
+
+int gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int Nc,
+            int Kin, hipStream_t stream) {
+    if (M <= 0 || Nc <= 0) return LYS_OK;
+    const int64_t n_rt = (M + GM_BM - 1) / GM_BM;
+    const int n_ct = (Nc + GM_BN - 1) / GM_BN;
+    const int64_t blocks = n_rt * n_ct;
+    if (blocks > 0x7fffffffLL) {
+        set_error("gemm_nt: grid too large (%lld blocks)", (long long)blocks);
+        return LYS_ENOSUP;
+    }
+    hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, Nc,
+                       Kin);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// ---- small helpers living with the GEMM ---------------------------------------------------------
+__global__ void pack_dictionary_kernel(const float* __restrict__ src, int n, int K, float* __restrict__ dst, int ldd,
+                                       int Kp) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)Kp * ldd) return;
+    const int a = (int)(t / ldd), f = (int)(t % ldd);
+    dst[t] = (a < K && f < n) ? src[(int64_t)a * n + f] : 0.f;
+}
+
+int pack_dictionary(const float* src, int n, int K, float* dst, hipStream_t stream) {
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    const int64_t tot = (int64_t)Kp * ldd;
+    hipLaunchKernelGGL(pack_dictionary_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, n, K,
+                       dst, ldd, Kp);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// dst[f][a] = src[a][f]  (packed dictionary -> feature-major copy used by the online-DL update GEMM)
+__global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, int lds_, float* __restrict__ dst,
+                                 int ldd_) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = by + i, c = bx + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = bx + i, c = by + threadIdx.x;  // dst row = src col
+        if (r < cols && c < rows) dst[(int64_t)r * ldd_ + c] = tile[threadIdx.x][i];
+    }
+}
+
+int transpose(const float* src, int rows, int cols, int ld_src, float* dst, int ld_dst, hipStream_t stream) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(32, 8);
+    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, stream, src, rows, cols, ld_src, dst, ld_dst);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+}  // namespace lys

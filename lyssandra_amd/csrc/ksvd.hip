@@ -1,0 +1,376 @@
+// Dictionary-update kernels for gfx950: sparse residual / error, atom-major index of the non-zeros,
+// and the approximate K-SVD atom update (lyssa/dict_learning/ksvd.py:98-126).
+//
+// Data layout (HBM-bound byte shuffling, no MFMA here): residual R is signal-major [N][ldr] so that one
+// signal is one contiguous 4*n-byte row; a 16-lane DPP row ("team") owns one signal at a time and moves it
+// with one dwordx4 per lane per 64 features.  Per (atom, signal) non-zero the sweep reads and writes the
+// residual row once per phase: algorithmic traffic 2*4n B (phase 1 read + phase 2 read/write = 3*4n B moved).
+#include "common.h"
+
+namespace lys {
+
+// ---------------------------------------------------------------------------------------------
+// R = X - D Z  and  err += ||R||^2      (ksvd.py:103, dict_learning/utils.py:14-19)
+// one wave per signal, lane f handles features f, f+64, ...
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__ X, int64_t ldx,
+                                                       const float* __restrict__ D, int ldd, int n, int k, int64_t N,
+                                                       const int32_t* __restrict__ idx,
+                                                       const float* __restrict__ coef,
+                                                       const int32_t* __restrict__ nnz, float* __restrict__ R,
+                                                       int64_t ldr, double* __restrict__ err) {
+    __shared__ double s_part[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wid, nwaves = (int64_t)gridDim.x * 4;
+    double acc = 0.0;
+    for (int64_t s = wave; s < N; s += nwaves) {
+        const int m = nnz[s];
+        float e2 = 0.f;
+        for (int f = lane; f < n; f += 64) {
+            float r = X[s * ldx + f];
+            for (int j = 0; j < m; ++j) {
+                const int a = idx[s * k + j];
+                r = fmaf(-coef[s * k + j], D[(int64_t)a * ldd + f], r);
+            }
+            if (R) R[s * ldr + f] = r;
+            e2 = fmaf(r, r, e2);
+        }
+        acc += (double)wave_sum_f(e2);
+    }
+    if (err) {
+        if (lane == 0) s_part[wid] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(err, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+    }
+}
+
+int residual(const float* X, int64_t ldx, const float* D, int n, int K, int k, int64_t N, const int32_t* idx,
+             const float* coef, const int32_t* nnz, float* R, int64_t ldr, double* err, hipStream_t stream) {
+    if (N <= 0) return LYS_OK;
+    const int ldd = padded_features(n);
+    int64_t blocks = (N + 3) / 4;
+    const int64_t cap = (int64_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, ldx, D, ldd, n, k, N, idx,
+                       coef, nnz, R, ldr, err);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSR by atom: deterministic counting sort of (signal, slot) entries by atom id.
+// The signal range is cut into T chunks; ONE wave walks a chunk signal by signal (so the order inside an
+// atom is the signal order), counting into LDS.  Pass A counts, pass B scans (atom-major, chunk-minor),
+// pass C scatters.  Entries with slot >= nnz or coef == 0 are dropped (omega_k = X[k,:] != 0, ksvd.py:111).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void csr_count_or_fill_kernel(const int32_t* __restrict__ idx,
+                                                               const float* __restrict__ coef,
+                                                               const int32_t* __restrict__ nnz, int K, int k, int64_t N,
+                                                               int T, int64_t S, int32_t* __restrict__ counts,
+                                                               int32_t* __restrict__ entry, int fill) {
+    extern __shared__ int s_cnt[];
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x;
+    for (int a = lane; a < K; a += 64) s_cnt[a] = fill ? counts[(int64_t)a * T + chunk] : 0;
+    __syncthreads();
+    const int64_t s0 = (int64_t)chunk * S;
+    const int64_t s1 = (s0 + S < N) ? s0 + S : N;
+    for (int64_t s = s0; s < s1; ++s) {
+        const int m = nnz[s];
+        for (int j = lane; j < m; j += 64) {
+            const int a = idx[s * k + j];
+            const float c = coef[s * k + j];
+            if (c != 0.f && a >= 0 && a < K) {
+                const int pos = atomicAdd(&s_cnt[a], 1);
+                if (fill) entry[pos] = (int32_t)(s * k + j);
+            }
+        }
+        // atoms inside one signal are distinct, so the LDS adds of one step never collide; the next
+        // signal's adds are issued after these (same wave, in order) => signal order is preserved.
+    }
+    if (!fill) {
+        __syncthreads();
+        for (int a = lane; a < K; a += 64) counts[(int64_t)a * T + chunk] = s_cnt[a];
+    }
+}
+
+// exclusive scan of `total` ints in place by one 1024-thread block; also writes row_ptr[a] = scanned[a*T]
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ counts, int64_t total, int K, int T,
+                                                        int32_t* __restrict__ row_ptr) {
+    __shared__ int s_sum[1024];
+    const int t = threadIdx.x;
+    const int64_t seg = (total + 1023) / 1024;
+    const int64_t b = (int64_t)t * seg, e = (b + seg < total) ? b + seg : total;
+    int sum = 0;
+    for (int64_t i = b; i < e; ++i) sum += counts[i];
+    s_sum[t] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan of the 1024 partials
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (t >= off) ? s_sum[t - off] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    int run = (t == 0) ? 0 : s_sum[t - 1];
+    for (int64_t i = b; i < e; ++i) {
+        const int c = counts[i];
+        counts[i] = run;
+        if (i % T == 0) row_ptr[i / T] = run;
+        run += c;
+    }
+    if (t == 1023) row_ptr[K] = s_sum[1023];
+}
+
+static void csr_plan(int64_t N, int& T, int64_t& S) {
+    int64_t t = (N + 255) / 256;
+    if (t < 1) t = 1;
+    if (t > 2048) t = 2048;
+    T = (int)t;
+    S = (N + T - 1) / T;
+}
+
+size_t csr_workspace_bytes(int K, int k, int64_t N) {
+    int T;
+    int64_t S;
+    csr_plan(N, T, S);
+    return (size_t)K * (size_t)T * sizeof(int32_t);
+}
+
+int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int32_t* row_ptr,
+                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream) {
+    int T;
+    int64_t S;
+    csr_plan(N, T, S);
+    if (ws_bytes < (size_t)K * T * sizeof(int32_t)) {
+        set_error("csr_by_atom: workspace %zu < %zu", ws_bytes, (size_t)K * T * sizeof(int32_t));
+        return LYS_EWORKSPACE;
+    }
+    if ((int64_t)N * k > 0x7fffffffLL) {
+        set_error("csr_by_atom: N*k = %lld exceeds int32 entries", (long long)N * k);
+        return LYS_ENOSUP;
+    }
+    if ((size_t)K * sizeof(int) > 64 * 1024) {
+        set_error("csr_by_atom: K = %d too large for the LDS counters", K);
+        return LYS_ENOSUP;
+    }
+    int32_t* counts = static_cast<int32_t*>(ws);
+    const size_t lds = (size_t)K * sizeof(int);
+    hipLaunchKernelGGL(csr_count_or_fill_kernel, dim3(T), dim3(64), lds, stream, idx, coef, nnz, K, k, N, T, S, counts,
+                       entry, 0);
+    LYS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, (int64_t)K * T, K, T, row_ptr);
+    LYS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_count_or_fill_kernel, dim3(T), dim3(64), lds, stream, idx, coef, nnz, K, k, N, T, S, counts,
+                       entry, 1);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// approximate K-SVD, one atom (ksvd.py:111-123).  A "team" = one 16-lane DPP row; lane q of a team owns
+// features 64*b + 4*q .. +3 for b < FB (n <= 64*FB).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_sum(float x) {  // sum over the 16 lanes of a DPP row, in every lane
+    x += dpp_f<0xB1>(x);
+    x += dpp_f<0x4E>(x);
+    x += dpp_f<0x124>(x);
+    x += dpp_f<0x128>(x);
+    return x;
+}
+__device__ __forceinline__ double row16_sum_d(double x) {
+    for (int off = 1; off < 16; off <<= 1) x += __shfl_xor(x, off, 16);
+    return x;
+}
+
+constexpr int KSVD_BLOCKS = 64;
+
+template <int FB>
+__global__ __launch_bounds__(256) void ksvd_accumulate_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n,
+                                                              int k, const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ entry,
+                                                              const float* __restrict__ coef,
+                                                              double* __restrict__ sbuf) {
+    __shared__ float s_acc[16][FB * 64 + 1];
+    const int beg = row_ptr[atom], end = row_ptr[atom + 1];
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int gteam = blockIdx.x * 16 + team, nteams = gridDim.x * 16;
+    if (beg + blockIdx.x * 16 >= end) return;  // block has no entry (uniform per block)
+    float4 acc[FB];
+    float sq = 0.f;
+#pragma unroll
+    for (int b = 0; b < FB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = beg + gteam; e < end; e += nteams) {
+        const int ss = entry[e];
+        const int64_t sig = ss / k;
+        const float x = coef[ss];
+        sq = fmaf(x, x, sq);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (f < n) {  // ldr is padded to a multiple of 4 and padded columns hold zeros
+                const float4 r = *reinterpret_cast<const float4*>(R + sig * ldr + f);
+                acc[b].x = fmaf(r.x, x, acc[b].x);
+                acc[b].y = fmaf(r.y, x, acc[b].y);
+                acc[b].z = fmaf(r.z, x, acc[b].z);
+                acc[b].w = fmaf(r.w, x, acc[b].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        s_acc[team][64 * b + 4 * q + 0] = acc[b].x;
+        s_acc[team][64 * b + 4 * q + 1] = acc[b].y;
+        s_acc[team][64 * b + 4 * q + 2] = acc[b].z;
+        s_acc[team][64 * b + 4 * q + 3] = acc[b].w;
+    }
+    if (q == 0) s_acc[team][FB * 64] = sq;
+    __syncthreads();
+    double* dst = sbuf + (int64_t)atom * (n + 1);
+    for (int f = threadIdx.x; f <= n; f += 256) {
+        const int src = (f == n) ? FB * 64 : f;
+        double tot = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) tot += (double)s_acc[t][src];
+        atomicAdd(dst + f, tot);
+    }
+}
+
+template <int FB>
+__global__ __launch_bounds__(256) void ksvd_apply_kernel(int atom, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                         const int32_t* __restrict__ row_ptr,
+                                                         const int32_t* __restrict__ entry, float* __restrict__ coef,
+                                                         const double* __restrict__ sbuf,
+                                                         const float* __restrict__ D, int ldd,
+                                                         float* __restrict__ Dnext) {
+    const int beg = row_ptr[atom], end = row_ptr[atom + 1];
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int gteam = blockIdx.x * 16 + team, nteams = gridDim.x * 16;
+    // block 0 always runs: it publishes d_new even when THIS shard holds no non-zero of the atom (multi-GPU:
+    // the statistics in sbuf are already all-reduced, every rank must end up with the same dictionary)
+    if (blockIdx.x != 0 && beg + blockIdx.x * 16 >= end) return;
+    // every team rebuilds d_new = normalize(sum R_i x_i + d_old * sum x_i^2) in fp64 (n values, trivial)
+    const double* s = sbuf + (int64_t)atom * (n + 1);
+    const double sumsq = s[n];
+    float4 dold[FB], dnew[FB];
+    double v[FB][4];
+    double nrm2 = 0.0;
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        const int f = 64 * b + 4 * q;
+        dold[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < n) dold[b] = *reinterpret_cast<const float4*>(D + (int64_t)atom * ldd + f);
+        const float od[4] = {dold[b].x, dold[b].y, dold[b].z, dold[b].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            v[b][c] = (f + c < n) ? s[f + c] + (double)od[c] * sumsq : 0.0;
+            nrm2 += v[b][c] * v[b][c];
+        }
+    }
+    nrm2 = row16_sum_d(nrm2);
+    const double scale = 1.0 / (sqrt(nrm2) + 2.220446049250313e-16);  // normalize(): x / (||x|| + eps)
+    float dd = 0.f;
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        dnew[b] = make_float4((float)(v[b][0] * scale), (float)(v[b][1] * scale), (float)(v[b][2] * scale),
+                              (float)(v[b][3] * scale));
+        dd = fmaf(dold[b].x, dnew[b].x, dd);
+        dd = fmaf(dold[b].y, dnew[b].y, dd);
+        dd = fmaf(dold[b].z, dnew[b].z, dd);
+        dd = fmaf(dold[b].w, dnew[b].w, dd);
+    }
+    dd = row16_sum(dd);  // d_old . d_new
+    if (blockIdx.x == 0 && team == 0) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (f < n) *reinterpret_cast<float4*>(Dnext + (int64_t)atom * ldd + f) = dnew[b];
+        }
+    }
+    for (int e = beg + gteam; e < end; e += nteams) {
+        const int ss = entry[e];
+        const int64_t sig = ss / k;
+        const float xo = coef[ss];
+        float4 r[FB];
+        float dot = 0.f;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            r[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < n) r[b] = *reinterpret_cast<const float4*>(R + sig * ldr + f);
+            dot = fmaf(r[b].x, dnew[b].x, dot);
+            dot = fmaf(r[b].y, dnew[b].y, dot);
+            dot = fmaf(r[b].z, dnew[b].z, dot);
+            dot = fmaf(r[b].w, dnew[b].w, dot);
+        }
+        dot = row16_sum(dot);
+        const float xn = fmaf(xo, dd, dot);  // (R_i + d_old x_old)' d_new
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (f < n) {
+                float4 o;
+                o.x = fmaf(-dnew[b].x, xn, fmaf(dold[b].x, xo, r[b].x));
+                o.y = fmaf(-dnew[b].y, xn, fmaf(dold[b].y, xo, r[b].y));
+                o.z = fmaf(-dnew[b].z, xn, fmaf(dold[b].z, xo, r[b].z));
+                o.w = fmaf(-dnew[b].w, xn, fmaf(dold[b].w, xo, r[b].w));
+                *reinterpret_cast<float4*>(R + sig * ldr + f) = o;
+            }
+        }
+        if (q == 0) coef[ss] = xn;
+    }
+}
+
+static int fb_of(int n) { return (n <= 64) ? 1 : (n <= 128) ? 2 : (n <= 256) ? 4 : 0; }
+
+int ksvd_atom_accumulate(int atom, const float* R, int64_t ldr, int n, int k, const int32_t* row_ptr,
+                         const int32_t* entry, const float* coef, double* sbuf, hipStream_t stream) {
+    switch (fb_of(n)) {
+        case 1: hipLaunchKernelGGL(ksvd_accumulate_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf); break;
+        case 2: hipLaunchKernelGGL(ksvd_accumulate_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf); break;
+        case 4: hipLaunchKernelGGL(ksvd_accumulate_kernel<4>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf); break;
+        default: set_error("ksvd: n = %d > 256 not supported", n); return LYS_ENOSUP;
+    }
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+int ksvd_atom_apply(int atom, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,
+                    float* coef, const double* sbuf, const float* D, float* Dnext, hipStream_t stream) {
+    const int ldd = padded_features(n);
+    switch (fb_of(n)) {
+        case 1: hipLaunchKernelGGL(ksvd_apply_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf, D, ldd, Dnext); break;
+        case 2: hipLaunchKernelGGL(ksvd_apply_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf, D, ldd, Dnext); break;
+        case 4: hipLaunchKernelGGL(ksvd_apply_kernel<4>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf, D, ldd, Dnext); break;
+        default: set_error("ksvd: n = %d > 256 not supported", n); return LYS_ENOSUP;
+    }
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+__global__ void ksvd_commit_kernel(int ldd, int K, const int32_t* __restrict__ row_ptr, const float* __restrict__ Dnext,
+                                   float* __restrict__ D) {
+    const int a = blockIdx.x;
+    if (a >= K || row_ptr[a] >= row_ptr[a + 1]) return;  // unused atom keeps its old column (ksvd.py:112-115)
+    for (int f = threadIdx.x; f < ldd; f += blockDim.x) D[(int64_t)a * ldd + f] = Dnext[(int64_t)a * ldd + f];
+}
+
+int ksvd_commit(int n, int K, const int32_t* row_ptr, const float* Dnext, float* D, hipStream_t stream) {
+    hipLaunchKernelGGL(ksvd_commit_kernel, dim3(K), dim3(64), 0, stream, padded_features(n), K, row_ptr, Dnext, D);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+int ksvd_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry, float* coef,
+               double* sbuf, float* D, float* Dnext, hipStream_t stream) {
+    LYS_CHECK_HIP(hipMemsetAsync(sbuf, 0, (size_t)K * (n + 1) * sizeof(double), stream));
+    for (int a = 0; a < K; ++a) {
+        int rc = ksvd_atom_accumulate(a, R, ldr, n, k, row_ptr, entry, coef, sbuf, stream);
+        if (rc) return rc;
+        rc = ksvd_atom_apply(a, R, ldr, n, k, row_ptr, entry, coef, sbuf, D, Dnext, stream);
+        if (rc) return rc;
+    }
+    return ksvd_commit(n, K, row_ptr, Dnext, D, stream);
+}
+
+}  // namespace lys

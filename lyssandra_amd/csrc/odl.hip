@@ -1,0 +1,149 @@
+// Online dictionary learning (Mairal) sufficient statistics and block update for gfx950 --
+// lyssa/dict_learning/online_dict_learn.py:84-98.
+//
+//   dA = Z Z'   and   dB = X Z'   are accumulated from the k-sparse codes through the atom-major index
+//   (k^2 + k*n scalar updates per signal instead of the reference's dense 2K^2 + 2nK FLOP per signal);
+//   one workgroup owns one atom: row `a` of dA lives in LDS, column `a` of dB in registers.
+//   The dictionary update is one fp32 MFMA GEMM (DA = D A, computed ONCE per batch like the reference, :91)
+//   plus a fused epilogue (:93-98).
+#include "common.h"
+
+namespace lys {
+
+int gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int Nc,
+            int Kin, hipStream_t stream);
+int transpose(const float* src, int rows, int cols, int ld_src, float* dst, int ld_dst, hipStream_t stream);
+
+__global__ __launch_bounds__(256) void odl_increment_kernel(const float* __restrict__ X, int64_t ldx, int n, int Kp,
+                                                            int ldd, int k, const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ coef,
+                                                            const int32_t* __restrict__ nnz,
+                                                            const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ entry,
+                                                            float* __restrict__ dA, float* __restrict__ dB) {
+    extern __shared__ float s_mem[];
+    float* s_row = s_mem;       // [Kp]   row `a` of Z Z'
+    float* s_b = s_mem + Kp;    // [ldd]  column `a` of X Z'
+    const int a = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int x = threadIdx.x; x < Kp + ldd; x += 256) s_mem[x] = 0.f;
+    __syncthreads();
+    const int beg = row_ptr[a], end = row_ptr[a + 1];
+    for (int e = beg + wid; e < end; e += 4) {
+        const int ss = entry[e];
+        const int64_t sig = ss / k;
+        const float xa = coef[ss];
+        const int m = nnz[sig];
+        for (int j = lane; j < m; j += 64) atomicAdd(&s_row[idx[sig * k + j]], xa * coef[sig * k + j]);
+        for (int f = lane; f < n; f += 64) atomicAdd(&s_b[f], xa * X[sig * ldx + f]);
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < Kp; x += 256) dA[(int64_t)a * Kp + x] = s_row[x];
+    for (int f = threadIdx.x; f < ldd; f += 256) dB[(int64_t)a * ldd + f] = s_b[f];
+}
+
+int odl_increments(const float* X, int64_t ldx, int n, int K, int k, const int32_t* idx, const float* coef,
+                   const int32_t* nnz, const int32_t* row_ptr, const int32_t* entry, float* dA, float* dB,
+                   hipStream_t stream) {
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    const size_t lds = (size_t)(Kp + ldd) * sizeof(float);
+    if (lds > 64 * 1024) {
+        set_error("odl_increments: K = %d too large for one LDS row", K);
+        return LYS_ENOSUP;
+    }
+    // rows >= K of dA/dB are written by nobody: the caller provides zeroed (or previously zero) buffers
+    LYS_CHECK_HIP(hipMemsetAsync(dA, 0, (size_t)Kp * Kp * sizeof(float), stream));
+    LYS_CHECK_HIP(hipMemsetAsync(dB, 0, (size_t)Kp * ldd * sizeof(float), stream));
+    hipLaunchKernelGGL(odl_increment_kernel, dim3(K), dim3(256), lds, stream, X, ldx, n, Kp, ldd, k, idx, coef, nnz,
+                       row_ptr, entry, dA, dB);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+__global__ void axpby_kernel(float* __restrict__ y, float beta, const float* __restrict__ x, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) y[i] = fmaf(beta, y[i], x[i]);
+}
+
+int axpby(float* y, float beta, const float* x, int64_t count, hipStream_t stream) {
+    if (count <= 0) return LYS_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, y, beta, x, count);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// one wave per atom: d += (B - DA) / (A_aa + eps); clip; d /= (||d|| + eps)     (:93-98)
+__global__ __launch_bounds__(64) void odl_update_kernel(float* __restrict__ D, int ldd, int n, int Kp,
+                                                        const float* __restrict__ A, const float* __restrict__ B,
+                                                        const float* __restrict__ DA, int non_neg) {
+    const int a = blockIdx.x, lane = threadIdx.x;
+    const float inv = 1.f / (A[(int64_t)a * Kp + a] + EPS64_F);
+    float ss = 0.f;
+    for (int f = lane; f < n; f += 64) {
+        const int64_t o = (int64_t)a * ldd + f;
+        float d = fmaf(inv, B[o] - DA[o], D[o]);
+        if (non_neg && d < 0.f) d = 0.f;
+        D[o] = d;
+        ss = fmaf(d, d, ss);
+    }
+    const float nrm = sqrtf(wave_sum_f(ss)) + EPS64_F;
+    for (int f = lane; f < n; f += 64) {
+        const int64_t o = (int64_t)a * ldd + f;
+        D[o] = D[o] / nrm;
+    }
+}
+
+int odl_update(float* D, const float* A, const float* B, int n, int K, int non_neg, float* scratch,
+               hipStream_t stream) {
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    float* Dt = scratch;                      // [ldd][Kp] feature-major copy of D
+    float* DA = scratch + (size_t)Kp * ldd;   // [Kp][ldd] (D A)' atom-major
+    int rc = transpose(D, Kp, ldd, ldd, Dt, Kp, stream);
+    if (rc) return rc;
+    // DA_am[a][f] = sum_j A[a][j] * D_am[j][f] = sum_j A[a][j] * Dt[f][j]   (A symmetric)
+    rc = gemm_nt(A, Kp, Dt, Kp, DA, ldd, Kp, ldd, Kp, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(odl_update_kernel, dim3(K), dim3(64), 0, stream, D, ldd, n, Kp, A, B, DA, non_neg);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// column normalisation of the packed dictionary (utils/math.py:65-71)
+__global__ __launch_bounds__(64) void norm_atoms_kernel(float* __restrict__ D, int ldd, int n) {
+    const int a = blockIdx.x, lane = threadIdx.x;
+    float ss = 0.f;
+    for (int f = lane; f < n; f += 64) {
+        const float d = D[(int64_t)a * ldd + f];
+        ss = fmaf(d, d, ss);
+    }
+    const float nrm = sqrtf(wave_sum_f(ss)) + EPS64_F;
+    for (int f = lane; f < n; f += 64) D[(int64_t)a * ldd + f] /= nrm;
+}
+
+int norm_atoms(float* D, int n, int K, hipStream_t stream) {
+    hipLaunchKernelGGL(norm_atoms_kernel, dim3(K), dim3(64), 0, stream, D, padded_features(n), n);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+__global__ void densify_kernel(const int32_t* __restrict__ idx, const float* __restrict__ coef,
+                               const int32_t* __restrict__ nnz, int k, int64_t N, double* __restrict__ Z) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * k) return;
+    const int64_t s = t / k;
+    const int j = (int)(t % k);
+    if (j < nnz[s]) Z[(int64_t)idx[t] * N + s] = (double)coef[t];
+}
+
+int densify_f64(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, double* Z,
+                hipStream_t stream) {
+    LYS_CHECK_HIP(hipMemsetAsync(Z, 0, (size_t)K * (size_t)N * sizeof(double), stream));
+    const int64_t tot = N * k;
+    if (tot <= 0) return LYS_OK;
+    hipLaunchKernelGGL(densify_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, idx, coef, nnz, k, N,
+                       Z);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+}  // namespace lys

@@ -1,0 +1,173 @@
+"""Drop-in for lyssa/dict_learning/ksvd.py (approximate K-SVD path) on MI355X.
+
+``approx_ksvd``, ``ksvd_dict_learn`` and ``ksvd_coder`` keep the reference's signatures, in-place mutation
+and host control flow (patience quirk, unused-atom replacement with the GLOBAL numpy RNG); the arithmetic --
+encode, residual, per-atom update, error -- runs in liblyssa_hip.so on device-resident data: X is uploaded
+once, the codes stay as a sparse triplet on the device for the whole fit.
+"""
+import time
+
+import numpy as np
+
+from .. import engine
+from ..sparse_coding import sparse_encoder
+from ..utils.math import normalize
+
+
+def _is_device_coder(sc):
+    return isinstance(sc, sparse_encoder) and sc.algorithm == 'bomp'
+
+
+def approx_ksvd(Y, D, X, n_cycles=1, verbose=True):
+    """lyssa/dict_learning/ksvd.py:98-126.  Y (n, N) data, D (n, K), X (K, N) dense codes.
+
+    Mutates D and X IN PLACE like the reference and returns ``(D, X, unused_atoms)``.  The support pattern
+    of X is preserved; atoms are visited in order 0..K-1 (Gauss-Seidel through the shared residual).
+    """
+    Ys = engine.signals_to_device(Y)
+    dd = engine.DeviceDictionary.from_host(D)
+    idx, coef, nnz = engine.sparsify_host(X)
+    R, _ = engine.residual(Ys, dd, idx, coef, nnz, want_R=True, want_err=False)
+    unused_atoms = []
+    for _ in range(n_cycles):
+        unused_atoms += engine.ksvd_cycle(R, dd, idx, coef, nnz)
+    D[:] = dd.to_host()
+    _scatter_codes(X, idx, coef, nnz)
+    return D, X, unused_atoms
+
+
+def _scatter_codes(X, idx, coef, nnz):
+    """Write the (updated) coefficients back into the dense host matrix, support unchanged."""
+    hi, hc, hn = idx.cpu().numpy(), coef.cpu().numpy(), nnz.cpu().numpy()
+    N, k = hi.shape
+    valid = np.arange(k)[None, :] < hn[:, None]
+    cols = np.broadcast_to(np.arange(N)[:, None], (N, k))
+    X[hi[valid], cols[valid]] = hc[valid]
+
+
+def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
+                    max_iter=20, non_neg=False, approx=False, eta=None,
+                    n_cycles=1, n_jobs=1, mmap=False, verbose=True, return_codes=True, group=None):
+    """lyssa/dict_learning/ksvd.py:129-231 (``approx=True`` path).
+
+    Returns ``(D, Z)`` with D float64 (n, K) and Z dense float64 (K, N) -- pass ``return_codes=False`` to skip
+    the dense materialisation (then Z is the device triplet).  Reference behaviours kept on purpose:
+      * patience: ``error_prev`` is refreshed only when ``verbose`` and *before* the test (:222-228), so the
+        loop stops after 11 iterations whatever ``max_iter`` is;
+      * unused atoms are replaced by random unused datapoints drawn with ``np.random.choice`` (:199-207);
+      * the error is evaluated with the atom-updated codes and the final dictionary (:220).
+    ``group``: torch.distributed group when X is this rank's shard of the signals (statistics all-reduced).
+    """
+    if not approx or non_neg:
+        raise NotImplementedError("only approx=True, non_neg=False is on the accelerated path "
+                                  "(exact rank-1 K-SVD / nn-K-SVD are out of scope)")
+    if eta is not None:
+        raise NotImplementedError("eta (force_mi) is outside the accelerated path")
+    X = np.asarray(X)
+    n_features, n_samples = X.shape
+    unused_data = []
+    if isinstance(init_dict, str) and init_dict == 'data':
+        from .utils import init_dictionary
+        D, unused_data = init_dictionary(X, n_atoms, method=init_dict, return_unused_data=True)
+    else:
+        D = np.copy(init_dict)
+    Xs = engine.signals_to_device(X)
+    dd = engine.DeviceDictionary.from_host(D)
+    device_coder = _is_device_coder(sparse_coder)
+    if mmap and sparse_coder is not None:
+        sparse_coder.mmap = True
+    if verbose:
+        print("dictionary initialized")
+    max_patience = 10
+    error_curr = 0
+    error_prev = 0
+    it = 0
+    patience = 0
+    idx = coef = nnz = None
+    while it < max_iter and patience < max_patience:
+        it_start = time.time()
+        # ---- sparse coding
+        if device_coder:
+            idx, coef, nnz = sparse_coder.encode_device(Xs, dd)
+        else:
+            idx, coef, nnz = engine.sparsify_host(sparse_coder(X, dd.to_host()))
+        t_sparse = time.time() - it_start
+        # ---- approximate K-SVD atom updates
+        R, _ = engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+        unused_atoms = []
+        for _ in range(n_cycles):
+            unused_atoms += engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group)
+        del R
+        # ---- replace unused atoms (host RNG, ksvd.py:199-207)
+        for j in range(len(unused_atoms)):
+            if len(unused_data) == 0:
+                break
+            _idx = np.random.choice(unused_data, size=1)
+            i_ = _idx[0]
+            dd.set_atom(unused_atoms[j], normalize(np.asarray(X[:, i_], dtype=np.float64)))
+            unused_data.remove(i_)
+        # ---- error with the updated codes (ksvd.py:220)
+        error_curr = engine.approx_error(Xs, dd, idx, coef, nnz)
+        if group is not None:
+            error_curr = _allreduce_scalar(error_curr, dd.device, group)
+        if verbose:
+            print("iteration %d: sparse coding %.3fs, total %.3fs, unused atoms %d, error %.6g (diff %.6g)"
+                  % (it, t_sparse, time.time() - it_start, len(unused_atoms), error_curr, error_curr - error_prev))
+            error_prev = error_curr
+        if (it > 0) and (error_curr > 0.9 * error_prev or error_curr > error_prev):
+            patience += 1
+        it += 1
+    D_out = dd.to_host()
+    if idx is None:
+        Z = np.zeros((n_atoms, n_samples))
+    elif return_codes:
+        Z = engine.densify(idx, coef, nnz, n_atoms)
+    else:
+        Z = (idx, coef, nnz)
+    return D_out, Z
+
+
+def _allreduce_scalar(v, device, group):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([v], dtype=torch.float64, device=device)
+    dist.all_reduce(t, group=group)
+    return float(t.item())
+
+
+class ksvd_coder(object):
+    """lyssa/dict_learning/ksvd.py:234-271 -- kwargs holder around ``ksvd_dict_learn``."""
+
+    def __init__(self, n_atoms=None, n_nonzero_coefs=None, sparse_coder=None, init_dict="data",
+                 max_iter=None, non_neg=False, approx=True, eta=None, n_cycles=1, n_jobs=1,
+                 mmap=False, verbose=True):
+        self.n_atoms = n_atoms
+        self.sparse_coder = sparse_coder
+        self.max_iter = max_iter
+        self.non_neg = non_neg
+        self.approx = approx
+        self.eta = eta
+        self.n_jobs = n_jobs
+        self.init_dict = init_dict
+        self.n_cycles = n_cycles
+        self.verbose = verbose
+        self.mmap = mmap
+        self.D = None
+
+    def _fit(self, X):
+        D, _ = ksvd_dict_learn(X, self.n_atoms, init_dict=self.init_dict,
+                               sparse_coder=self.sparse_coder, max_iter=self.max_iter,
+                               non_neg=self.non_neg, approx=self.approx, eta=self.eta, n_cycles=self.n_cycles,
+                               n_jobs=self.n_jobs, mmap=self.mmap, verbose=self.verbose, return_codes=False)
+        self.D = D
+
+    def __call__(self, X):
+        self._fit(X)
+        Z = self.sparse_coder(X, self.D)
+        return Z
+
+    def fit(self, X):
+        self._fit(X)
+
+    def encode(self, X):
+        return self.sparse_coder(X, self.D)

@@ -1,0 +1,323 @@
+"""Device-side operations of the sparse-coding engine (thin, typed wrappers over the C-ABI).
+
+PyTorch is used here for plumbing only: device memory (tensors), the current HIP stream and dtype/layout
+conversion of user arrays.  All arithmetic of the hot path runs in liblyssa_hip.so.
+
+Layouts (see include/lyssa_hip.h): signals are signal-major ``[N, n]`` fp32, the dictionary is packed
+atom-major ``[Kp, ldd]`` fp32, sparse codes are the triplet ``(idx int32 [N,k], coef fp32 [N,k], nnz int32 [N])``.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise _lib.LyssaHipError("no HIP device visible: the lyssandra_amd engine is MI355X-only and has no CPU path")
+    return torch
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def device_of(dev=None):
+    torch = require_gpu()
+    if dev is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(dev)
+
+
+# --------------------------------------------------------------------------------------------- conversions
+def signals_to_device(X, device=None):
+    """(n_features, n_samples) array of any float dtype / memory order -> signal-major fp32 cuda tensor [N, n].
+
+    Accepts a cuda tensor that is already signal-major fp32 via ``SignalBatch`` (see below)."""
+    torch = require_gpu()
+    device = device_of(device)
+    if isinstance(X, torch.Tensor):
+        t = X.to(device)
+        return t.t().contiguous().to(torch.float32)
+    X = np.asarray(X)
+    if X.ndim != 2:
+        raise ValueError("X must be 2-D (n_features, n_samples)")
+    # transpose on the device: the host only does one dtype-preserving copy
+    t = torch.from_numpy(np.ascontiguousarray(X)).to(device)
+    return t.t().contiguous().to(torch.float32)
+
+
+class DeviceDictionary(object):
+    """Packed dictionary + its Gram matrix on one device (both recomputed by ``set``)."""
+
+    def __init__(self, n, K, device=None):
+        torch = require_gpu()
+        self.device = device_of(device)
+        self.n, self.K = int(n), int(K)
+        self.Kp = _lib.padded_atoms(K)
+        self.ldd = _lib.padded_features(n)
+        self.D = torch.zeros((self.Kp, self.ldd), dtype=torch.float32, device=self.device)
+        self.G = torch.zeros((self.Kp, self.Kp), dtype=torch.float32, device=self.device)
+        self._gram_valid = False
+
+    @classmethod
+    def from_host(cls, D, device=None):
+        D = np.asarray(D)
+        dd = cls(D.shape[0], D.shape[1], device)
+        dd.set(D)
+        return dd
+
+    def set(self, D):
+        """D: (n, K) host array or (n, K) cuda tensor."""
+        torch = _torch()
+        if isinstance(D, torch.Tensor):
+            src = D.to(self.device).t().contiguous().to(torch.float32)
+        else:
+            D = np.asarray(D)
+            src = torch.from_numpy(np.ascontiguousarray(D.T.astype(np.float32))).to(self.device)
+        assert tuple(src.shape) == (self.K, self.n), (tuple(src.shape), self.K, self.n)
+        lib = _lib.load()
+        _lib.check(lib.lys_pack_dictionary(_ptr(src), self.n, self.K, _ptr(self.D), _stream()), "lys_pack_dictionary")
+        self._gram_valid = False
+        return self
+
+    def set_atom(self, k, col):
+        """Overwrite one atom from a host vector (used by the K-SVD unused-atom replacement)."""
+        torch = _torch()
+        v = torch.from_numpy(np.asarray(col, dtype=np.float32)).to(self.device)
+        self.D[k, :self.n] = v
+        self._gram_valid = False
+
+    def gram(self):
+        if not self._gram_valid:
+            lib = _lib.load()
+            _lib.check(lib.lys_gram(_ptr(self.D), self.n, self.K, _ptr(self.G), _stream()), "lys_gram")
+            self._gram_valid = True
+        return self.G
+
+    def invalidate(self):
+        self._gram_valid = False
+
+    def to_host(self):
+        """-> (n, K) float64, the reference's dictionary layout."""
+        return self.D[:self.K, :self.n].t().contiguous().double().cpu().numpy()
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    torch = _torch()
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def release_workspaces():
+    _ws_cache.clear()
+
+
+# --------------------------------------------------------------------------------------------- Batch-OMP
+def bomp_encode(Xs, dd, k, out=None):
+    """Batch-OMP of the signal-major batch ``Xs`` [N, >=n] against ``dd``.  Returns (idx, coef, nnz)."""
+    torch = _torch()
+    lib = _lib.load()
+    N = int(Xs.shape[0])
+    k = int(k)
+    if k < 1:
+        raise ValueError("n_nonzero_coefs must be >= 1")
+    assert Xs.dtype == torch.float32 and Xs.stride(1) == 1
+    if out is None:
+        idx = torch.empty((N, k), dtype=torch.int32, device=dd.device)
+        coef = torch.empty((N, k), dtype=torch.float32, device=dd.device)
+        nnz = torch.empty((N,), dtype=torch.int32, device=dd.device)
+    else:
+        idx, coef, nnz = out
+    if N == 0:
+        return idx, coef, nnz
+    G = dd.gram()
+    ws_bytes = lib.lys_bomp_workspace_bytes(dd.n, dd.K, k, N)
+    ws = _workspace(ws_bytes, dd.device, "bomp")
+    _lib.check(lib.lys_bomp_encode(_ptr(Xs), Xs.stride(0), _ptr(dd.D), _ptr(G), dd.n, dd.K, k, N,
+                                   _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(ws), ws.numel(), _stream()),
+               "lys_bomp_encode")
+    return idx, coef, nnz
+
+
+def densify(idx, coef, nnz, K, out=None):
+    """Sparse triplet -> dense float64 (K, N) host array (the reference's return type, sparse_coding.py:365)."""
+    torch = _torch()
+    lib = _lib.load()
+    N, k = int(idx.shape[0]), int(idx.shape[1])
+    if out is None:
+        out = np.zeros((K, N))
+    else:
+        out[:] = 0
+    if N == 0:
+        return out
+    if K * N * 8 <= (1 << 30):
+        Zd = torch.empty((K, N), dtype=torch.float64, device=idx.device)
+        _lib.check(lib.lys_densify_f64(_ptr(idx), _ptr(coef), _ptr(nnz), K, k, N, _ptr(Zd), _stream()),
+                   "lys_densify_f64")
+        out[:] = Zd.cpu().numpy()
+        return out
+    # very large outputs: move only the triplet over PCIe and scatter on the host (format conversion only)
+    hi, hc, hn = idx.cpu().numpy(), coef.cpu().numpy(), nnz.cpu().numpy()
+    valid = np.arange(k)[None, :] < hn[:, None]
+    cols = np.broadcast_to(np.arange(N)[:, None], (N, k))
+    out[hi[valid], cols[valid]] = hc[valid]
+    return out
+
+
+def sparsify_host(Z, k=None, device=None):
+    """Dense (K, N) host codes -> triplet on the device (slots in ascending atom order)."""
+    torch = require_gpu()
+    device = device_of(device)
+    Z = np.asarray(Z)
+    K, N = Z.shape
+    nz = Z != 0
+    cnt = nz.sum(axis=0).astype(np.int32)
+    kk = int(max(1, cnt.max() if N else 1))
+    if k is not None:
+        if kk > k:
+            raise ValueError("Z has a column with %d non-zeros > k=%d" % (kk, k))
+        kk = int(k)
+    idx = -np.ones((N, kk), dtype=np.int32)
+    coef = np.zeros((N, kk), dtype=np.float32)
+    cols, rows = np.nonzero(nz.T)  # sorted by signal, then atom
+    slot = np.arange(len(cols)) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    idx[cols, slot] = rows
+    coef[cols, slot] = Z[rows, cols]
+    return (torch.from_numpy(idx).to(device), torch.from_numpy(coef).to(device),
+            torch.from_numpy(cnt).to(device))
+
+
+# --------------------------------------------------------------------------------------------- residual / error
+def residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=True):
+    """R = X - DZ (signal-major [N, ldd], zero padded) and ||X - DZ||_F^2 (python float)."""
+    torch = _torch()
+    lib = _lib.load()
+    N, k = int(idx.shape[0]), int(idx.shape[1])
+    R = torch.zeros((N, dd.ldd), dtype=torch.float32, device=dd.device) if want_R else None
+    err = torch.zeros((1,), dtype=torch.float64, device=dd.device) if want_err else None
+    _lib.check(lib.lys_residual(_ptr(Xs), Xs.stride(0), _ptr(dd.D), dd.n, dd.K, k, N, _ptr(idx), _ptr(coef), _ptr(nnz),
+                                _ptr(R), dd.ldd, _ptr(err), _stream()), "lys_residual")
+    return R, (float(err.item()) if want_err else None)
+
+
+def approx_error(Xs, dd, idx, coef, nnz):
+    return residual(Xs, dd, idx, coef, nnz, want_R=False, want_err=True)[1]
+
+
+# --------------------------------------------------------------------------------------------- CSR by atom
+def csr_by_atom(idx, coef, nnz, K):
+    torch = _torch()
+    lib = _lib.load()
+    N, k = int(idx.shape[0]), int(idx.shape[1])
+    row_ptr = torch.empty((K + 1,), dtype=torch.int32, device=idx.device)
+    entry = torch.empty((max(1, N * k),), dtype=torch.int32, device=idx.device)
+    ws_bytes = lib.lys_csr_workspace_bytes(K, k, N)
+    ws = _workspace(max(ws_bytes, 4), idx.device, "csr")
+    _lib.check(lib.lys_csr_by_atom(_ptr(idx), _ptr(coef), _ptr(nnz), K, k, N, _ptr(row_ptr), _ptr(entry),
+                                   _ptr(ws), ws.numel(), _stream()), "lys_csr_by_atom")
+    return row_ptr, entry
+
+
+# --------------------------------------------------------------------------------------------- approx K-SVD
+def ksvd_cycle(R, dd, idx, coef, nnz, group=None):
+    """One dictionary-update cycle (atoms 0..K-1 in order) of approx K-SVD, in place on R, coef and dd.D.
+
+    Returns the list of unused atoms of this cycle (lyssa/dict_learning/ksvd.py:111-115).
+    ``group``: torch.distributed process group => per-atom all-reduce of the n+1 sufficient statistics.
+    """
+    torch = _torch()
+    lib = _lib.load()
+    N, k = int(idx.shape[0]), int(idx.shape[1])
+    row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
+    sbuf = torch.zeros((dd.K, dd.n + 1), dtype=torch.float64, device=dd.device)
+    Dnext = torch.zeros_like(dd.D)
+    dist_on = group is not None
+    if not dist_on:
+        _lib.check(lib.lys_ksvd_sweep(_ptr(R), R.stride(0), dd.n, dd.K, k, _ptr(row_ptr), _ptr(entry), _ptr(coef),
+                                      _ptr(sbuf), _ptr(dd.D), _ptr(Dnext), _stream()), "lys_ksvd_sweep")
+        counts = (row_ptr[1:] - row_ptr[:-1])
+    else:
+        import torch.distributed as dist
+        counts = (row_ptr[1:] - row_ptr[:-1]).to(torch.int64)
+        dist.all_reduce(counts, group=group)
+        # a rank whose shard does not use the atom still has to take part in the reduction and the commit
+        row_glob = torch.zeros((dd.K + 1,), dtype=torch.int32, device=dd.device)
+        row_glob[1:] = torch.cumsum(torch.clamp(counts, max=1), 0).to(torch.int32)
+        for a in range(dd.K):
+            _lib.check(lib.lys_ksvd_atom_accumulate(a, _ptr(R), R.stride(0), dd.n, k, _ptr(row_ptr), _ptr(entry),
+                                                    _ptr(coef), _ptr(sbuf), _stream()), "lys_ksvd_atom_accumulate")
+            dist.all_reduce(sbuf[a], group=group)
+            _lib.check(lib.lys_ksvd_atom_apply(a, _ptr(R), R.stride(0), dd.n, k, _ptr(row_ptr), _ptr(entry),
+                                               _ptr(coef), _ptr(sbuf), _ptr(dd.D), _ptr(Dnext), _stream()),
+                       "lys_ksvd_atom_apply")
+        _lib.check(lib.lys_ksvd_commit(dd.n, dd.K, _ptr(row_glob), _ptr(Dnext), _ptr(dd.D), _stream()),
+                   "lys_ksvd_commit")
+    dd.invalidate()
+    unused = torch.nonzero(counts == 0).flatten().cpu().numpy().tolist()
+    return unused
+
+
+# --------------------------------------------------------------------------------------------- online DL
+class OdlState(object):
+    """Device-resident A (K x K) and B (n x K, stored atom-major) of online dictionary learning."""
+
+    def __init__(self, dd, A=None, B=None):
+        torch = _torch()
+        self.dd = dd
+        self.A = torch.zeros((dd.Kp, dd.Kp), dtype=torch.float32, device=dd.device)
+        self.B = torch.zeros((dd.Kp, dd.ldd), dtype=torch.float32, device=dd.device)
+        self.dA = torch.zeros_like(self.A)
+        self.dB = torch.zeros_like(self.B)
+        self.scratch = torch.empty((2 * dd.Kp * dd.ldd,), dtype=torch.float32, device=dd.device)
+        if A is not None:
+            self.A[:dd.K, :dd.K] = torch.from_numpy(np.asarray(A, dtype=np.float32)).to(dd.device)
+        if B is not None:
+            self.B[:dd.K, :dd.n] = torch.from_numpy(np.ascontiguousarray(np.asarray(B, dtype=np.float32).T)).to(dd.device)
+
+    def batch_update(self, Xs, idx, coef, nnz, beta, non_neg=False, group=None):
+        """online_dict_learn.py:84-98 for one mini-batch (statistics, then the dictionary update)."""
+        lib = _lib.load()
+        dd = self.dd
+        N, k = int(idx.shape[0]), int(idx.shape[1])
+        row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
+        _lib.check(lib.lys_odl_increments(_ptr(Xs), Xs.stride(0), dd.n, dd.K, k, _ptr(idx), _ptr(coef), _ptr(nnz),
+                                          _ptr(row_ptr), _ptr(entry), _ptr(self.dA), _ptr(self.dB), _stream()),
+                   "lys_odl_increments")
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.dA, group=group)
+            dist.all_reduce(self.dB, group=group)
+        _lib.check(lib.lys_axpby(_ptr(self.A), float(beta), _ptr(self.dA), self.A.numel(), _stream()), "lys_axpby")
+        _lib.check(lib.lys_axpby(_ptr(self.B), float(beta), _ptr(self.dB), self.B.numel(), _stream()), "lys_axpby")
+        _lib.check(lib.lys_odl_update(_ptr(dd.D), _ptr(self.A), _ptr(self.B), dd.n, dd.K, int(bool(non_neg)),
+                                      _ptr(self.scratch), _stream()), "lys_odl_update")
+        dd.invalidate()
+
+    def A_host(self):
+        return self.A[:self.dd.K, :self.dd.K].double().cpu().numpy()
+
+    def B_host(self):
+        return self.B[:self.dd.K, :self.dd.n].t().contiguous().double().cpu().numpy()
+
+
+def synchronize():
+    _torch().cuda.synchronize()

@@ -1,0 +1,149 @@
+"""Drop-in for ``lyssa.sparse_coding.sparse_encoder`` (lyssa/sparse_coding.py:512-726) on MI355X.
+
+Same constructor, attributes and call contract as the reference class:
+
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 10}, n_jobs=1)
+    Z = se.encode(X, D)          # X (n_features, n_samples), D (n_features, n_atoms)
+                                 # -> NEW dense float64 (n_atoms, n_samples), like the reference
+
+``'bomp'`` runs entirely in liblyssa_hip.so (fp32 MFMA GEMMs for G = D'D and alpha0 = D'X, wave-per-signal
+greedy/Cholesky kernel).  There is NO CPU fallback: without the library or without a GPU the call raises.
+Unknown algorithms raise ``ValueError("Sparse optimizer not found.")`` exactly like sparse_coding.py:705-706;
+the reference's other algorithms are outside the accelerated path and raise NotImplementedError.
+
+Beyond the reference API, ``encode_sparse`` returns the device-resident sparse triplet (idx, coef, nnz) --
+the dense float64 (K, N) return type costs 8 KB per signal at K=1024 and is only materialised on request.
+"""
+import os
+import tempfile
+
+import numpy as np
+
+from . import engine
+
+_REFERENCE_ALGORITHMS = ('omp', 'bomp', 'thresh', 'nnomp', 'group_omp', 'sparse_group_omp', 'somp', 'iht',
+                         'lasso', 'llc')
+
+
+class sparse_encoder(object):
+    """MI355X implementation of the reference's sparse_encoder (only ``algorithm='bomp'`` is accelerated)."""
+
+    def __init__(self, algorithm='omp', params=None, n_jobs=1, verbose=True, mmap=False, name='sparse_coder'):
+        # lyssa/sparse_coding.py:587-598
+        self.name = name
+        self.algorithm = algorithm
+        self.params = params
+        if self.params is None:
+            self.params = {}
+        if n_jobs == -1:
+            from .utils import cpu_count
+            n_jobs = cpu_count
+        self.n_jobs = n_jobs      # kept for API compatibility; parallelism comes from the GPU(s)
+        self.verbose = verbose
+        self.mmap = mmap
+        self.device = None        # None => current HIP device
+        self._dd = None           # cached DeviceDictionary (re-packed on every call: D may have changed)
+
+    # -- reference API ---------------------------------------------------------------------------------
+    def encode(self, X, D):
+        return self.__call__(X, D)
+
+    def __call__(self, X, D):
+        """lyssa/sparse_coding.py:603-726 -> dense float64 Z (n_atoms, n_samples)."""
+        n_samples = X.shape[1]
+        n_atoms = D.shape[1]
+        if self.params.get('lambda') is not None:
+            assert self.params.get('lambda') <= n_atoms
+        self._check_algorithm()
+        idx, coef, nnz = self.encode_sparse(X, D)
+        if self.mmap:
+            out = _empty_mmap((n_atoms, n_samples))
+        else:
+            out = np.zeros((n_atoms, n_samples))
+        return engine.densify(idx, coef, nnz, n_atoms, out=out)
+
+    # -- extended API ----------------------------------------------------------------------------------
+    def encode_sparse(self, X, D):
+        """Same inputs as ``encode``; returns the device-resident triplet (idx [N,k], coef [N,k], nnz [N])."""
+        self._check_algorithm()
+        k = self._k()
+        Xs = engine.signals_to_device(X, self.device)
+        dd = self._dictionary(D)
+        return engine.bomp_encode(Xs, dd, k)
+
+    def encode_device(self, Xs, dd):
+        """Device-resident form: ``Xs`` signal-major fp32 cuda tensor [N, n], ``dd`` an engine.DeviceDictionary."""
+        self._check_algorithm()
+        return engine.bomp_encode(Xs, dd, self._k())
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    def _k(self):
+        k = self.params.get('n_nonzero_coefs')
+        if k is None:
+            # the reference dies with a TypeError in np.zeros((None, None)) (sparse_coding.py:317)
+            raise ValueError("params['n_nonzero_coefs'] is required for algorithm='bomp'")
+        return int(k)
+
+    def _check_algorithm(self):
+        if self.algorithm == 'bomp':
+            return
+        if self.algorithm in _REFERENCE_ALGORITHMS:
+            raise NotImplementedError(
+                "algorithm=%r is outside the MI355X-accelerated path (only 'bomp' is implemented; "
+                "there is deliberately no CPU fallback in this package)" % (self.algorithm,))
+        raise ValueError("Sparse optimizer not found.")  # sparse_coding.py:705-706
+
+    def _dictionary(self, D):
+        D = np.asarray(D) if not _is_tensor(D) else D
+        n, K = int(D.shape[0]), int(D.shape[1])
+        dd = self._dd
+        if dd is None or dd.n != n or dd.K != K:
+            dd = engine.DeviceDictionary(n, K, self.device)
+            self._dd = dd
+        dd.set(D)
+        return dd
+
+
+def _is_tensor(x):
+    try:
+        import torch
+        return isinstance(x, torch.Tensor)
+    except ImportError:  # pragma: no cover
+        return False
+
+
+def _empty_mmap(shape):
+    """Counterpart of lyssa.utils.dataset.get_empty_mmap (utils/dataset.py:136-149): float64 memmap on disk."""
+    d = os.environ.get("LYSSA_MMAP_DIR", tempfile.gettempdir())
+    fd, path = tempfile.mkstemp(prefix="lyssa_mmap_", suffix=".dat", dir=d)
+    os.close(fd)
+    return np.memmap(path, dtype=np.float64, mode='w+', shape=shape)
+
+
+def batch_omp(X, Alpha, D, Gram, n_nonzero_coefs=None, tol=None):
+    """Function form of lyssa/sparse_coding.py:302-367 for callers that precomputed Alpha and Gram.
+
+    X and D are used for their shapes only (as in the reference, :306-307); ``tol`` is accepted and unused
+    (as in the reference).  Alpha (n_atoms, n_samples), Gram (n_atoms, n_atoms) host arrays -> dense float64 Z.
+    """
+    import ctypes
+    from . import _lib
+    torch = engine.require_gpu()
+    lib = _lib.load()
+    K, N = int(D.shape[1]), int(X.shape[1])
+    k = int(n_nonzero_coefs)
+    Kp = _lib.padded_atoms(K)
+    dev = engine.device_of(None)
+    a0 = torch.zeros((N, Kp), dtype=torch.float32, device=dev)
+    a0[:, :K] = torch.from_numpy(np.ascontiguousarray(np.asarray(Alpha, dtype=np.float32).T)).to(dev)
+    G = torch.zeros((Kp, Kp), dtype=torch.float32, device=dev)
+    G[:K, :K] = torch.from_numpy(np.asarray(Gram, dtype=np.float32)).to(dev)
+    idx = torch.empty((N, k), dtype=torch.int32, device=dev)
+    coef = torch.empty((N, k), dtype=torch.float32, device=dev)
+    nnz = torch.empty((N,), dtype=torch.int32, device=dev)
+    _lib.check(lib.lys_bomp_from_alpha0(ctypes.c_void_p(a0.data_ptr()), ctypes.c_void_p(G.data_ptr()), K, k, N,
+                                        ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(coef.data_ptr()),
+                                        ctypes.c_void_p(nnz.data_ptr()),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "lys_bomp_from_alpha0")
+    return engine.densify(idx, coef, nnz, K)

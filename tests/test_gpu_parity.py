@@ -1,0 +1,395 @@
+"""GPU parity tests: the HIP engine (through the C-ABI) against the CPU oracle and the golden vectors.
+
+Bars (BASELINE.json north_star): identical OMP support sets on signals without correlation ties (recorded
+min relative top-1/top-2 gap >= 1e-5), coefficients and learned atoms within 1e-5 relative (fp32 engine vs
+float64 reference).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TIE_GAP = 1e-5   # below this relative gap a signal is a "tie" signal and support parity is not graded
+COEF_TOL = 1e-5  # max |dz| / max |z| per signal
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from lyssandra_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def _host_triplet(t):
+    return tuple(x.cpu().numpy() for x in t)
+
+
+def _encode(eng, X, D, k):
+    Xs = eng.signals_to_device(X)
+    dd = eng.DeviceDictionary.from_host(D)
+    return _host_triplet(eng.bomp_encode(Xs, dd, k))
+
+
+def _compare_supports(idx, coef, nnz, g_idx, g_coef, g_nnz, gap, label):
+    """g_idx sorted ascending (golden); idx in selection order (engine)."""
+    N, k = idx.shape
+    bad_support, bad_coef, ties = [], [], 0
+    worst = 0.0
+    for i in range(N):
+        m, gm = int(nnz[i]), int(g_nnz[i])
+        mine = dict(zip(idx[i, :m].tolist(), coef[i, :m].tolist()))
+        ref = dict(zip(g_idx[i, :gm].tolist(), g_coef[i, :gm].tolist()))
+        if set(mine) != set(ref):
+            if gap[i] < TIE_GAP:
+                ties += 1
+            else:
+                bad_support.append(i)
+            continue
+        scale = max(abs(v) for v in ref.values()) if ref else 1.0
+        err = max(abs(mine[a] - ref[a]) for a in ref) / scale if ref else 0.0
+        worst = max(worst, err)
+        if err > COEF_TOL:
+            bad_coef.append((i, err))
+    print("%s: N=%d tie-signals with different support=%d, worst coef rel err=%.3g" % (label, N, ties, worst))
+    assert not bad_support, "%s: support mismatch on no-tie signals %s" % (label, bad_support[:10])
+    assert not bad_coef, "%s: coefficient mismatch %s" % (label, bad_coef[:10])
+
+
+# ------------------------------------------------------------------------------------------------ GEMMs
+@pytest.mark.parametrize("n,K,N", [(64, 1024, 300), (64, 256, 129), (17, 100, 33), (256, 512, 64), (10, 4, 100),
+                                   (128, 4096, 70)])
+def test_gram_and_alpha0(eng, n, K, N):
+    import ctypes
+    import torch
+    from lyssandra_amd import _lib
+    rs = np.random.RandomState(n * 7 + K)
+    D = rs.randn(n, K).astype(np.float32)
+    D /= np.linalg.norm(D, axis=0, keepdims=True)
+    X = rs.randn(n, N).astype(np.float32)
+    dd = eng.DeviceDictionary.from_host(D)
+    G = dd.gram().cpu().numpy().astype(np.float64)
+    Gref = D.astype(np.float64).T @ D.astype(np.float64)
+    assert np.max(np.abs(G[:K, :K] - Gref)) < 2e-6
+    assert np.all(G[K:, :] == 0) and np.all(G[:, K:] == 0)
+    Xs = eng.signals_to_device(X)
+    a0 = torch.empty((N, dd.Kp), dtype=torch.float32, device=dd.device)
+    lib = _lib.load()
+    _lib.check(lib.lys_alpha0(ctypes.c_void_p(Xs.data_ptr()), Xs.stride(0), ctypes.c_void_p(dd.D.data_ptr()), n, K, N,
+                              ctypes.c_void_p(a0.data_ptr()),
+                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "lys_alpha0")
+    A = a0.cpu().numpy().astype(np.float64)
+    Aref = X.astype(np.float64).T @ D.astype(np.float64)
+    assert np.max(np.abs(A[:, :K] - Aref)) < 1e-5 * max(1.0, np.abs(Aref).max())
+    assert np.all(A[:, K:] == 0)
+
+
+def test_gemm_is_transpose_detecting(eng):
+    """Asymmetric operands: A = unit rows picks single columns of B (guide: always check with asymmetric B)."""
+    n, K, N = 64, 128, 64
+    D = np.zeros((n, K), dtype=np.float32)
+    for a in range(K):
+        D[a % n, a] = 1.0 + a  # atom a = (1+a) * e_{a mod n}
+    X = np.zeros((n, N), dtype=np.float32)
+    for i in range(N):
+        X[(3 * i + 1) % n, i] = 2.0 + i
+    idx, coef, nnz = _encode(eng, X, D, 1)  # k=1 selects argmax |d_a . x| = largest a with a%n == (3i+1)%n
+    for i in range(N):
+        f = (3 * i + 1) % n
+        cands = [a for a in range(K) if a % n == f]
+        best = max(cands)
+        assert idx[i, 0] == best
+        assert abs(coef[i, 0] - (1.0 + best) * (2.0 + i)) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ Batch-OMP
+@pytest.mark.parametrize("name", ["F1", "F2", "F3"])
+def test_bomp_golden(eng, name):
+    g = load_golden(name)
+    X, D, k = g["X"], g["D"], int(g["k"])
+    idx, coef, nnz = _encode(eng, X, D, k)
+    assert idx.shape == (X.shape[1], k)
+    _compare_supports(idx, coef, nnz, g["idx"], g["coef"], g["nnz"], g["gap"], name)
+
+
+@pytest.mark.parametrize("case", ["dup", "exact2", "k1", "k4K4", "pool37", "nonunit", "ragged"])
+def test_bomp_edge_cases(eng, case):
+    g = load_golden("F4")
+    X, D, k = g[case + "_X"], g[case + "_D"], int(g[case + "_k"])
+    Zr = g[case + "_Z"]
+    gap = g[case + "_gap"]
+    K, N = Zr.shape
+    idx, coef, nnz = _encode(eng, X, D, k)
+    Z = np.zeros((K, N))
+    for i in range(N):
+        m = int(nnz[i])
+        assert len(set(idx[i, :m].tolist())) == m, "duplicate atom in a support"
+        assert np.all(idx[i, m:] == -1) and np.all(coef[i, m:] == 0)
+        Z[idx[i, :m], i] = coef[i, :m]
+    scale = np.maximum(np.abs(Zr).max(axis=0), 1e-30)
+    if case == "exact2":
+        # exactly representable signals: after the true atoms the residual is rounding noise (1e-16 in the float64
+        # reference, 1e-7 in fp32) and the greedy selection is undefined.  Compare the
+        # significant coefficients; everything else must be noise-sized.  The last signal is all-zero.
+        big = np.abs(Zr) > 1e-6 * scale[None, :]
+        assert np.max(np.abs(Z - Zr)[big] / np.broadcast_to(scale[None, :], Z.shape)[big]) < 1e-5
+        assert np.all(np.abs(Z[~big]) <= 1e-5 * np.broadcast_to(scale[None, :], Z.shape)[~big] + 1e-12)
+        assert np.all(Z[:, -1] == 0) and nnz[-1] == 1 and idx[-1, 0] == 0
+        return
+    for i in range(N):
+        same = np.array_equal(Z[:, i] != 0, Zr[:, i] != 0)
+        if not same:
+            assert gap[i] < TIE_GAP, "%s: support mismatch on no-tie signal %d (gap %.3g)" % (case, i, gap[i])
+            continue
+        assert np.max(np.abs(Z[:, i] - Zr[:, i])) / scale[i] < COEF_TOL, (case, i)
+
+
+def test_bomp_vs_oracle_metric_shape(eng):
+    """Seeded Gaussian patches at the metric shape (n=64, K=1024, k=10) against the float64 oracle."""
+    from oracle import lyssa_oracle as orc
+    rs = np.random.RandomState(2024)
+    n, K, k, N = 64, 1024, 10, 3000
+    D = rs.randn(n, K)
+    D /= np.linalg.norm(D, axis=0, keepdims=True)
+    D = D.astype(np.float32)
+    X = rs.randn(n, N).astype(np.float32)
+    oi, oc, on, gap = orc.bomp_encode_sparse(X.astype(np.float64), D.astype(np.float64), k)
+    idx, coef, nnz = _encode(eng, X, D, k)
+    srt = np.sort(np.where(oi >= 0, oi, 1 << 30), axis=1)
+    order = np.argsort(np.where(oi >= 0, oi, 1 << 30), axis=1)
+    g_idx = np.where(srt < (1 << 30), srt, -1).astype(np.int32)
+    g_coef = np.take_along_axis(oc, order, axis=1)
+    _compare_supports(idx, coef, nnz, g_idx, g_coef, on, gap, "metric-shape")
+    # selection ORDER is also reproduced on no-tie signals
+    ok = gap >= TIE_GAP
+    assert np.array_equal(idx[ok], oi[ok])
+
+
+def test_bomp_generic_kernel_large_K(eng):
+    """K=4096 (config-3 dictionary size) goes through the workgroup-per-signal kernel."""
+    from oracle import lyssa_oracle as orc
+    rs = np.random.RandomState(4096)
+    n, K, k, N = 64, 4096, 12, 96
+    D = rs.randn(n, K)
+    D /= np.linalg.norm(D, axis=0, keepdims=True)
+    D = D.astype(np.float32)
+    X = rs.randn(n, N).astype(np.float32)
+    oi, oc, on, gap = orc.bomp_encode_sparse(X.astype(np.float64), D.astype(np.float64), k)
+    idx, coef, nnz = _encode(eng, X, D, k)
+    ok = gap >= TIE_GAP
+    assert np.array_equal(idx[ok], oi[ok])
+    scale = np.abs(oc).max(axis=1, keepdims=True)
+    assert np.max((np.abs(coef - oc) / scale)[ok]) < COEF_TOL
+
+
+def test_bomp_full_size_properties(eng):
+    """Size-independent properties at the metric's full shape (2^20 signals): OMP invariants checked on the device
+    with plain torch fp32 algebra -- support has k distinct atoms, residual is orthogonal to the selected atoms,
+    sharding-invariance (encoding two halves separately gives bit-identical results)."""
+    import torch
+    n, K, k, N = 64, 1024, 10, 1 << 20
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    Dt = torch.randn((n, K), device="cuda", generator=gen)
+    Dt = Dt / Dt.norm(dim=0, keepdim=True)
+    Xs = torch.randn((N, n), device="cuda", generator=gen)
+    dd = eng.DeviceDictionary(n, K)
+    dd.set(Dt)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    assert int(nnz.min()) == k and int(nnz.max()) == k
+    srt = torch.sort(idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    assert int(idx.min()) >= 0 and int(idx.max()) < K
+    Dam = dd.D[:K, :n]                                   # [K, n]
+    sub = slice(0, 1 << 17)
+    atoms = Dam[idx[sub].long()]                          # [M, k, n]
+    recon = torch.einsum("mk,mkn->mn", coef[sub], atoms)
+    r = Xs[sub] - recon
+    corr = torch.einsum("mn,mkn->mk", r, atoms).abs().max().item()
+    assert corr < 2e-4, corr                              # fp32: residual orthogonal to the support
+    assert (r.norm(dim=1) < Xs[sub].norm(dim=1)).all()
+    h = N // 2
+    i1, c1, z1 = eng.bomp_encode(Xs[:h], dd, k)
+    i2, c2, z2 = eng.bomp_encode(Xs[h:], dd, k)
+    assert torch.equal(torch.cat([i1, i2]), idx) and torch.equal(torch.cat([c1, c2]), coef)
+
+
+# ------------------------------------------------------------------------------------------------ drop-in class
+def test_sparse_encoder_dropin(eng):
+    from lyssandra_amd.sparse_coding import sparse_encoder, batch_omp
+    from oracle import lyssa_oracle as orc
+    g = load_golden("F1")
+    X, D, k = g["X"].astype(np.float64), g["D"].astype(np.float64), int(g["k"])
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, n_jobs=4, verbose=False)
+    Z = se.encode(X, D)
+    assert Z.dtype == np.float64 and Z.shape == (D.shape[1], X.shape[1])
+    Zf = se(np.asfortranarray(X), D.astype(np.float32))           # any memory order / dtype
+    assert np.array_equal(Z, Zf)
+    Zo = orc.bomp_encode(X, D, k)
+    ok = g["gap"] >= TIE_GAP
+    assert np.array_equal((Z != 0)[:, ok], (Zo != 0)[:, ok])
+    assert np.max(np.abs(Z - Zo)[:, ok]) < 1e-5 * np.abs(Zo).max()
+    Zm = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, mmap=True)(X, D)
+    assert isinstance(Zm, np.memmap) and np.array_equal(np.asarray(Zm), Z)
+    # function form with precomputed Alpha / Gram
+    Zb = batch_omp(X, D.T @ X, D, D.T @ D, n_nonzero_coefs=k)
+    assert np.array_equal((Zb != 0)[:, ok], (Zo != 0)[:, ok])
+    # reference's own tests: unknown algorithm raises; k=K=4, n=10 shape
+    with pytest.raises(Exception):
+        sparse_encoder(algorithm='se', params={'n_nonzero_coefs': 4}).encode(X, D)
+    with pytest.raises(NotImplementedError):
+        sparse_encoder(algorithm='lasso', params={'lambda': 1}).encode(X, D)
+    Xr = np.random.RandomState(0).rand(10, 100)
+    Dr = np.random.RandomState(1).rand(10, 4)
+    Zr = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 4}).encode(Xr, Dr)
+    assert Zr.shape == (4, 100)
+
+
+# ------------------------------------------------------------------------------------------------ residual / CSR
+def test_residual_error_and_csr(eng):
+    import torch
+    from oracle import lyssa_oracle as orc
+    g = load_golden("F5")
+    X, D0, k = g["X"].astype(np.float64), g["D0"].astype(np.float64), int(g["k"])
+    Xs = eng.signals_to_device(X)
+    dd = eng.DeviceDictionary.from_host(D0)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    R, err = eng.residual(Xs, dd, idx, coef, nnz)
+    Z = eng.densify(idx, coef, nnz, D0.shape[1])
+    Rref = X - D0 @ Z
+    assert np.max(np.abs(R[:, :64].cpu().numpy().T - Rref)) < 1e-5
+    assert abs(err - np.sum(Rref ** 2)) < 1e-5 * np.sum(Rref ** 2)
+    row_ptr, entry = eng.csr_by_atom(idx, coef, nnz, D0.shape[1])
+    rp, en = row_ptr.cpu().numpy(), entry.cpu().numpy()
+    hi = idx.cpu().numpy()
+    assert rp[0] == 0 and rp[-1] == int((Z != 0).sum())
+    for a in range(D0.shape[1]):
+        seg = en[rp[a]:rp[a + 1]]
+        sig = seg // k
+        assert np.all(hi.reshape(-1)[seg] == a)
+        assert np.all(np.diff(sig) > 0)                       # signals ascending inside an atom
+        assert np.array_equal(sig, np.flatnonzero(Z[a] != 0))
+
+
+# ------------------------------------------------------------------------------------------------ approx K-SVD
+def _atom_err(D, Dref):
+    return np.max(np.linalg.norm(D - Dref, axis=0) / np.maximum(np.linalg.norm(Dref, axis=0), 1e-30))
+
+
+def test_approx_ksvd_golden(eng):
+    """lyssa/dict_learning/ksvd.py:98-126 on F5: D, codes and error after each of 3 iterations."""
+    from lyssandra_amd.dict_learning.ksvd import approx_ksvd
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    g = load_golden("F5")
+    X, k = g["X"].astype(np.float64), int(g["k"])
+    K = g["D0"].shape[1]
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    # (a) atom update alone, from the reference's own codes: isolates the sweep kernels
+    for it in range(3):
+        Dprev = g["D0"].astype(np.float64) if it == 0 else g["it%d_D" % (it - 1)]
+        Zin = np.zeros((K, X.shape[1]))
+        gi, gc, gn = g["it%d_idx" % it], g["it%d_coef_in" % it], g["it%d_nnz" % it]
+        for i in range(X.shape[1]):
+            Zin[gi[i, :gn[i]], i] = gc[i, :gn[i]]
+        D = Dprev.copy()
+        Dr, Zr, unused = approx_ksvd(X, D, Zin, n_cycles=1, verbose=False)
+        assert Dr is D and Zr is Zin                           # in-place contract
+        assert _atom_err(D, g["it%d_D" % it]) < 1e-5, (it, _atom_err(D, g["it%d_D" % it]))
+        Zgold = np.zeros_like(Zin)
+        for i in range(X.shape[1]):
+            Zgold[gi[i, :gn[i]], i] = g["it%d_coef" % it][i, :gn[i]]
+        assert np.array_equal(Zin != 0, Zgold != 0)
+        assert np.max(np.abs(Zin - Zgold)) < 1e-5 * np.abs(Zgold).max()
+        assert list(unused) == list(g["it%d_unused" % it])
+    # (b) the full alternation, engine encode included (fp32 rounding may move a tie signal's support)
+    D = g["D0"].astype(np.float64).copy()
+    for it in range(3):
+        Z = se.encode(X, D)
+        D, Z, unused = approx_ksvd(X, D, Z, n_cycles=1, verbose=False)
+        err = np.sum((X - D @ Z) ** 2)
+        assert abs(err - float(g["it%d_err" % it])) < 2e-4 * float(g["it%d_err" % it]), (it, err)
+    # (c) n_cycles = 2
+    D = g["D0"].astype(np.float64).copy()
+    Z = np.zeros((K, X.shape[1]))
+    gi, gc, gn = g["it0_idx"], g["it0_coef_in"], g["it0_nnz"]
+    for i in range(X.shape[1]):
+        Z[gi[i, :gn[i]], i] = gc[i, :gn[i]]
+    approx_ksvd(X, D, Z, n_cycles=2, verbose=False)
+    assert _atom_err(D, g["cyc2_D"]) < 1e-5
+
+
+def test_ksvd_coder_dropin(eng):
+    """ksvd_dict_learn host control flow: patience quirk (11 encode calls), global-RNG use, ndarray init_dict."""
+    from lyssandra_amd.dict_learning.ksvd import ksvd_dict_learn, ksvd_coder
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    g = load_golden("F5")
+    X, k = g["X"].astype(np.float64)[:, :600], int(g["k"])
+    calls = []
+
+    class counting(sparse_encoder):
+        def encode_device(self, Xs, dd):
+            calls.append(1)
+            return sparse_encoder.encode_device(self, Xs, dd)
+
+    se = counting(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    np.random.seed(1234)
+    D, Z = ksvd_dict_learn(X, 32, init_dict='data', sparse_coder=se, max_iter=50, approx=True, verbose=False)
+    assert len(calls) == 11 == int(g["full_v0_ncalls"])
+    assert D.shape == (64, 32) and Z.shape == (32, 600)
+    assert np.random.randint(0, 2 ** 31 - 1) == int(g["full_v0_rng_after"])   # same RNG consumption
+    # 11 alternations in fp32 vs float64: dictionaries agree loosely (chaotic amplification of tie flips),
+    # tightly checked per-iteration above
+    assert np.max(np.abs(np.linalg.norm(D, axis=0) - 1)) < 1e-5
+    # ndarray init_dict, 2 iterations: tight
+    D2, Z2 = ksvd_dict_learn(X, 128, init_dict=g["D0"].astype(np.float64), sparse_coder=se, max_iter=2, approx=True,
+                             verbose=False)
+    assert _atom_err(D2, g["init_nd_D"]) < 5e-4
+    coder = ksvd_coder(n_atoms=32, sparse_coder=se, max_iter=3, approx=True, verbose=False)
+    np.random.seed(5)
+    coder.fit(X)
+    assert coder.D.shape == (64, 32)
+    assert coder.encode(X).shape == (32, 600)
+
+
+# ------------------------------------------------------------------------------------------------ online DL
+def test_online_dict_learn_golden(eng):
+    from lyssandra_amd.dict_learning.online_dict_learn import online_dict_learn, online_dictionary_coder
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    g5, g = load_golden("F5"), load_golden("F6")
+    X, D0, k = g5["X"].astype(np.float64), g5["D0"].astype(np.float64), int(g["k"])
+    K = D0.shape[1]
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    # (a) kernel level: statistics + dictionary update from the ORACLE's codes (no encode differences), 3 batches
+    from oracle import lyssa_oracle as orc
+    Xs = eng.signals_to_device(X)
+    dd = eng.DeviceDictionary.from_host(D0)
+    state = eng.OdlState(dd)
+    Do, Ao, Bo = D0.copy(), np.zeros((K, K)), np.zeros((64, K))
+    for b, beta_i in enumerate([0.0, 0.5, 1.0]):
+        sl = slice(500 * b, 500 * (b + 1))
+        Zb = orc.bomp_encode(X[:, sl], Do, k)
+        idx, coef, nnz = eng.sparsify_host(Zb, k=k)
+        dd.set(Do)
+        state.batch_update(Xs[sl], idx, coef, nnz, beta_i)
+        Do, Ao, Bo = orc.odl_batch_update(Do, Ao, Bo, X[:, sl], Zb, beta_i)
+        assert np.max(np.abs(state.A_host() - Ao)) < 1e-5 * np.abs(Ao).max(), b
+        assert np.max(np.abs(state.B_host() - Bo)) < 1e-5 * np.abs(Bo).max(), b
+        assert _atom_err(dd.to_host(), Do) < 1e-5, (b, _atom_err(dd.to_host(), Do))
+    # (b) one batch through the drop-in function: D after the first batch is logged in e1_Dlog[1]
+    D, A, B = online_dict_learn(X[:, :500], K, sparse_coder=se, batch_size=500, D_init=D0.copy(), beta=0.0,
+                                n_epochs=1)
+    assert _atom_err(D, g["e1_Dlog"][1]) < 1e-3, _atom_err(D, g["e1_Dlog"][1])
+    # (c) whole fits against the reference's results (tie flips in the fp32 encode perturb single atoms)
+    for tag, n_epochs, beta in [("e1", 1, None), ("e1b", 1, 0.9), ("e2", 2, None)]:
+        D, A, B = online_dict_learn(X, K, sparse_coder=se, batch_size=int(g["batch_size"]), D_init=D0.copy(),
+                                    beta=beta, n_epochs=n_epochs)
+        assert D.shape == (64, K) and A.shape == (K, K) and B.shape == (64, K)
+        tol = 2e-3 if n_epochs == 1 else 2e-2
+        assert _atom_err(D, g[tag + "_D"]) < tol, (tag, _atom_err(D, g[tag + "_D"]))
+        assert np.max(np.abs(A - g[tag + "_A"])) < tol * np.abs(g[tag + "_A"]).max(), tag
+        assert np.max(np.abs(B - g[tag + "_B"])) < tol * np.abs(g[tag + "_B"]).max(), tag
+    coder = online_dictionary_coder(n_atoms=K, sparse_coder=se, batch_size=500, D_init=D0.copy(), beta=0.5, n_epochs=1)
+    coder.fit(X[:, :1000])
+    coder.fit(X[:, 1000:])
+    assert _atom_err(coder.D, g["warm_D"]) < 2e-3
+    assert np.max(np.abs(coder.A - g["warm_A"])) < 2e-3 * np.abs(g["warm_A"]).max()
