@@ -66,6 +66,10 @@ def load():
         raise LyssaHipError(
             "HIP engine library not found at %s -- build it with `python -m lyssandra_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # The engine shares device pointers and HIP streams with PyTorch, so both must sit on ONE HIP runtime
+    # instance: import torch first, then our DT_NEEDED libamdhip64.so.7 resolves (by soname) to the runtime
+    # torch already loaded.  Loading in the other order leaves two runtimes in the process.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
