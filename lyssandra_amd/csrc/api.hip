@@ -1,5 +1,6 @@
 // extern "C" surface of liblyssa_hip.so -- see include/lyssa_hip.h for the contract.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -30,7 +31,8 @@ int num_cus() {
 }
 
 // implemented in the kernel translation units
-int gemm_nt(const float*, int64_t, const float*, int64_t, float*, int64_t, int64_t, int, int, hipStream_t);
+int gemm_nt(const float*, int64_t, const float*, int64_t, float*, int64_t, int64_t, int, int, hipStream_t,
+            bool stream_c = false);
 int pack_dictionary(const float*, int, int, float*, hipStream_t);
 bool bomp_has_wave_kernel(int Kp, int k);
 size_t bomp_generic_scratch_bytes(int Kp, int k);
@@ -54,10 +56,10 @@ int odl_update(float*, const float*, const float*, int, int, int, float*, hipStr
 int norm_atoms(float*, int, int, hipStream_t);
 int densify_f64(const int32_t*, const float*, const int32_t*, int, int, int64_t, double*, hipStream_t);
 
-// alpha0 tile: how many signals per GEMM+OMP round.  ~128 MiB of alpha0 keeps the producer->consumer
-// hand-off inside the 256 MiB Infinity Cache instead of HBM.
+// alpha0 tile: how many signals per GEMM+OMP round.  Two tiles of ~64 MiB are in flight (ping-pong), which keeps
+// the producer->consumer hand-off of alpha0 inside the 256 MiB Infinity Cache instead of HBM.
 static int64_t tile_signals(int Kp) {
-    const int64_t bytes = 128ll << 20;
+    const int64_t bytes = 64ll << 20;
     int64_t t = bytes / ((int64_t)Kp * 4);
     t = (t / 512) * 512;
     return t < 512 ? 512 : t;
@@ -69,10 +71,11 @@ static bool g_event_made[64];
 // ---- optional per-stage HIP-event profile of lys_bomp_encode (bench.py's roofline object) --------------
 struct StageProfile {
     bool on = false;
-    static constexpr int CAP = 3 * 4096;
+    static constexpr int PER_TILE = 4;  // GEMM begin/end (on its stream), greedy begin/end (on its stream)
+    static constexpr int CAP = PER_TILE * 4096;
     hipEvent_t ev[CAP];
     int made = 0;  // events created so far
-    int used = 0;  // events recorded since the last collect (3 per tile: before GEMM, after GEMM, after OMP)
+    int used = 0;  // events recorded since the last collect
     int64_t signals = 0;
 };
 static StageProfile g_prof;
@@ -86,6 +89,46 @@ static int prof_mark(hipStream_t stream) {
     LYS_CHECK_HIP(hipEventRecord(g_prof.ev[g_prof.used], stream));
     g_prof.used++;
     return LYS_OK;
+}
+
+// ---- two-stream tile pipeline: the alpha0 GEMM of tile t+1 (MFMA pipe, LDS) runs next to the greedy kernel of
+// tile t (VALU, latency-bound); the two kernels co-reside on a CU (2 x 192 + 128 VGPRs per SIMD lane).
+struct Pipe {
+    bool made = false;
+    hipStream_t s_gemm = nullptr, s_omp = nullptr;
+    hipEvent_t ev_in = nullptr, ev_gemm[2] = {nullptr, nullptr}, ev_omp[2] = {nullptr, nullptr};
+};
+static Pipe g_pipe[64];
+
+static int pipe_get(Pipe** out) {
+    int dev = 0;
+    LYS_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) {
+        set_error("device index %d out of range", dev);
+        return LYS_EINVAL;
+    }
+    Pipe& p = g_pipe[dev];
+    if (!p.made) {
+        LYS_CHECK_HIP(hipStreamCreateWithFlags(&p.s_gemm, hipStreamNonBlocking));
+        LYS_CHECK_HIP(hipStreamCreateWithFlags(&p.s_omp, hipStreamNonBlocking));
+        LYS_CHECK_HIP(hipEventCreateWithFlags(&p.ev_in, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) {
+            LYS_CHECK_HIP(hipEventCreateWithFlags(&p.ev_gemm[i], hipEventDisableTiming));
+            LYS_CHECK_HIP(hipEventCreateWithFlags(&p.ev_omp[i], hipEventDisableTiming));
+        }
+        p.made = true;
+    }
+    *out = &p;
+    return LYS_OK;
+}
+
+static bool pipeline_enabled() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("LYS_PIPELINE");
+        cached = (e && e[0] == '0') ? 0 : 1;
+    }
+    return cached == 1;
 }
 
 }  // namespace lys
@@ -129,9 +172,9 @@ int lys_gram(const float* D_packed, int n, int K, float* G, void* stream) {
 
 size_t lys_bomp_workspace_bytes(int n, int K, int k, int64_t N) {
     const int Kp = padded_atoms(K);
-    int64_t t = tile_signals(Kp);
-    if (N < t) t = (N < 1) ? 1 : N;
-    size_t bytes = (size_t)t * (size_t)Kp * sizeof(float);
+    const int64_t t = tile_signals(Kp);
+    int64_t rows = (N <= t) ? ((N < 1) ? 1 : N) : 2 * t;  // one tile, or two ping-pong tiles
+    size_t bytes = (size_t)rows * (size_t)Kp * sizeof(float);
     if (!bomp_has_wave_kernel(Kp, k)) bytes += bomp_generic_scratch_bytes(Kp, k);
     return bytes;
 }
@@ -173,23 +216,63 @@ int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const fl
     }
     float* gen = wave ? nullptr : static_cast<float*>(workspace);
     float* alpha0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + gen_bytes);
-    int64_t tile = (int64_t)((workspace_bytes - gen_bytes) / ((size_t)Kp * sizeof(float)));
+    const int64_t rows = (int64_t)((workspace_bytes - gen_bytes) / ((size_t)Kp * sizeof(float)));
     const int64_t pref = tile_signals(Kp);
-    if (tile > pref) tile = pref;
-    for (int64_t s0 = 0; s0 < N; s0 += tile) {
-        const int64_t cnt = (N - s0 < tile) ? N - s0 : tile;
-        const bool prof = g_prof.on && g_prof.used + 3 <= StageProfile::CAP;
-        int rc;
-        if (prof && (rc = prof_mark(STREAM(stream)))) return rc;
-        rc = gemm_nt(X + s0 * ldx, ldx, D_packed, ldd, alpha0, Kp, cnt, Kp, n, STREAM(stream));
-        if (rc) return rc;
-        if (prof && (rc = prof_mark(STREAM(stream)))) return rc;
-        rc = bomp_from_alpha0(alpha0, G, Kp, k, cnt, idx + s0 * k, coef + s0 * k, nnz + s0, gen, STREAM(stream));
-        if (rc) return rc;
+    hipStream_t user = STREAM(stream);
+    int rc;
+    if (N <= rows && N <= pref) {
+        // single tile: both kernels on the caller's stream
+        const bool prof = g_prof.on && g_prof.used + StageProfile::PER_TILE <= StageProfile::CAP;
+        if (prof && (rc = prof_mark(user))) return rc;
+        if ((rc = gemm_nt(X, ldx, D_packed, ldd, alpha0, Kp, N, Kp, n, user, true))) return rc;
+        if (prof && ((rc = prof_mark(user)) || (rc = prof_mark(user)))) return rc;
+        if ((rc = bomp_from_alpha0(alpha0, G, Kp, k, N, idx, coef, nnz, gen, user))) return rc;
         if (prof) {
-            if ((rc = prof_mark(STREAM(stream)))) return rc;
+            if ((rc = prof_mark(user))) return rc;
+            g_prof.signals += N;
+        }
+        return LYS_OK;
+    }
+    const bool piped = pipeline_enabled() && rows >= 2 * 512;
+    int64_t tile = piped ? rows / 2 : rows;
+    if (tile > pref) tile = pref;
+    tile = (tile / 512) * 512;
+    if (tile < 512) tile = (rows < 512) ? rows : 512;
+    Pipe* pp = nullptr;
+    hipStream_t sg = user, so = user;
+    if (piped) {
+        if ((rc = pipe_get(&pp))) return rc;
+        sg = pp->s_gemm;
+        so = pp->s_omp;
+        LYS_CHECK_HIP(hipEventRecord(pp->ev_in, user));
+        LYS_CHECK_HIP(hipStreamWaitEvent(sg, pp->ev_in, 0));
+        LYS_CHECK_HIP(hipStreamWaitEvent(so, pp->ev_in, 0));
+    }
+    int64_t t = 0;
+    for (int64_t s0 = 0; s0 < N; s0 += tile, ++t) {
+        const int64_t cnt = (N - s0 < tile) ? N - s0 : tile;
+        const int b = piped ? (int)(t & 1) : 0;
+        float* a0 = alpha0 + (size_t)b * (size_t)tile * Kp;
+        const bool prof = g_prof.on && g_prof.used + StageProfile::PER_TILE <= StageProfile::CAP;
+        if (piped && t >= 2) LYS_CHECK_HIP(hipStreamWaitEvent(sg, pp->ev_omp[b], 0));  // buffer b is free again
+        if (prof && (rc = prof_mark(sg))) return rc;
+        if ((rc = gemm_nt(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, Kp, n, sg, true))) return rc;
+        if (prof && (rc = prof_mark(sg))) return rc;
+        if (piped) {
+            LYS_CHECK_HIP(hipEventRecord(pp->ev_gemm[b], sg));
+            LYS_CHECK_HIP(hipStreamWaitEvent(so, pp->ev_gemm[b], 0));
+        }
+        if (prof && (rc = prof_mark(so))) return rc;
+        if ((rc = bomp_from_alpha0(a0, G, Kp, k, cnt, idx + s0 * k, coef + s0 * k, nnz + s0, gen, so))) return rc;
+        if (prof) {
+            if ((rc = prof_mark(so))) return rc;
             g_prof.signals += cnt;
         }
+        if (piped) LYS_CHECK_HIP(hipEventRecord(pp->ev_omp[b], so));
+    }
+    if (piped) {
+        // the greedy stream is in-order: its last event covers every tile (and every GEMM they waited for)
+        LYS_CHECK_HIP(hipStreamWaitEvent(user, pp->ev_omp[(t - 1) & 1], 0));
     }
     return LYS_OK;
 }
@@ -275,12 +358,13 @@ int lys_profile_enable(int on) {
 
 int lys_profile_collect(double* gemm_ms_host, double* omp_ms_host, int* launches_host, int64_t* signals_host) {
     double g = 0.0, o = 0.0;
-    const int tiles = g_prof.used / 3;
+    const int tiles = g_prof.used / StageProfile::PER_TILE;
     for (int t = 0; t < tiles; ++t) {
         float a = 0.f, b = 0.f;
-        LYS_CHECK_HIP(hipEventSynchronize(g_prof.ev[3 * t + 2]));
-        LYS_CHECK_HIP(hipEventElapsedTime(&a, g_prof.ev[3 * t], g_prof.ev[3 * t + 1]));
-        LYS_CHECK_HIP(hipEventElapsedTime(&b, g_prof.ev[3 * t + 1], g_prof.ev[3 * t + 2]));
+        hipEvent_t* e = &g_prof.ev[StageProfile::PER_TILE * t];
+        LYS_CHECK_HIP(hipEventSynchronize(e[3]));
+        LYS_CHECK_HIP(hipEventElapsedTime(&a, e[0], e[1]));
+        LYS_CHECK_HIP(hipEventElapsedTime(&b, e[2], e[3]));
         g += a;
         o += b;
     }

@@ -34,31 +34,38 @@ struct Lay {
     __device__ static __forceinline__ int reg_of(int atom) { return (atom / (64 * V)) * V + (atom % V); }
 };
 
-template <int R>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// STREAM: the row is read exactly once (alpha0) -> non-temporal load, so it does not evict Gram rows from L2
+template <int R, bool STREAM = false>
 __device__ __forceinline__ void load_row(const float* __restrict__ row, int lane, float (&v)[R]) {
     using L = Lay<R>;
     if constexpr (L::V == 4) {
 #pragma unroll
         for (int c = 0; c < L::C; ++c) {
-            const float4 t = reinterpret_cast<const float4*>(row)[c * 64 + lane];
+            const f32x4* ptr = reinterpret_cast<const f32x4*>(row) + (c * 64 + lane);
+            const f32x4 t = STREAM ? __builtin_nontemporal_load(ptr) : *ptr;
             v[4 * c + 0] = t.x;
             v[4 * c + 1] = t.y;
             v[4 * c + 2] = t.z;
             v[4 * c + 3] = t.w;
         }
     } else if constexpr (L::V == 2) {
-        const float2 t = reinterpret_cast<const float2*>(row)[lane];
+        const f32x2* ptr = reinterpret_cast<const f32x2*>(row) + lane;
+        const f32x2 t = STREAM ? __builtin_nontemporal_load(ptr) : *ptr;
         v[0] = t.x;
         v[1] = t.y;
     } else {
-        v[0] = row[lane];
+        v[0] = STREAM ? __builtin_nontemporal_load(row + lane) : row[lane];
     }
 }
 
 // Uniform extraction  w[i] = p[i][rr](lane L)  for i < J, with rr only known at run time (wave-uniform):
 // an if-chain over rr keeps every register index static (dynamic VGPR indexing would go to scratch).
 template <int R, int KMAX, int J, int RR>
-__device__ __forceinline__ void extract_case(const float (&p)[KMAX][R], int rr, int L, float (&w)[KMAX]) {
+__device__ __forceinline__ void extract_case(const float (&p)[KMAX - 1 > 0 ? KMAX - 1 : 1][R], int rr, int L,
+                                             float (&w)[KMAX]) {
     if constexpr (RR < R) {
         if (rr == RR) {
 #pragma unroll
@@ -117,7 +124,7 @@ __device__ __forceinline__ bool wave_argmax(const float (&a)[R], int lane, int& 
 template <int R, int KMAX>
 struct OmpState {
     float a[R];         // current correlations
-    float p[KMAX][R];   // orthogonalised Gram columns
+    float p[KMAX - 1 > 0 ? KMAX - 1 : 1][R];   // orthogonalised Gram columns (the last selection needs none)
     float Lrow[KMAX];   // Lrow[j] lane i (<j) = L[j][i]
     float tv;           // lane j = t_j
     float rinv;         // lane j = 1/rho_j
@@ -137,9 +144,13 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX>& s, const float* __r
         if (!wave_argmax<R>(s.a, lane, kk, akk, Lown, rown)) return;
         // re-selection => stop (sparse_coding.py:323-325)
         if (__ballot(lane < J && s.dxv == kk) != 0ull) return;
+        // The vector update is only needed if another selection follows: the reference's last
+        // `a = a0 - G[:,Dx] z` (:359) is never read.  (J + 1 < k is wave-uniform; for J == KMAX-1 it is
+        // statically false, so p[KMAX-1] never exists.)
+        const bool more = (J + 1 < KMAX) && (J + 1 < k);
         // Gram row of the new atom (G is symmetric: row kk == column kk), issued before the scalar work
         float g[R];
-        load_row<R>(G + (int64_t)kk * L::Kp, lane, g);
+        if (more) load_row<R>(G + (int64_t)kk * L::Kp, lane, g);
 
         float w[KMAX];
         extract_case<R, KMAX, J, 0>(s.p, rown, Lown, w);
@@ -147,18 +158,23 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX>& s, const float* __r
 #pragma unroll
         for (int i = 0; i < J; ++i) vs = fmaf(-w[i], w[i], vs);
         if (J > 0 && vs < EPS32_F) return;  // reference: vs < eps (:335,345); the fp32 engine uses fp32 eps
-        const float rho = sqrtf(vs);
-        const float inv = 1.f / rho;
+        // 1/sqrt(vs): hardware rsq (1 ulp) + one Newton step instead of an IEEE sqrt and an IEEE divide
+        float inv = __builtin_amdgcn_rsqf(vs);
+        inv = inv * fmaf(-0.5f * vs, inv * inv, 1.5f);
         const float t = akk * inv;
 
+        if constexpr (J + 1 < KMAX) {
+            if (more) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float acc = g[r];
+                for (int r = 0; r < R; ++r) {
+                    float acc = g[r];
 #pragma unroll
-            for (int i = 0; i < J; ++i) acc = fmaf(-w[i], s.p[i][r], acc);
-            acc *= inv;
-            s.p[J][r] = acc;
-            s.a[r] = fmaf(-t, acc, s.a[r]);
+                    for (int i = 0; i < J; ++i) acc = fmaf(-w[i], s.p[i][r], acc);
+                    acc *= inv;
+                    s.p[J][r] = acc;
+                    s.a[r] = fmaf(-t, acc, s.a[r]);
+                }
+            }
         }
         float lr = 0.f;
 #pragma unroll
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void bomp_wave_kernel(const fl
     if (sig >= N) return;
 
     OmpState<R, KMAX> s;
-    load_row<R>(alpha0 + sig * L::Kp, lane, s.a);
+    load_row<R, true>(alpha0 + sig * L::Kp, lane, s.a);
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) s.Lrow[j] = 0.f;
     s.tv = 0.f;

@@ -63,15 +63,23 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_i(int x) {
     return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
 }
-// Wave-wide max of a non-negative float, result uniform (SGPR) -- 4 row steps + 2 row broadcasts, no LDS.
+// DPP move with 0 for lanes whose source is invalid (old = 0, bound_ctrl).
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u0(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+// Wave-wide max of a NON-NEGATIVE float, result uniform (SGPR) -- 4 row steps + 2 row broadcasts, no LDS.
+// Done on the bit patterns (for x >= 0 the unsigned order equals the float order): v_max_u32 needs no NaN
+// canonicalisation and takes the DPP source directly (v_max_u32_dpp), 1 VALU op per step instead of 3.
 __device__ __forceinline__ float wave_max_f(float x) {
-    x = fmaxf(x, dpp_f<0xB1>(x));   // quad_perm [1,0,3,2]
-    x = fmaxf(x, dpp_f<0x4E>(x));   // quad_perm [2,3,0,1]
-    x = fmaxf(x, dpp_f<0x124>(x));  // row_ror:4
-    x = fmaxf(x, dpp_f<0x128>(x));  // row_ror:8  -> every lane of a 16-lane row holds the row max
-    x = fmaxf(x, dpp_f<0x142>(x));  // row_bcast:15
-    x = fmaxf(x, dpp_f<0x143>(x));  // row_bcast:31 -> lane 63 holds the wave max
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u = max(u, dpp_u0<0xB1>(u));   // quad_perm [1,0,3,2]
+    u = max(u, dpp_u0<0x4E>(u));   // quad_perm [2,3,0,1]
+    u = max(u, dpp_u0<0x124>(u));  // row_ror:4
+    u = max(u, dpp_u0<0x128>(u));  // row_ror:8  -> every lane of a 16-lane row holds the row max
+    u = max(u, dpp_u0<0x142>(u));  // row_bcast:15
+    u = max(u, dpp_u0<0x143>(u));  // row_bcast:31 -> lane 63 holds the wave max
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)u, 63));
 }
 __device__ __forceinline__ int wave_min_i(int x) {
     x = min(x, dpp_i<0xB1>(x));

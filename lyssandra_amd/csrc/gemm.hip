@@ -18,6 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GM_BM = 128, GM_BN = 128, GM_BK = 32, GM_LD = GM_BK + 4;
 
+template <bool STREAM_C>  // STREAM_C: C is write-once/read-once (alpha0) -> non-temporal stores keep G resident in L2
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                            const float* __restrict__ B, int64_t ldb,
                                                            float* __restrict__ C, int64_t ldc,
@@ -114,13 +115,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < M && col < Nc) C[row * ldc + col] = acc[i][j][r];
+                if (row < M && col < Nc) {
+                    if constexpr (STREAM_C)
+                        __builtin_nontemporal_store(acc[i][j][r], &C[row * ldc + col]);
+                    else
+                        C[row * ldc + col] = acc[i][j][r];
+                }
             }
         }
 }
 
 int gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int Nc,
-            int Kin, hipStream_t stream) {
+            int Kin, hipStream_t stream, bool stream_c) {
     if (M <= 0 || Nc <= 0) return LYS_OK;
     const int64_t n_rt = (M + GM_BM - 1) / GM_BM;
     const int n_ct = (Nc + GM_BN - 1) / GM_BN;
@@ -129,8 +135,12 @@ int gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, 
         set_error("gemm_nt: grid too large (%lld blocks)", (long long)blocks);
         return LYS_ENOSUP;
     }
-    hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, Nc,
-                       Kin);
+    if (stream_c)
+        hipLaunchKernelGGL(gemm_nt_f32_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, A, lda, B, ldb, C,
+                           ldc, M, Nc, Kin);
+    else
+        hipLaunchKernelGGL(gemm_nt_f32_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, A, lda, B, ldb, C,
+                           ldc, M, Nc, Kin);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }

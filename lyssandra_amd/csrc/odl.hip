@@ -11,7 +11,7 @@
 namespace lys {
 
 int gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int Nc,
-            int Kin, hipStream_t stream);
+            int Kin, hipStream_t stream, bool stream_c = false);
 int transpose(const float* src, int rows, int cols, int ld_src, float* dst, int ld_dst, hipStream_t stream);
 
 __global__ __launch_bounds__(256) void odl_increment_kernel(const float* __restrict__ X, int64_t ldx, int n, int Kp,

@@ -1,37 +1,39 @@
-"""Condense rocprofv3 outputs (kernel stats + PMC csv) into a small text summary for profiles/."""
-import csv
+"""Condense rocprofv3 outputs (rocpd sqlite .db, the default format of this rocprofv3) into a text summary."""
 import glob
 import os
+import sqlite3
 import sys
-from collections import defaultdict
 
 root = sys.argv[1]
 
 
 def short(name):
     name = name.split("(")[0]
-    return name[-90:]
+    return name[-84:]
 
 
-print("== rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1) ==")
-for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    rows = list(csv.DictReader(open(f)))
-    print("file:", os.path.relpath(f, root))
-    print("%-92s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
-    for r in rows[:14]:
-        print("%-92s %8s %14s %12s %8s" % (short(r.get("Name", "")), r.get("Calls"), r.get("TotalDurationNs"),
-                                            r.get("AverageNs"), r.get("Percentage")))
-for tag in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_mfma"):
-    files = glob.glob(os.path.join(root, tag, "**", "*counter_collection.csv"), recursive=True)
-    for f in files:
-        agg = defaultdict(lambda: defaultdict(float))
-        cnt = defaultdict(set)
-        for r in csv.DictReader(open(f)):
-            k = short(r.get("Kernel_Name", ""))
-            agg[k][r.get("Counter_Name")] += float(r.get("Counter_Value", 0) or 0)
-            cnt[k].add(r.get("Dispatch_Id"))
-        print("\n== PMC pass %s: per-dispatch averages ==" % tag)
-        for k in sorted(agg, key=lambda x: -len(cnt[x])):
-            n = max(1, len(cnt[k]))
-            vals = ", ".join("%s=%.4g" % (c, v / n) for c, v in sorted(agg[k].items()))
-            print("%-70s dispatches=%d  %s" % (k[-70:], n, vals))
+for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
+    db = sqlite3.connect(f)
+    cur = db.cursor()
+    tag = os.path.basename(os.path.dirname(f))
+    if tag == "trace":
+        print("== rocprofv3 --kernel-trace --stats :: %s ==" % os.path.relpath(f, root))
+        print("%-86s %7s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+        for name, calls, tot, avg, pct in cur.execute(
+                "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 16"):
+            print("%-86s %7d %14d %12.0f %7.2f" % (short(name), calls, tot, avg, pct))
+        print("\nregister / LDS use per kernel (from the dispatch records):")
+        for name, v, a, s, lds, wg, gx in cur.execute(
+                "select name,vgpr_count,accum_vgpr_count,sgpr_count,lds_size,workgroup_x,max(grid_x) from kernels group by name order by sum(duration) desc limit 10"):
+            print("%-86s vgpr=%s agpr=%s sgpr=%s lds=%s wg=%s max_grid=%s" % (short(name), v, a, s, lds, wg, gx))
+    else:
+        print("\n== PMC pass %s: per-dispatch averages (sum over instances) ==" % tag)
+        q = ("select k.name, e.counter_name, sum(e.counter_value), count(distinct e.dispatch_id), avg(k.duration) "
+             "from pmc_events e join kernels k on k.dispatch_id = e.dispatch_id group by k.name, e.counter_name")
+        rows = {}
+        for name, cname, tot, nd, dur in cur.execute(q):
+            rows.setdefault(name, {"n": nd, "dur": dur})[cname] = tot / max(1, nd)
+        for name in sorted(rows, key=lambda x: -rows[x]["n"])[:8]:
+            r = rows[name]
+            vals = ", ".join("%s=%.5g" % (c, v) for c, v in sorted(r.items()) if c not in ("n", "dur"))
+            print("%-60s dispatches=%d avg_ns=%.0f  %s" % (short(name)[-60:], r["n"], r["dur"], vals))
