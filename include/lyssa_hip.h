@@ -145,6 +145,13 @@ int lys_norm_atoms(float* D_packed, int n, int K, void* stream);
 int lys_densify_f64(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N,
                     double* Z, void* stream);
 /*
+ * DIAGNOSTICS ONLY: timing ablations of the greedy kernel at Kp = 1024, k <= 10 (variant 0 = product kernel;
+ * 1 = Gram rows forced cache-hot, 2 = no orthogonalisation FMAs, 3 = IEEE sqrt/divide; 1 and 2 give WRONG
+ * results on purpose).  `lds_bytes` of dynamic LDS (<= 64 KiB) throttles resident workgroups per CU.
+ */
+int lys_debug_bomp_variant(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef,
+                           int32_t* nnz, int variant, int lds_bytes, void* stream);
+/*
  * Per-stage HIP-event profile of lys_bomp_encode: when enabled, every tile records events before the
  * alpha0 GEMM, between GEMM and greedy kernel, and after the greedy kernel, on the caller's stream.
  * lys_profile_collect synchronises on them, returns the summed kernel durations (ms), the number of

@@ -37,6 +37,7 @@ int pack_dictionary(const float*, int, int, float*, hipStream_t);
 bool bomp_has_wave_kernel(int Kp, int k);
 size_t bomp_generic_scratch_bytes(int Kp, int k);
 int bomp_from_alpha0(const float*, const float*, int, int, int64_t, int32_t*, float*, int32_t*, float*, hipStream_t);
+int bomp_debug_variant(const float*, const float*, int64_t, int, int32_t*, float*, int32_t*, int, int, hipStream_t);
 int residual(const float*, int64_t, const float*, int, int, int, int64_t, const int32_t*, const float*, const int32_t*,
              float*, int64_t, double*, hipStream_t);
 size_t csr_workspace_bytes(int, int, int64_t);
@@ -56,10 +57,14 @@ int odl_update(float*, const float*, const float*, int, int, int, float*, hipStr
 int norm_atoms(float*, int, int, hipStream_t);
 int densify_f64(const int32_t*, const float*, const int32_t*, int, int, int64_t, double*, hipStream_t);
 
-// alpha0 tile: how many signals per GEMM+OMP round.  Two tiles of ~64 MiB are in flight (ping-pong), which keeps
-// the producer->consumer hand-off of alpha0 inside the 256 MiB Infinity Cache instead of HBM.
+// alpha0 tile: how many signals per GEMM + greedy round.  Measured on MI355X (tools/omp_ab.py): the greedy kernel
+// runs 6 % faster at 262144 signals per launch than at 32768 (launch ramp/tail amortised); keeping the alpha0
+// hand-off inside the 256 MiB Infinity Cache (32768-signal tiles) bought nothing because the kernel is bound by
+// the latency of Gram-row fetches that miss L2, not by HBM bandwidth.  1 GiB of alpha0 per tile.
 static int64_t tile_signals(int Kp) {
-    const int64_t bytes = 64ll << 20;
+    int64_t bytes = 1ll << 30;
+    const char* e = getenv("LYS_TILE_MB");
+    if (e && atoi(e) > 0) bytes = (int64_t)atoi(e) << 20;
     int64_t t = bytes / ((int64_t)Kp * 4);
     t = (t / 512) * 512;
     return t < 512 ? 512 : t;
@@ -126,7 +131,7 @@ static bool pipeline_enabled() {
     static int cached = -1;
     if (cached < 0) {
         const char* e = getenv("LYS_PIPELINE");
-        cached = (e && e[0] == '0') ? 0 : 1;
+        cached = (e && e[0] == '1') ? 1 : 0;  // off by default: measured slower (both kernels contend in L2)
     }
     return cached == 1;
 }
@@ -173,7 +178,7 @@ int lys_gram(const float* D_packed, int n, int K, float* G, void* stream) {
 size_t lys_bomp_workspace_bytes(int n, int K, int k, int64_t N) {
     const int Kp = padded_atoms(K);
     const int64_t t = tile_signals(Kp);
-    int64_t rows = (N <= t) ? ((N < 1) ? 1 : N) : 2 * t;  // one tile, or two ping-pong tiles
+    int64_t rows = (N <= t) ? ((N < 1) ? 1 : N) : (pipeline_enabled() ? 2 * t : t);  // one tile (two if ping-pong)
     size_t bytes = (size_t)rows * (size_t)Kp * sizeof(float);
     if (!bomp_has_wave_kernel(Kp, k)) bytes += bomp_generic_scratch_bytes(Kp, k);
     return bytes;
@@ -345,6 +350,16 @@ int lys_densify_f64(const int32_t* idx, const float* coef, const int32_t* nnz, i
                     void* stream) {
     LYS_REQUIRE(idx && coef && nnz && Z, "densify: null pointer");
     return densify_f64(idx, coef, nnz, K, k, N, Z, STREAM(stream));
+}
+
+int lys_debug_bomp_variant(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef,
+                           int32_t* nnz, int variant, int lds_bytes, void* stream) {
+    LYS_REQUIRE(alpha0 && G && idx && coef && nnz && k >= 1 && k <= 10, "debug_bomp_variant: bad arguments");
+    if (lds_bytes > 64 * 1024) {
+        set_error("lds_bytes > 64 KiB needs the max-dynamic-LDS attribute");
+        return LYS_EINVAL;
+    }
+    return bomp_debug_variant(alpha0, G, N, k, idx, coef, nnz, variant, lds_bytes, STREAM(stream));
 }
 
 int lys_profile_enable(int on) {

@@ -61,17 +61,17 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, int lane
     }
 }
 
-// Uniform extraction  w[i] = p[i][rr](lane L)  for i < J, with rr only known at run time (wave-uniform):
+// Uniform extraction  w[i] = p[i][rr](lane L)  for NLDS <= i < J, with rr only known at run time (wave-uniform):
 // an if-chain over rr keeps every register index static (dynamic VGPR indexing would go to scratch).
-template <int R, int KMAX, int J, int RR>
-__device__ __forceinline__ void extract_case(const float (&p)[KMAX - 1 > 0 ? KMAX - 1 : 1][R], int rr, int L,
-                                             float (&w)[KMAX]) {
+template <int R, int KMAX, int NLDS, int J, int RR>
+__device__ __forceinline__ void extract_case(const float (&p)[(KMAX - 1 - NLDS) > 0 ? (KMAX - 1 - NLDS) : 1][R], int rr,
+                                             int L, float (&w)[KMAX]) {
     if constexpr (RR < R) {
         if (rr == RR) {
 #pragma unroll
-            for (int i = 0; i < J; ++i) w[i] = readlane_f(p[i][RR], L);
+            for (int i = NLDS; i < J; ++i) w[i] = readlane_f(p[i - NLDS][RR], L);
         } else {
-            extract_case<R, KMAX, J, RR + 1>(p, rr, L, w);
+            extract_case<R, KMAX, NLDS, J, RR + 1>(p, rr, L, w);
         }
     }
 }
@@ -121,21 +121,28 @@ __device__ __forceinline__ bool wave_argmax(const float (&a)[R], int lane, int& 
     return true;
 }
 
-template <int R, int KMAX>
+// NLDS of the k-1 orthogonalised vectors (the oldest ones, p_0..p_{NLDS-1}) live in LDS instead of VGPRs: each
+// costs 4 KB of LDS per wave and 4 ds_read_b128 per step, and frees 16 VGPRs -- at K=1024, k=10 three of them
+// bring the kernel under 168 VGPRs = 3 waves/SIMD, which is what hides the Gram-row fetch latency.
+template <int R, int KMAX, int NLDS>
 struct OmpState {
-    float a[R];         // current correlations
-    float p[KMAX - 1 > 0 ? KMAX - 1 : 1][R];   // orthogonalised Gram columns (the last selection needs none)
-    float Lrow[KMAX];   // Lrow[j] lane i (<j) = L[j][i]
-    float tv;           // lane j = t_j
-    float rinv;         // lane j = 1/rho_j
-    int dxv;            // lane j = Dx[j]
+    float a[R];                                                     // current correlations
+    float p[(KMAX - 1 - NLDS) > 0 ? (KMAX - 1 - NLDS) : 1][R];      // p_i for i >= NLDS (the last selection needs none)
+    float Lrow[KMAX];                                               // Lrow[j] lane i (<j) = L[j][i]
+    float tv;                                                       // lane j = t_j
+    float rinv;                                                     // lane j = 1/rho_j
+    int dxv;                                                        // lane j = Dx[j]
     int nsel;
 };
 
 // Steps J..KMAX-1 as a compile-time recursion (a loop with early exits around the convergent cross-lane
 // operations is not unrolled by the compiler, which would push p[][] to scratch).
-template <int R, int KMAX, int J>
-__device__ __forceinline__ void omp_steps(OmpState<R, KMAX>& s, const float* __restrict__ G, int k, int lane) {
+// VAR != 0 are timing ablations (wrong results on purpose; reachable only through lys_debug_bomp_variant):
+//   1: Gram row index forced to kk & 7 (cache-hot rows)   2: no orthogonalisation FMAs   3: IEEE sqrt + divide
+//   4: Gram rows restricted to kk & 255 (1 MB, L2-resident)   5: kk & 63 (256 KB)
+template <int R, int KMAX, int NLDS, int J, int VAR = 0>
+__device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const float* __restrict__ G, int k, int lane,
+                                          f32x4* __restrict__ lds /* [NLDS][R/4][64] of this wave */) {
     using L = Lay<R>;
     if constexpr (J < KMAX) {
         if (J >= k) return;
@@ -150,29 +157,80 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX>& s, const float* __r
         const bool more = (J + 1 < KMAX) && (J + 1 < k);
         // Gram row of the new atom (G is symmetric: row kk == column kk), issued before the scalar work
         float g[R];
-        if (more) load_row<R>(G + (int64_t)kk * L::Kp, lane, g);
+        if (more)
+            load_row<R>(G + (int64_t)(VAR == 1 ? (kk & 7) : VAR == 4 ? (kk & 255) : VAR == 5 ? (kk & 63)
+                                      : VAR == 6 ? (kk % 768) : VAR == 7 ? (kk & 511) : VAR == 8 ? (kk % 896) : kk) * L::Kp,
+                        lane, g);
 
         float w[KMAX];
-        extract_case<R, KMAX, J, 0>(s.p, rown, Lown, w);
+        if constexpr (NLDS > 0) {
+            // element kk of an LDS-resident vector: one broadcast read
+            const float* lf = reinterpret_cast<const float*>(lds);
+#pragma unroll
+            for (int i = 0; i < (J < NLDS ? J : NLDS); ++i) {
+                const float v = lf[((i * L::C + (rown >> 2)) * 64 + Lown) * 4 + (rown & 3)];
+                w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+            }
+        }
+        if constexpr (J > NLDS) extract_case<R, KMAX, NLDS, J, 0>(s.p, rown, Lown, w);
         float vs = 1.f;
 #pragma unroll
         for (int i = 0; i < J; ++i) vs = fmaf(-w[i], w[i], vs);
         if (J > 0 && vs < EPS32_F) return;  // reference: vs < eps (:335,345); the fp32 engine uses fp32 eps
         // 1/sqrt(vs): hardware rsq (1 ulp) + one Newton step instead of an IEEE sqrt and an IEEE divide
-        float inv = __builtin_amdgcn_rsqf(vs);
-        inv = inv * fmaf(-0.5f * vs, inv * inv, 1.5f);
+        float inv;
+        if constexpr (VAR == 3) {
+            inv = 1.f / sqrtf(vs);
+        } else {
+            inv = __builtin_amdgcn_rsqf(vs);
+            inv = inv * fmaf(-0.5f * vs, inv * inv, 1.5f);
+        }
         const float t = akk * inv;
 
         if constexpr (J + 1 < KMAX) {
             if (more) {
+                if constexpr (NLDS > 0) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float acc = g[r];
+                    for (int c = 0; c < L::C; ++c) {
+                        f32x4 acc = {g[4 * c], g[4 * c + 1], g[4 * c + 2], g[4 * c + 3]};
 #pragma unroll
-                    for (int i = 0; i < J; ++i) acc = fmaf(-w[i], s.p[i][r], acc);
-                    acc *= inv;
-                    s.p[J][r] = acc;
-                    s.a[r] = fmaf(-t, acc, s.a[r]);
+                        for (int i = 0; i < (VAR == 2 ? 0 : J); ++i) {
+                            f32x4 pv;
+                            if (i < NLDS) {
+                                pv = lds[(i * L::C + c) * 64 + lane];
+                            } else {
+                                pv = f32x4{s.p[i - NLDS][4 * c], s.p[i - NLDS][4 * c + 1], s.p[i - NLDS][4 * c + 2],
+                                           s.p[i - NLDS][4 * c + 3]};
+                            }
+                            acc.x = fmaf(-w[i], pv.x, acc.x);
+                            acc.y = fmaf(-w[i], pv.y, acc.y);
+                            acc.z = fmaf(-w[i], pv.z, acc.z);
+                            acc.w = fmaf(-w[i], pv.w, acc.w);
+                        }
+                        acc *= inv;
+                        if constexpr (J < NLDS) {
+                            lds[(J * L::C + c) * 64 + lane] = acc;
+                        } else {
+                            s.p[J - NLDS][4 * c] = acc.x;
+                            s.p[J - NLDS][4 * c + 1] = acc.y;
+                            s.p[J - NLDS][4 * c + 2] = acc.z;
+                            s.p[J - NLDS][4 * c + 3] = acc.w;
+                        }
+                        s.a[4 * c] = fmaf(-t, acc.x, s.a[4 * c]);
+                        s.a[4 * c + 1] = fmaf(-t, acc.y, s.a[4 * c + 1]);
+                        s.a[4 * c + 2] = fmaf(-t, acc.z, s.a[4 * c + 2]);
+                        s.a[4 * c + 3] = fmaf(-t, acc.w, s.a[4 * c + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float acc = g[r];
+#pragma unroll
+                        for (int i = 0; i < (VAR == 2 ? 0 : J); ++i) acc = fmaf(-w[i], s.p[i][r], acc);
+                        acc *= inv;
+                        s.p[J][r] = acc;
+                        s.a[r] = fmaf(-t, acc, s.a[r]);
+                    }
                 }
             }
         }
@@ -184,22 +242,25 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX>& s, const float* __r
         s.rinv = writelane_f(inv, J, s.rinv, lane);
         s.dxv = writelane_i(kk, J, s.dxv, lane);
         s.nsel = J + 1;
-        omp_steps<R, KMAX, J + 1>(s, G, k, lane);
+        omp_steps<R, KMAX, NLDS, J + 1, VAR>(s, G, k, lane, lds);
     }
 }
 
-template <int R, int KMAX, int WAVES_PER_SIMD>
+template <int R, int KMAX, int WAVES_PER_SIMD, int NLDS = 0, int VAR = 0>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void bomp_wave_kernel(const float* __restrict__ alpha0,
                                                                         const float* __restrict__ G, int64_t N, int k,
                                                                         int32_t* __restrict__ idx_out,
                                                                         float* __restrict__ coef_out,
                                                                         int32_t* __restrict__ nnz_out) {
     using L = Lay<R>;
+    static_assert(NLDS == 0 || L::V == 4, "LDS-resident vectors need the dwordx4 layout");
+    __shared__ f32x4 s_p[NLDS > 0 ? 4 * NLDS * L::C * 64 : 1];
     const int lane = threadIdx.x & 63;
-    const int64_t sig = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = threadIdx.x >> 6;
+    const int64_t sig = (int64_t)blockIdx.x * 4 + wid;
     if (sig >= N) return;
 
-    OmpState<R, KMAX> s;
+    OmpState<R, KMAX, NLDS> s;
     load_row<R, true>(alpha0 + sig * L::Kp, lane, s.a);
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) s.Lrow[j] = 0.f;
@@ -207,7 +268,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void bomp_wave_kernel(const fl
     s.rinv = 0.f;
     s.dxv = -1;
     s.nsel = 0;
-    omp_steps<R, KMAX, 0>(s, G, k, lane);
+    omp_steps<R, KMAX, NLDS, 0, VAR>(s, G, k, lane, s_p + wid * (NLDS * L::C * 64));
     const int nsel = s.nsel;
 
     // z = L^-T t  (second triangular solve, sparse_coding.py:354), column-oriented over lanes
@@ -353,8 +414,14 @@ static int launch_wave(const float* alpha0, const float* G, int64_t N, int k, in
         set_error("bomp: too many signals per launch (%lld)", (long long)N);
         return LYS_ENOSUP;
     }
-    hipLaunchKernelGGL((bomp_wave_kernel<R, KMAX, W>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N, k,
-                       idx, coef, nnz);
+    if constexpr (R == 16 && KMAX == 10) {
+        // headline shape: 3 vectors in LDS -> <= 168 VGPRs -> 3 waves/SIMD (48 KB LDS per 4-wave workgroup)
+        hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N,
+                           k, idx, coef, nnz);
+    } else {
+        hipLaunchKernelGGL((bomp_wave_kernel<R, KMAX, W>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N,
+                           k, idx, coef, nnz);
+    }
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -371,6 +438,30 @@ static int dispatch_k(const float* alpha0, const float* G, int64_t N, int k, int
         if (k <= 32) return launch_wave<R, 32>(alpha0, G, N, k, idx, coef, nnz, stream);
     }
     return 1;  // not covered by a register kernel
+}
+
+// timing ablations of the headline shape (Kp = 1024, k <= 10); `lds_bytes` of dynamic LDS throttle blocks per CU
+int bomp_debug_variant(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
+                       int variant, int lds_bytes, hipStream_t stream) {
+    const dim3 grid((unsigned)((N + 3) / 4)), block(256);
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 1: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 1>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 2: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 2>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 3: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 3>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 4: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 5: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 6: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 1>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 7: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 3, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 8: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 4>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 9: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 5>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 10: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 6>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 11: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 7>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 12: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 8>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        default: set_error("unknown variant %d", variant); return LYS_EINVAL;
+    }
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
 }
 
 // true when (K,k) is served by a register-resident wave kernel
