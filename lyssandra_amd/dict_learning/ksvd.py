@@ -47,7 +47,8 @@ def _scatter_codes(X, idx, coef, nnz):
 
 def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
                     max_iter=20, non_neg=False, approx=False, eta=None,
-                    n_cycles=1, n_jobs=1, mmap=False, verbose=True, return_codes=True, group=None):
+                    n_cycles=1, n_jobs=1, mmap=False, verbose=True, return_codes=True, group=None, shard_span=None,
+                    n_total=None):
     """lyssa/dict_learning/ksvd.py:129-231 (``approx=True`` path).
 
     Returns ``(D, Z)`` with D float64 (n, K) and Z dense float64 (K, N) -- pass ``return_codes=False`` to skip
@@ -56,7 +57,10 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
         loop stops after 11 iterations whatever ``max_iter`` is;
       * unused atoms are replaced by random unused datapoints drawn with ``np.random.choice`` (:199-207);
       * the error is evaluated with the atom-updated codes and the final dictionary (:220).
-    ``group``: torch.distributed group when X is this rank's shard of the signals (statistics all-reduced).
+    ``group``: torch.distributed group when X is THIS RANK'S SHARD of the signals, columns
+    ``shard_span = (start, stop)`` of ``n_total`` (lyssandra_amd.dist.local_shard): per-atom statistics and the error
+    are all-reduced, `init_dict='data'` and the unused-atom replacement work on GLOBAL signal indices (every rank
+    must hold the same numpy RNG state).  The returned codes are the local shard's.
     """
     if not approx or non_neg:
         raise NotImplementedError("only approx=True, non_neg=False is on the accelerated path "
@@ -66,9 +70,16 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
     X = np.asarray(X)
     n_features, n_samples = X.shape
     unused_data = []
+    if group is not None:
+        from .. import dist as _dist
+        if shard_span is None or n_total is None:
+            raise ValueError("group mode needs shard_span=(start, stop) and n_total")
     if isinstance(init_dict, str) and init_dict == 'data':
-        from .utils import init_dictionary
-        D, unused_data = init_dictionary(X, n_atoms, method=init_dict, return_unused_data=True)
+        if group is None:
+            from .utils import init_dictionary
+            D, unused_data = init_dictionary(X, n_atoms, method=init_dict, return_unused_data=True)
+        else:
+            D, unused_data = _dist.init_dictionary_sharded(X, shard_span, n_total, n_atoms, group)
     else:
         D = np.copy(init_dict)
     Xs = engine.signals_to_device(X)
@@ -104,7 +115,8 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
                 break
             _idx = np.random.choice(unused_data, size=1)
             i_ = _idx[0]
-            dd.set_atom(unused_atoms[j], normalize(np.asarray(X[:, i_], dtype=np.float64)))
+            col = X[:, i_] if group is None else _dist.fetch_global_column(X, shard_span, int(i_), group)
+            dd.set_atom(unused_atoms[j], normalize(np.asarray(col, dtype=np.float64)))
             unused_data.remove(i_)
         # ---- error with the updated codes (ksvd.py:220)
         error_curr = engine.approx_error(Xs, dd, idx, coef, nnz)

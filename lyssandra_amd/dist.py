@@ -1,0 +1,130 @@
+"""Multi-GPU protocols of the hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference's only parallel strategy is a data-parallel map over column batches of the signal matrix
+(`run_parallel`, lyssa/utils/__init__.py:40-163: 100 even batches, results scattered back by column).  The GPU
+counterpart: every rank owns ONE contiguous signal shard (`shard_range`, the `gen_even_batches` partition), the
+dictionary is replicated.
+
+  * encode           -- no collective at all (signals are independent given D);
+  * approx K-SVD     -- exact reference semantics need, per atom IN ORDER, the sum over shards of the n+1 numbers
+                        [sum_i R_i x_i , sum_i x_i^2] before the atom is normalised (lyssa/dict_learning/ksvd.py:116-119);
+                        coefficient and residual updates are then shard-local (:121-123);
+  * online DL        -- one all-reduce of [dA | dB] per mini-batch (online_dict_learn.py:84-85), then the identical
+                        replicated update (:91-98);
+  * errors, counts   -- scalar / K-vector all-reduces.
+
+The protocol functions below are written against a small `ops` interface so that the SAME control flow runs on the
+HIP engine (engine.HipKsvdOps / engine.OdlState) and, in the CPU tests (gloo, world_size 2), on a numpy stand-in.
+"""
+import numpy as np
+
+from .utils import shard_range  # noqa: F401  (re-export)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world(group=None):
+    dist = _dist()
+    if not dist.is_available() or not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def allreduce_sum_(t, group=None):
+    """In-place sum over ranks of a torch tensor (no-op without an initialised process group)."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if not t.is_cuda and dist.get_backend(group) == "nccl":
+            import torch
+            d = t.to(torch.device("cuda", torch.cuda.current_device()))  # RCCL only moves device memory
+            dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(d.cpu())
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def local_shard(X, group=None):
+    """Columns of the (n, N) host matrix that belong to this rank (contiguous, remainder to the last rank)."""
+    ws, rk = world(group)
+    s, e = shard_range(X.shape[1], ws, rk)
+    return X[:, s:e], (s, e)
+
+
+# ------------------------------------------------------------------------------------------------ approx K-SVD
+def ksvd_cycle_sharded(ops, K, group=None):
+    """One dictionary-update cycle over signal shards.  `ops` provides, for the LOCAL shard:
+
+        ops.local_counts()        -> int64 tensor [K]: number of local non-zeros per atom
+        ops.accumulate(a)         -> enqueue phase 1 of atom a into ops.stats(a)
+        ops.stats(a)              -> fp64 tensor [n+1] (view into the statistics buffer) to be all-reduced
+        ops.apply(a)              -> phase 2 of atom a from the reduced statistics (also publishes d_new)
+        ops.commit(global_counts) -> D[a] <- d_new for every atom that is used on ANY rank
+
+    Returns the list of atoms unused on every rank (ksvd.py:111-115).  Atoms are visited strictly in order.
+    """
+    counts = ops.local_counts()
+    allreduce_sum_(counts, group)
+    for a in range(K):
+        ops.accumulate(a)
+        allreduce_sum_(ops.stats(a), group)
+        ops.apply(a)
+    ops.commit(counts)
+    return [int(a) for a in (counts == 0).nonzero().flatten().tolist()]
+
+
+# ------------------------------------------------------------------------------------------------ online DL
+def odl_batch_sharded(ops, beta, non_neg=False, group=None):
+    """One mini-batch of online DL over shards: local increments, one all-reduce of [dA | dB], replicated update.
+
+        ops.increments() -> (dA, dB) tensors holding the LOCAL Z Z' and X Z'
+        ops.update(beta, non_neg) -> A = beta A + dA; B = beta B + dB; dictionary update
+    """
+    dA, dB = ops.increments()
+    allreduce_sum_(dA, group)
+    allreduce_sum_(dB, group)
+    ops.update(beta, non_neg)
+
+
+# ------------------------------------------------------------------------------------------------ host helpers
+def init_dictionary_sharded(X_local, span, N_total, n_atoms, group=None):
+    """`init_dictionary(method='data')` (lyssa/dict_learning/utils.py:49-70) when the signals are sharded.
+
+    Every rank must hold the same numpy global-RNG state (seed identically): the candidate list (columns with
+    energy > 1e-6) is all-gathered, the SAME `np.random.choice` draw is made everywhere, chosen columns are
+    contributed by their owners through one all-reduce.  Returns (D (n, K) float64, unused_data as GLOBAL indices).
+    """
+    import torch
+    from .utils.math import norm_cols
+    n = X_local.shape[0]
+    s, e = span
+    mask = torch.zeros((N_total,), dtype=torch.int32)
+    mask[s:e] = torch.from_numpy((np.einsum('ij,ij->j', X_local, X_local) > 1e-6).astype(np.int32))
+    allreduce_sum_(mask, group)
+    idxs = np.flatnonzero(mask.numpy()).tolist()
+    if len(idxs) < n_atoms:
+        raise ValueError("not enough datapoints to initialize the dictionary")
+    subset = np.random.choice(len(idxs), size=n_atoms, replace=False)
+    subset_idxs = np.array(idxs).astype(int)[subset]
+    D = torch.zeros((n, n_atoms), dtype=torch.float64)
+    for j, g in enumerate(subset_idxs):
+        if s <= g < e:
+            D[:, j] = torch.from_numpy(np.asarray(X_local[:, g - s], dtype=np.float64))
+    allreduce_sum_(D, group)
+    D = norm_cols(D.numpy().copy())
+    chosen = set(subset_idxs.tolist())
+    return D, [x for x in idxs if x not in chosen]
+
+
+def fetch_global_column(X_local, span, g, group=None):
+    """Column `g` (global index) of the sharded signal matrix on every rank (owner contributes, others add zeros)."""
+    import torch
+    s, e = span
+    v = torch.zeros((X_local.shape[0],), dtype=torch.float64)
+    if s <= g < e:
+        v += torch.from_numpy(np.asarray(X_local[:, g - s], dtype=np.float64))
+    allreduce_sum_(v, group)
+    return v.numpy()

@@ -238,42 +238,66 @@ def csr_by_atom(idx, coef, nnz, K):
 
 
 # --------------------------------------------------------------------------------------------- approx K-SVD
+class HipKsvdOps(object):
+    """`ops` of dist.ksvd_cycle_sharded on the HIP engine (one atom = two kernel launches, stats in fp64)."""
+
+    def __init__(self, R, dd, idx, coef, nnz):
+        torch = _torch()
+        self.lib = _lib.load()
+        self.R, self.dd, self.coef = R, dd, coef
+        self.k = int(idx.shape[1])
+        self.row_ptr, self.entry = csr_by_atom(idx, coef, nnz, dd.K)
+        self.sbuf = torch.zeros((dd.K, dd.n + 1), dtype=torch.float64, device=dd.device)
+        self.Dnext = torch.zeros_like(dd.D)
+
+    def local_counts(self):
+        torch = _torch()
+        return (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
+
+    def accumulate(self, a):
+        _lib.check(self.lib.lys_ksvd_atom_accumulate(a, _ptr(self.R), self.R.stride(0), self.dd.n, self.k,
+                                                     _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.coef),
+                                                     _ptr(self.sbuf), _stream()), "lys_ksvd_atom_accumulate")
+
+    def stats(self, a):
+        return self.sbuf[a]
+
+    def apply(self, a):
+        _lib.check(self.lib.lys_ksvd_atom_apply(a, _ptr(self.R), self.R.stride(0), self.dd.n, self.k,
+                                                _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.coef),
+                                                _ptr(self.sbuf), _ptr(self.dd.D), _ptr(self.Dnext), _stream()),
+                   "lys_ksvd_atom_apply")
+
+    def commit(self, global_counts):
+        torch = _torch()
+        used = torch.zeros((self.dd.K + 1,), dtype=torch.int32, device=self.dd.device)
+        used[1:] = torch.cumsum(torch.clamp(global_counts, max=1), 0).to(torch.int32)  # row_ptr of "used anywhere"
+        _lib.check(self.lib.lys_ksvd_commit(self.dd.n, self.dd.K, _ptr(used), _ptr(self.Dnext), _ptr(self.dd.D),
+                                            _stream()), "lys_ksvd_commit")
+        self.dd.invalidate()
+
+    def sweep_single_gpu(self):
+        """All atoms of one cycle in one C call (no per-atom Python / collective)."""
+        _lib.check(self.lib.lys_ksvd_sweep(_ptr(self.R), self.R.stride(0), self.dd.n, self.dd.K, self.k,
+                                           _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.coef), _ptr(self.sbuf),
+                                           _ptr(self.dd.D), _ptr(self.Dnext), _stream()), "lys_ksvd_sweep")
+        self.dd.invalidate()
+        counts = self.local_counts()
+        return _torch().nonzero(counts == 0).flatten().cpu().numpy().tolist()
+
+
 def ksvd_cycle(R, dd, idx, coef, nnz, group=None):
     """One dictionary-update cycle (atoms 0..K-1 in order) of approx K-SVD, in place on R, coef and dd.D.
 
     Returns the list of unused atoms of this cycle (lyssa/dict_learning/ksvd.py:111-115).
-    ``group``: torch.distributed process group => per-atom all-reduce of the n+1 sufficient statistics.
+    ``group``: torch.distributed process group => signals are sharded over its ranks and the n+1 sufficient
+    statistics of every atom are all-reduced between the two phases (dist.ksvd_cycle_sharded).
     """
-    torch = _torch()
-    lib = _lib.load()
-    N, k = int(idx.shape[0]), int(idx.shape[1])
-    row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
-    sbuf = torch.zeros((dd.K, dd.n + 1), dtype=torch.float64, device=dd.device)
-    Dnext = torch.zeros_like(dd.D)
-    dist_on = group is not None
-    if not dist_on:
-        _lib.check(lib.lys_ksvd_sweep(_ptr(R), R.stride(0), dd.n, dd.K, k, _ptr(row_ptr), _ptr(entry), _ptr(coef),
-                                      _ptr(sbuf), _ptr(dd.D), _ptr(Dnext), _stream()), "lys_ksvd_sweep")
-        counts = (row_ptr[1:] - row_ptr[:-1])
-    else:
-        import torch.distributed as dist
-        counts = (row_ptr[1:] - row_ptr[:-1]).to(torch.int64)
-        dist.all_reduce(counts, group=group)
-        # a rank whose shard does not use the atom still has to take part in the reduction and the commit
-        row_glob = torch.zeros((dd.K + 1,), dtype=torch.int32, device=dd.device)
-        row_glob[1:] = torch.cumsum(torch.clamp(counts, max=1), 0).to(torch.int32)
-        for a in range(dd.K):
-            _lib.check(lib.lys_ksvd_atom_accumulate(a, _ptr(R), R.stride(0), dd.n, k, _ptr(row_ptr), _ptr(entry),
-                                                    _ptr(coef), _ptr(sbuf), _stream()), "lys_ksvd_atom_accumulate")
-            dist.all_reduce(sbuf[a], group=group)
-            _lib.check(lib.lys_ksvd_atom_apply(a, _ptr(R), R.stride(0), dd.n, k, _ptr(row_ptr), _ptr(entry),
-                                               _ptr(coef), _ptr(sbuf), _ptr(dd.D), _ptr(Dnext), _stream()),
-                       "lys_ksvd_atom_apply")
-        _lib.check(lib.lys_ksvd_commit(dd.n, dd.K, _ptr(row_glob), _ptr(Dnext), _ptr(dd.D), _stream()),
-                   "lys_ksvd_commit")
-    dd.invalidate()
-    unused = torch.nonzero(counts == 0).flatten().cpu().numpy().tolist()
-    return unused
+    ops = HipKsvdOps(R, dd, idx, coef, nnz)
+    if group is None:
+        return ops.sweep_single_gpu()
+    from . import dist as _d
+    return _d.ksvd_cycle_sharded(ops, dd.K, group)
 
 
 # --------------------------------------------------------------------------------------------- online DL
@@ -295,17 +319,26 @@ class OdlState(object):
 
     def batch_update(self, Xs, idx, coef, nnz, beta, non_neg=False, group=None):
         """online_dict_learn.py:84-98 for one mini-batch (statistics, then the dictionary update)."""
+        from . import dist as _d
+        self._batch = (Xs, idx, coef, nnz)
+        _d.odl_batch_sharded(self, beta, non_neg=non_neg, group=group)
+        self._batch = None
+
+    # -- the `ops` interface of dist.odl_batch_sharded
+    def increments(self):
         lib = _lib.load()
         dd = self.dd
-        N, k = int(idx.shape[0]), int(idx.shape[1])
+        Xs, idx, coef, nnz = self._batch
+        k = int(idx.shape[1])
         row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
         _lib.check(lib.lys_odl_increments(_ptr(Xs), Xs.stride(0), dd.n, dd.K, k, _ptr(idx), _ptr(coef), _ptr(nnz),
                                           _ptr(row_ptr), _ptr(entry), _ptr(self.dA), _ptr(self.dB), _stream()),
                    "lys_odl_increments")
-        if group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(self.dA, group=group)
-            dist.all_reduce(self.dB, group=group)
+        return self.dA, self.dB
+
+    def update(self, beta, non_neg=False):
+        lib = _lib.load()
+        dd = self.dd
         _lib.check(lib.lys_axpby(_ptr(self.A), float(beta), _ptr(self.dA), self.A.numel(), _stream()), "lys_axpby")
         _lib.check(lib.lys_axpby(_ptr(self.B), float(beta), _ptr(self.dB), self.B.numel(), _stream()), "lys_axpby")
         _lib.check(lib.lys_odl_update(_ptr(dd.D), _ptr(self.A), _ptr(self.B), dd.n, dd.K, int(bool(non_neg)),

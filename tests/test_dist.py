@@ -1,0 +1,148 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the SAME protocol code as the GPU engine
+(lyssandra_amd.dist) with a numpy stand-in for the shard-local kernels, and must reproduce the single-process
+oracle (lyssa/dict_learning/ksvd.py:98-126, online_dict_learn.py:84-98) on the full data."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+EPS = np.finfo(np.float64).eps
+
+
+class NumpyKsvdOps(object):
+    """Shard-local phases of one approx-K-SVD atom update in numpy (test stand-in for engine.HipKsvdOps)."""
+
+    def __init__(self, Y, D, Z):
+        self.D, self.Z = D, Z
+        self.R = Y - D @ Z
+        n, K = D.shape
+        self.sbuf = torch.zeros((K, n + 1), dtype=torch.float64)
+        self.Dnext = np.zeros_like(D)
+
+    def local_counts(self):
+        return torch.from_numpy((self.Z != 0).sum(axis=1).astype(np.int64))
+
+    def accumulate(self, a):
+        om = self.Z[a] != 0
+        x = self.Z[a, om]
+        self.sbuf[a, :-1] = torch.from_numpy(self.R[:, om] @ x)
+        self.sbuf[a, -1] = float(np.dot(x, x))
+
+    def stats(self, a):
+        return self.sbuf[a]
+
+    def apply(self, a):
+        s = self.sbuf[a].numpy()
+        v = s[:-1] + self.D[:, a] * s[-1]
+        dn = v / (np.sqrt(np.dot(v, v)) + EPS)
+        self.Dnext[:, a] = dn
+        om = self.Z[a] != 0
+        if om.any():
+            xo = self.Z[a, om]
+            xn = self.R[:, om].T @ dn + xo * float(self.D[:, a] @ dn)
+            self.R[:, om] += np.outer(self.D[:, a], xo) - np.outer(dn, xn)
+            self.Z[a, om] = xn
+
+    def commit(self, counts):
+        used = counts.numpy() > 0
+        self.D[:, used] = self.Dnext[:, used]
+
+
+class NumpyOdlOps(object):
+    def __init__(self, D, A, B, Xb, Zb):
+        self.D, self.A, self.B, self.Xb, self.Zb = D, A, B, Xb, Zb
+
+    def increments(self):
+        self.dA = torch.from_numpy(self.Zb @ self.Zb.T)
+        self.dB = torch.from_numpy(self.Xb @ self.Zb.T)
+        return self.dA, self.dB
+
+    def update(self, beta, non_neg=False):
+        self.A[:] = beta * self.A + self.dA.numpy()
+        self.B[:] = beta * self.B + self.dB.numpy()
+        DA = self.D @ self.A
+        for k in range(self.D.shape[1]):
+            self.D[:, k] = (1 / (self.A[k, k] + EPS)) * (self.B[:, k] - DA[:, k]) + self.D[:, k]
+        if non_neg:
+            self.D[self.D < 0] = 0
+        self.D /= (np.sqrt((self.D * self.D).sum(0)) + EPS)[None, :]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lyssandra_amd import dist as ld
+        from oracle import lyssa_oracle as orc
+        rs = np.random.RandomState(5)
+        n, K, k, N = 16, 24, 3, 203          # N not divisible by world: remainder goes to the last rank
+        D0 = rs.randn(n, K)
+        D0 /= np.sqrt((D0 * D0).sum(0))
+        X = rs.randn(n, N)
+        X[:, 7] = 0.0                         # a zero-energy column is never an init candidate
+        Z = orc.bomp_encode(X, D0, k)
+        Z[K - 1, :] = 0.0                     # make the last atom unused on every rank
+        Xl, span = ld.local_shard(X)
+        assert span == ld.shard_range(N, world, rank)
+        # ---- approx K-SVD: sharded protocol == sequential reference semantics
+        Dl, Zl = D0.copy(), Z[:, span[0]:span[1]].copy()
+        ops = NumpyKsvdOps(Xl, Dl, Zl)
+        unused = ld.ksvd_cycle_sharded(ops, K)
+        Dref, Zref = D0.copy(), Z.copy()
+        Dref, Zref, unused_ref = orc.approx_ksvd(X, Dref, Zref, n_cycles=1)
+        assert unused == list(unused_ref) == [K - 1]
+        assert np.max(np.abs(Dl - Dref)) < 1e-12
+        assert np.max(np.abs(Zl - Zref[:, span[0]:span[1]])) < 1e-12
+        # ---- online DL: one all-reduce of [dA | dB] per batch == full-batch statistics
+        Do, Ao, Bo = D0.copy(), np.zeros((K, K)), np.zeros((n, K))
+        Dg, Ag, Bg = D0.copy(), np.zeros((K, K)), np.zeros((n, K))
+        for beta in (0.0, 0.7):
+            Zb = orc.bomp_encode(X, Dg, k)
+            ld.odl_batch_sharded(NumpyOdlOps(Do, Ao, Bo, Xl, orc.bomp_encode(Xl, Do, k)), beta)
+            Dg, Ag, Bg = orc.odl_batch_update(Dg, Ag, Bg, X, Zb, beta)
+            assert np.max(np.abs(Ao - Ag)) < 1e-10 and np.max(np.abs(Bo - Bg)) < 1e-10
+            assert np.max(np.abs(Do - Dg)) < 1e-10
+        # ---- sharded init_dictionary == the reference's on the full matrix (same global RNG state)
+        np.random.seed(77)
+        Di, unused_data = ld.init_dictionary_sharded(Xl, span, N, 9)
+        np.random.seed(77)
+        Dfull, unused_full = orc.init_dictionary(X.copy(), 9, return_unused_data=True)
+        assert np.max(np.abs(Di - Dfull)) < 1e-14 and unused_data == unused_full and 7 not in unused_data
+        col = ld.fetch_global_column(Xl, span, 150)
+        assert np.array_equal(col, X[:, 150])
+        # ---- scalar reduction used for the error
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        ld.allreduce_sum_(t)
+        assert t.item() == world * (world + 1) / 2
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_protocols_gloo_world2():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}
+
+
+def test_single_process_is_a_noop_group():
+    from lyssandra_amd import dist as ld
+    t = torch.ones(3)
+    assert ld.world() == (1, 0) and torch.equal(ld.allreduce_sum_(t), torch.ones(3))
+    X = np.arange(12.0).reshape(2, 6)
+    Xl, span = ld.local_shard(X)
+    assert span == (0, 6) and Xl.shape == (2, 6)
