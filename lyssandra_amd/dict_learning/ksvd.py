@@ -95,20 +95,23 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
     it = 0
     patience = 0
     idx = coef = nnz = None
+    out = None            # code triplet, residual and index buffers are allocated once and reused every iteration
+    R = None
+    buffers = {}
     while it < max_iter and patience < max_patience:
         it_start = time.time()
         # ---- sparse coding
         if device_coder:
-            idx, coef, nnz = sparse_coder.encode_device(Xs, dd)
+            idx, coef, nnz = out = sparse_coder.encode_device(Xs, dd, out=out)
         else:
             idx, coef, nnz = engine.sparsify_host(sparse_coder(X, dd.to_host()))
         t_sparse = time.time() - it_start
         # ---- approximate K-SVD atom updates
-        R, _ = engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+        R, _ = engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False,
+                               out=R if (R is not None and R.shape[0] == idx.shape[0]) else None)
         unused_atoms = []
         for _ in range(n_cycles):
-            unused_atoms += engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group)
-        del R
+            unused_atoms += engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group, buffers=buffers)
         # ---- replace unused atoms (host RNG, ksvd.py:199-207)
         for j in range(len(unused_atoms)):
             if len(unused_data) == 0:

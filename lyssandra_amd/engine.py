@@ -207,12 +207,17 @@ def sparsify_host(Z, k=None, device=None):
 
 
 # --------------------------------------------------------------------------------------------- residual / error
-def residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=True):
-    """R = X - DZ (signal-major [N, ldd], zero padded) and ||X - DZ||_F^2 (python float)."""
+def residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=True, out=None):
+    """R = X - DZ (signal-major [N, ldd], zero padded) and ||X - DZ||_F^2 (python float).
+
+    ``out``: a previously returned R of the same shape to reuse (its padded columns are already zero)."""
     torch = _torch()
     lib = _lib.load()
     N, k = int(idx.shape[0]), int(idx.shape[1])
-    R = torch.zeros((N, dd.ldd), dtype=torch.float32, device=dd.device) if want_R else None
+    if want_R:
+        R = out if out is not None else torch.zeros((N, dd.ldd), dtype=torch.float32, device=dd.device)
+    else:
+        R = None
     err = torch.zeros((1,), dtype=torch.float64, device=dd.device) if want_err else None
     _lib.check(lib.lys_residual(_ptr(Xs), Xs.stride(0), _ptr(dd.D), dd.n, dd.K, k, N, _ptr(idx), _ptr(coef), _ptr(nnz),
                                 _ptr(R), dd.ldd, _ptr(err), _stream()), "lys_residual")
@@ -224,12 +229,15 @@ def approx_error(Xs, dd, idx, coef, nnz):
 
 
 # --------------------------------------------------------------------------------------------- CSR by atom
-def csr_by_atom(idx, coef, nnz, K):
+def csr_by_atom(idx, coef, nnz, K, out=None):
     torch = _torch()
     lib = _lib.load()
     N, k = int(idx.shape[0]), int(idx.shape[1])
-    row_ptr = torch.empty((K + 1,), dtype=torch.int32, device=idx.device)
-    entry = torch.empty((max(1, N * k),), dtype=torch.int32, device=idx.device)
+    if out is not None:
+        row_ptr, entry = out
+    else:
+        row_ptr = torch.empty((K + 1,), dtype=torch.int32, device=idx.device)
+        entry = torch.empty((max(1, N * k),), dtype=torch.int32, device=idx.device)
     ws_bytes = lib.lys_csr_workspace_bytes(K, k, N)
     ws = _workspace(max(ws_bytes, 4), idx.device, "csr")
     _lib.check(lib.lys_csr_by_atom(_ptr(idx), _ptr(coef), _ptr(nnz), K, k, N, _ptr(row_ptr), _ptr(entry),
@@ -241,14 +249,26 @@ def csr_by_atom(idx, coef, nnz, K):
 class HipKsvdOps(object):
     """`ops` of dist.ksvd_cycle_sharded on the HIP engine (one atom = two kernel launches, stats in fp64)."""
 
-    def __init__(self, R, dd, idx, coef, nnz):
+    def __init__(self, R, dd, idx, coef, nnz, buffers=None):
         torch = _torch()
         self.lib = _lib.load()
         self.R, self.dd, self.coef = R, dd, coef
         self.k = int(idx.shape[1])
-        self.row_ptr, self.entry = csr_by_atom(idx, coef, nnz, dd.K)
-        self.sbuf = torch.zeros((dd.K, dd.n + 1), dtype=torch.float64, device=dd.device)
-        self.Dnext = torch.zeros_like(dd.D)
+        N = int(idx.shape[0])
+        if buffers is None:
+            buffers = {}
+        key = (N, self.k, dd.K, dd.n)
+        if buffers.get("key") != key:  # (re)allocate: stable pointers let lys_ksvd_sweep replay its hipGraph
+            buffers.clear()
+            buffers["key"] = key
+            buffers["row_ptr"] = torch.empty((dd.K + 1,), dtype=torch.int32, device=dd.device)
+            buffers["entry"] = torch.empty((max(1, N * self.k),), dtype=torch.int32, device=dd.device)
+            buffers["sbuf"] = torch.zeros((dd.K, dd.n + 1), dtype=torch.float64, device=dd.device)
+            buffers["Dnext"] = torch.zeros_like(dd.D)
+        self.row_ptr, self.entry = csr_by_atom(idx, coef, nnz, dd.K, out=(buffers["row_ptr"], buffers["entry"]))
+        self.sbuf = buffers["sbuf"]
+        self.sbuf.zero_()
+        self.Dnext = buffers["Dnext"]
 
     def local_counts(self):
         torch = _torch()
@@ -286,14 +306,16 @@ class HipKsvdOps(object):
         return _torch().nonzero(counts == 0).flatten().cpu().numpy().tolist()
 
 
-def ksvd_cycle(R, dd, idx, coef, nnz, group=None):
+def ksvd_cycle(R, dd, idx, coef, nnz, group=None, buffers=None):
     """One dictionary-update cycle (atoms 0..K-1 in order) of approx K-SVD, in place on R, coef and dd.D.
 
     Returns the list of unused atoms of this cycle (lyssa/dict_learning/ksvd.py:111-115).
     ``group``: torch.distributed process group => signals are sharded over its ranks and the n+1 sufficient
     statistics of every atom are all-reduced between the two phases (dist.ksvd_cycle_sharded).
+    ``buffers``: a dict kept by the caller across cycles/iterations; index / statistics buffers are allocated once
+    in it so that the sweep's captured hipGraph is replayed instead of re-captured.
     """
-    ops = HipKsvdOps(R, dd, idx, coef, nnz)
+    ops = HipKsvdOps(R, dd, idx, coef, nnz, buffers)
     if group is None:
         return ops.sweep_single_gpu()
     from . import dist as _d

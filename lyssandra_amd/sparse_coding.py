@@ -71,10 +71,11 @@ class sparse_encoder(object):
         dd = self._dictionary(D)
         return engine.bomp_encode(Xs, dd, k)
 
-    def encode_device(self, Xs, dd):
-        """Device-resident form: ``Xs`` signal-major fp32 cuda tensor [N, n], ``dd`` an engine.DeviceDictionary."""
+    def encode_device(self, Xs, dd, out=None):
+        """Device-resident form: ``Xs`` signal-major fp32 cuda tensor [N, n], ``dd`` an engine.DeviceDictionary;
+        ``out`` = a previously returned triplet to overwrite (stable buffers for iterative learners)."""
         self._check_algorithm()
-        return engine.bomp_encode(Xs, dd, self._k())
+        return engine.bomp_encode(Xs, dd, self._k(), out=out)
 
     # -- helpers ---------------------------------------------------------------------------------------
     def _k(self):

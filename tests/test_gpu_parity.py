@@ -327,9 +327,9 @@ def test_ksvd_coder_dropin(eng):
     calls = []
 
     class counting(sparse_encoder):
-        def encode_device(self, Xs, dd):
+        def encode_device(self, Xs, dd, out=None):
             calls.append(1)
-            return sparse_encoder.encode_device(self, Xs, dd)
+            return sparse_encoder.encode_device(self, Xs, dd, out=out)
 
     se = counting(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
     np.random.seed(1234)
@@ -416,9 +416,11 @@ def _sharded_worker(rank, world, port, out):
         idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
         R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
         unused = eng.ksvd_cycle(R, dd, idx, coef, nnz, group=dist.group.WORLD)
+        D_after_ksvd = dd.to_host()
         state = eng.OdlState(dd)
-        state.batch_update(Xs, idx, coef, nnz, 0.0, group=dist.group.WORLD)
-        out[rank] = dict(D=dd.to_host(), unused=unused, span=span, coef=coef.cpu().numpy(), A=state.A_host())
+        state.batch_update(Xs, idx, coef, nnz, 0.0, group=dist.group.WORLD)   # also updates dd.D (online DL)
+        out[rank] = dict(D=D_after_ksvd, unused=unused, span=span, coef=coef.cpu().numpy(), A=state.A_host(),
+                         D_odl=dd.to_host())
     finally:
         dist.destroy_process_group()
 
@@ -447,8 +449,8 @@ def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
     assert _atom_err(r0["D"], D1) < 2e-6                          # fp32 partial sums regrouped across shards
     c = np.concatenate([r0["coef"], r1["coef"]])
     assert np.max(np.abs(c - coef.cpu().numpy())) < 1e-5 * np.abs(c).max()
-    state = eng.OdlState(dd)
-    dd2 = eng.DeviceDictionary.from_host(D1)
-    st2 = eng.OdlState(dd2)
+    st2 = eng.OdlState(dd)
     st2.batch_update(Xs, idx, coef, nnz, 0.0)
-    assert np.max(np.abs(st2.A_host() - r0["A"])) < 1e-4 * np.abs(r0["A"]).max()
+    assert np.max(np.abs(st2.A_host() - r0["A"])) < 1e-5 * np.abs(r0["A"]).max()
+    assert np.array_equal(r0["D_odl"], r1["D_odl"])
+    assert _atom_err(r0["D_odl"], dd.to_host()) < 1e-5

@@ -16,7 +16,8 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
     db = sqlite3.connect(f)
     cur = db.cursor()
     tag = os.path.basename(os.path.dirname(f))
-    if tag == "trace":
+    has_pmc = cur.execute("select count(*) from pmc_events").fetchone()[0] > 0
+    if not has_pmc:
         print("== rocprofv3 --kernel-trace --stats :: %s ==" % os.path.relpath(f, root))
         print("%-86s %7s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
         for name, calls, tot, avg, pct in cur.execute(
