@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- Batch-OMP encode throughput on MI355X (the metric of BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--signals S] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--patches-per-gpu S] [--no-cpu-baseline]
 
 One *step* = one pass of the hot path (`lys_bomp_encode`: alpha0 = X D MFMA GEMM + wave-per-signal greedy /
 Cholesky kernel, sparse-triplet output) over one batch of S synthetic Gaussian 64-dim patches per GPU against a
@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--signals", type=int, default=1 << 20, help="patches per GPU per step")
+    ap.add_argument("--patches-per-gpu", dest="signals", type=int, default=1 << 20, help="patches per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8000)
     args = ap.parse_args()
@@ -59,11 +59,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and not distributed:
         raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
+    # one rank per GPU; LYS_BENCH_BACKEND=gloo lets several ranks share one GPU to smoke-test the N>1 code path
+    backend = os.environ.get("LYS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % n_dev
+    if dev_index >= n_dev:
+        raise SystemExit("LOCAL_RANK=%d but only %d device(s) visible" % (local_rank, n_dev))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from lyssandra_amd import _lib, engine
     lib = _lib.load()
@@ -86,6 +97,7 @@ def main():
         engine.bomp_encode(Xs, dd, k, out=out)
 
     def barrier():
+        torch.cuda.synchronize()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
