@@ -77,12 +77,14 @@ __device__ __forceinline__ void extract_case(const float (&p)[(KMAX - 1 - NLDS) 
 }
 
 template <int R>
-__device__ __forceinline__ bool wave_argmax(const float (&a)[R], int lane, int& kk, float& akk, int& Lown, int& rown) {
+__device__ __forceinline__ bool wave_argmax(const float (&a)[R], int lane, int& kk, float& akk, int& Lown, int& rown,
+                                            float& mabs) {
     using L = Lay<R>;
     float best = fabsf(a[0]);
 #pragma unroll
     for (int r = 1; r < R; ++r) best = fmaxf(best, fabsf(a[r]));
     const float m = wave_max_f(best);
+    mabs = m;
     const unsigned long long bal = __ballot(best == m);
     if (bal == 0ull) return false;  // NaN correlations: nothing sensible to select
     const unsigned mbits = __builtin_bit_cast(unsigned, m);
@@ -131,9 +133,17 @@ struct OmpState {
     float Lrow[KMAX];                                               // Lrow[j] lane i (<j) = L[j][i]
     float tv;                                                       // lane j = t_j
     float rinv;                                                     // lane j = 1/rho_j
+    float m0;                                                       // max |alpha0| (noise-floor reference)
     int dxv;                                                        // lane j = Dx[j]
     int nsel;
 };
+
+// Once the largest correlation has dropped below NOISE_REL * max|alpha0| the residual is fp32 rounding noise of the
+// alpha0 GEMM: the float64 reference goes on selecting atoms there with coefficients of order 1e-16 (SURVEY
+// appendix A, "exactly representable signal"); in fp32 such picks carry 1e-7-sized coefficients that an
+// ill-conditioned support amplifies into the significant ones.  The engine stops instead (dense results agree with
+// the reference to 1e-5; nnz is smaller).  Never reached on signals with a real residual.
+constexpr float NOISE_REL = 4e-6f;
 
 // Steps J..KMAX-1 as a compile-time recursion (a loop with early exits around the convergent cross-lane
 // operations is not unrolled by the compiler, which would push p[][] to scratch).
@@ -147,8 +157,13 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
     if constexpr (J < KMAX) {
         if (J >= k) return;
         int kk, Lown, rown;
-        float akk;
-        if (!wave_argmax<R>(s.a, lane, kk, akk, Lown, rown)) return;
+        float akk, mabs;
+        if (!wave_argmax<R>(s.a, lane, kk, akk, Lown, rown, mabs)) return;
+        if constexpr (J == 0) {
+            s.m0 = mabs;
+        } else {
+            if (mabs < NOISE_REL * s.m0) return;
+        }
         // re-selection => stop (sparse_coding.py:323-325)
         if (__ballot(lane < J && s.dxv == kk) != 0ull) return;
         // The vector update is only needed if another selection follows: the reference's last
@@ -266,6 +281,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void bomp_wave_kernel(const fl
     for (int j = 0; j < KMAX; ++j) s.Lrow[j] = 0.f;
     s.tv = 0.f;
     s.rinv = 0.f;
+    s.m0 = 0.f;
     s.dxv = -1;
     s.nsel = 0;
     omp_steps<R, KMAX, NLDS, 0, VAR>(s, G, k, lane, s_p + wid * (NLDS * L::C * 64));
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restri
     __shared__ float s_L[64 * 64];
     __shared__ float s_t[64], s_rinv[64], s_z[64];
     __shared__ int s_dx[64];
-    __shared__ float s_akk;
+    __shared__ float s_akk, s_m0;
     __shared__ int s_kk, s_stop;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -345,6 +361,8 @@ __global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restri
                     }
                 }
                 bool stop = !(mm == mm) || kk == 0x7fffffff;
+                if (j == 0) s_m0 = mm;
+                else if (mm < NOISE_REL * s_m0) stop = true;  // fp32 noise floor, see NOISE_REL
                 for (int i = 0; i < j && !stop; ++i) stop = (s_dx[i] == kk);
                 s_kk = kk;
                 s_stop = stop ? 1 : 0;

@@ -454,3 +454,95 @@ def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
     assert np.max(np.abs(st2.A_host() - r0["A"])) < 1e-5 * np.abs(r0["A"]).max()
     assert np.array_equal(r0["D_odl"], r1["D_odl"])
     assert _atom_err(r0["D_odl"], dd.to_host()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ more shapes
+@pytest.mark.parametrize("n,K,k,N", [(128, 96, 4, 700), (200, 150, 6, 500), (30, 40, 3, 257)])
+def test_approx_ksvd_other_feature_sizes(eng, n, K, k, N):
+    """Atom-update kernels at n = 128 (2 feature blocks), n = 200 (4 blocks, ragged) and n = 30 against the oracle,
+    driven from the oracle's own codes; 2 cycles; one atom deliberately unused."""
+    from lyssandra_amd.dict_learning.ksvd import approx_ksvd
+    from oracle import lyssa_oracle as orc
+    rs = np.random.RandomState(n + K)
+    D0 = rs.randn(n, K)
+    D0 /= np.linalg.norm(D0, axis=0, keepdims=True)
+    D0 = D0.astype(np.float32).astype(np.float64)
+    X = rs.randn(n, N).astype(np.float32).astype(np.float64)
+    Z0 = orc.bomp_encode(X, D0, k)
+    Z0[K // 2, :] = 0.0                                            # unused atom
+    Dr, Zr, ur = orc.approx_ksvd(X, D0.copy(), Z0.copy(), n_cycles=2)
+    D, Z = D0.copy(), Z0.copy()
+    _, _, u = approx_ksvd(X, D, Z, n_cycles=2, verbose=False)
+    assert list(u) == list(ur) == [K // 2, K // 2]
+    assert _atom_err(D, Dr) < 1e-5, _atom_err(D, Dr)
+    assert np.array_equal(Z != 0, Zr != 0)
+    assert np.max(np.abs(Z - Zr)) < 1e-5 * np.abs(Zr).max()
+    assert np.array_equal(D[:, K // 2], D0[:, K // 2])             # unused atom keeps its column
+
+
+def test_online_dl_non_neg_and_error_pass(eng):
+    """non_neg clipping (online_dict_learn.py:96-97) and the epoch-end error pass, against the oracle."""
+    from lyssandra_amd.dict_learning.online_dict_learn import online_dict_learn
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    from oracle import lyssa_oracle as orc
+    rs = np.random.RandomState(9)
+    n, K, k, N = 24, 40, 3, 600
+    D0 = np.abs(rs.randn(n, K))
+    D0 /= np.linalg.norm(D0, axis=0, keepdims=True)
+    D0 = D0.astype(np.float32).astype(np.float64)
+    X = np.abs(rs.randn(n, N)).astype(np.float32).astype(np.float64)
+    # kernel level with the oracle's codes
+    Zb = orc.bomp_encode(X, D0, k)
+    Do, Ao, Bo = orc.odl_batch_update(D0.copy(), np.zeros((K, K)), np.zeros((n, K)), X, Zb, 0.0, non_neg=True)
+    Xs = eng.signals_to_device(X)
+    dd = eng.DeviceDictionary.from_host(D0)
+    st = eng.OdlState(dd)
+    st.batch_update(Xs, *eng.sparsify_host(Zb, k=k), 0.0, non_neg=True)
+    Dh = dd.to_host()
+    assert Dh.min() >= 0.0 and _atom_err(Dh, Do) < 1e-5
+    # whole function, 3 epochs (error pass + patience bookkeeping run), loose: tie flips allowed
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    D, A, B = online_dict_learn(X, K, sparse_coder=se, batch_size=200, D_init=D0.copy(), beta=0.9, n_epochs=3,
+                                non_neg=True)
+    assert D.min() >= 0.0 and np.max(np.abs(np.linalg.norm(D, axis=0) - 1)) < 1e-5
+    Dr, Ar, Br = orc.online_dict_learn(X, K, encode=lambda X_, D_: orc.bomp_encode(X_, D_, k), batch_size=200,
+                                       D_init=D0.copy(), beta=0.9, n_epochs=3, non_neg=True)
+    assert _atom_err(D, Dr) < 5e-2
+
+
+def test_bomp_early_termination_and_small_k(eng):
+    """Signals that terminate early keep < k non-zeros, padded with idx = -1 / coef = 0 (sparse_coding.py:323-325,
+    335,345); k larger than the signal's rank; k = 1..3 at K = 1024."""
+    from oracle import lyssa_oracle as orc
+    rs = np.random.RandomState(21)
+    n, K = 8, 64
+    D = rs.randn(n, K)
+    D /= np.linalg.norm(D, axis=0, keepdims=True)
+    D = D.astype(np.float32)
+    X = np.zeros((n, 12), dtype=np.float32)
+    for i in range(12):
+        X[:, i] = 3.0 * D[:, 5 * i]                                # exactly one atom: residual is 0 after one step
+    X[:, 11] = 0
+    idx, coef, nnz = _encode(eng, X, D, 6)
+    Zr = orc.bomp_encode(X.astype(np.float64), D.astype(np.float64), 6)
+    for i in range(11):
+        m = nnz[i]
+        assert 1 <= m <= 6 and np.all(idx[i, m:] == -1) and np.all(coef[i, m:] == 0)
+        assert len(set(idx[i, :m].tolist())) == m
+        assert idx[i, 0] == 5 * i and abs(coef[i, 0] - 3.0) < 1e-5   # the true atom first, everything after is noise
+        assert np.all(np.abs(coef[i, 1:m]) < 1e-5)
+        assert m <= 2                                                 # engine stops at the fp32 noise floor
+        # (the float64 path keeps fitting the 1e-7-sized float32 rounding residual of X with further atoms; in this
+        #  8-dimensional, highly coherent dictionary that moves its coefficients by ~1e-5 -- noise regime, SURVEY app. A)
+        assert abs(Zr[5 * i, i] - 3.0) < 1e-3 and np.all(np.abs(np.delete(Zr[:, i], 5 * i)) < 1e-3)
+    assert nnz[11] == 1 and coef[11, 0] == 0 and idx[11, 0] == 0
+    D2 = rs.randn(64, 1024)
+    D2 /= np.linalg.norm(D2, axis=0, keepdims=True)
+    D2 = D2.astype(np.float32)
+    X2 = rs.randn(64, 200).astype(np.float32)
+    for k in (1, 2, 3, 7):
+        oi, oc, on, gap = orc.bomp_encode_sparse(X2.astype(np.float64), D2.astype(np.float64), k)
+        i2, c2, n2 = _encode(eng, X2, D2, k)
+        ok = gap >= TIE_GAP
+        assert np.array_equal(i2[ok], oi[ok]) and np.all(n2 == k)
+        assert np.max(np.abs(c2 - oc)[ok]) < 1e-5 * np.abs(oc).max()
