@@ -43,7 +43,7 @@ int lys_version(void);
 int lys_device_info(int dev, char* name_host, int name_cap, int* n_cu_host, size_t* hbm_bytes_host);
 
 /* ---- shape helpers (host, pure) --------------------------------------------------------------- */
-int lys_padded_atoms(int K);     /* next of {64,128,256,512,1024} or multiple of 1024 above      */
+int lys_padded_atoms(int K);     /* next of {64,128,256,512,1024}; above 1024: next multiple of 2048 */
 int lys_padded_features(int n);  /* next multiple of 8                                            */
 
 /* ---- dictionary ------------------------------------------------------------------------------- */

@@ -305,6 +305,184 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void bomp_wave_kernel(const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Workgroup-per-signal register kernel for K > 1024: 512 threads (8 waves) share one signal, thread t holds the
+// R = Kp/512 correlations  c*2048 + 4t + e  (dwordx4-coalesced rows) and the matching slices of the k-1
+// orthogonalised vectors in VGPRs.  Same arithmetic as bomp_wave_kernel; the argmax and the w_i = p_i[kk]
+// extraction go through LDS with two barriers per step.  K = 4096, k = 20 (config 3): 19*8 = 152 vector VGPRs,
+// one workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+template <int R, int KMAX>
+struct BlkState {
+    float a[R];
+    float p[KMAX - 1][R];
+};
+
+template <int R, int KMAX, int J, int RR>
+__device__ __forceinline__ void blk_publish(const BlkState<R, KMAX>& s, int r, float* s_w, float* s_akk) {
+    // owner thread only: element r (run-time) of every vector -> LDS.  A recursive if/else with an opaque asm on
+    // every value keeps the register indices static (the optimiser otherwise folds the chain into a dynamic
+    // index and the whole state lands in scratch).
+    if constexpr (RR < R) {
+        if (r == RR) {
+            float v = s.a[RR];
+            asm volatile("" : "+v"(v));
+            *s_akk = v;
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+                float u = s.p[i][RR];
+                asm volatile("" : "+v"(u));
+                s_w[i] = u;
+            }
+        } else {
+            blk_publish<R, KMAX, J, RR + 1>(s, r, s_w, s_akk);
+        }
+    }
+}
+
+template <int R, int KMAX, int J>
+__device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __restrict__ G, int Kp, int k, int tid,
+                                          float* s_max, int* s_idx, float* s_w, float* s_akk, float* s_L, float* s_t,
+                                          float* s_rinv, int* s_dx, int* s_nsel, float& m0) {
+    if constexpr (J < KMAX) {
+        if (J >= k) return;
+        const int lane = tid & 63, wid = tid >> 6;
+        // ---- block-wide argmax |a|, lowest index wins
+        float best = fabsf(s.a[0]);
+#pragma unroll
+        for (int r = 1; r < R; ++r) best = fmaxf(best, fabsf(s.a[r]));
+        const float mw = wave_max_f(best);
+        int cand = 0x7fffffff;
+#pragma unroll
+        for (int r = R - 1; r >= 0; --r) cand = (fabsf(s.a[r]) == mw) ? ((r >> 2) * 2048 + tid * 4 + (r & 3)) : cand;
+        const int cw = wave_min_i(cand);
+        float* smx = s_max + (J & 1) * 8;
+        int* six = s_idx + (J & 1) * 8;
+        if (lane == 0) {
+            smx[wid] = mw;
+            six[wid] = cw;
+        }
+        __syncthreads();
+        float m = smx[0];
+        int kk = six[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            const float v = smx[q];
+            const int c = six[q];
+            const bool better = (v > m) || (v == m && c < kk);
+            m = better ? v : m;
+            kk = better ? c : kk;
+        }
+        if (!(m == m) || kk == 0x7fffffff) return;  // NaN correlations
+        if constexpr (J == 0) {
+            m0 = m;
+        } else {
+            if (m < NOISE_REL * m0) return;
+        }
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+            if (s_dx[i] == kk) return;  // re-selection => stop (sparse_coding.py:323-325)
+        const bool more = (J + 1 < KMAX) && (J + 1 < k);
+        float g[R];
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < R / 4; ++c) {
+                const f32x4 t4 = *(reinterpret_cast<const f32x4*>(G + (int64_t)kk * Kp) + c * 512 + tid);
+                g[4 * c] = t4.x;
+                g[4 * c + 1] = t4.y;
+                g[4 * c + 2] = t4.z;
+                g[4 * c + 3] = t4.w;
+            }
+        }
+        // ---- owner publishes a[kk] and w_i = p_i[kk]
+        if (tid == ((kk & 2047) >> 2)) blk_publish<R, KMAX, J, 0>(s, (kk >> 11) * 4 + (kk & 3), s_w, s_akk);
+        __syncthreads();
+        float w[KMAX];
+        float vs = 1.f;
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            w[i] = s_w[i];
+            vs = fmaf(-w[i], w[i], vs);
+        }
+        if (J > 0 && vs < EPS32_F) return;
+        float inv = __builtin_amdgcn_rsqf(vs);
+        inv = inv * fmaf(-0.5f * vs, inv * inv, 1.5f);
+        const float t = (*s_akk) * inv;
+        if constexpr (J + 1 < KMAX) {
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float acc = g[r];
+#pragma unroll
+                    for (int i = 0; i < J; ++i) acc = fmaf(-w[i], s.p[i][r], acc);
+                    acc *= inv;
+                    s.p[J][r] = acc;
+                    s.a[r] = fmaf(-t, acc, s.a[r]);
+                }
+            }
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < J; ++i) s_L[J * KMAX + i] = w[i];
+            s_t[J] = t;
+            s_rinv[J] = inv;
+            s_dx[J] = kk;
+            *s_nsel = J + 1;
+        }
+        // s_dx[J] is read by every thread in the next step only after that step's first barrier
+        blk_steps<R, KMAX, J + 1>(s, G, Kp, k, tid, s_max, s_idx, s_w, s_akk, s_L, s_t, s_rinv, s_dx, s_nsel, m0);
+    }
+}
+
+template <int R, int KMAX, int W>
+__global__ __launch_bounds__(512, W) void bomp_block_kernel(const float* __restrict__ alpha0,
+                                                            const float* __restrict__ G, int64_t N, int k,
+                                                            int32_t* __restrict__ idx_out,
+                                                            float* __restrict__ coef_out,
+                                                            int32_t* __restrict__ nnz_out) {
+    constexpr int Kp = 512 * R;
+    __shared__ float s_max[16];
+    __shared__ int s_idx[16];
+    __shared__ float s_w[KMAX];
+    __shared__ float s_akk;
+    __shared__ float s_L[KMAX * KMAX];
+    __shared__ float s_t[KMAX], s_rinv[KMAX], s_z[KMAX];
+    __shared__ int s_dx[KMAX];
+    __shared__ int s_nsel;
+    const int tid = threadIdx.x;
+    const int64_t sig = blockIdx.x;
+    if (tid == 0) s_nsel = 0;
+    if (tid < KMAX) s_dx[tid] = -1;
+    BlkState<R, KMAX> s;
+#pragma unroll
+    for (int c = 0; c < R / 4; ++c) {
+        const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(alpha0 + sig * Kp) + c * 512 + tid);
+        s.a[4 * c] = t4.x;
+        s.a[4 * c + 1] = t4.y;
+        s.a[4 * c + 2] = t4.z;
+        s.a[4 * c + 3] = t4.w;
+    }
+    __syncthreads();
+    float m0 = 0.f;
+    blk_steps<R, KMAX, 0>(s, G, Kp, k, tid, s_max, s_idx, s_w, &s_akk, s_L, s_t, s_rinv, s_dx, &s_nsel, m0);
+    __syncthreads();
+    const int nsel = s_nsel;
+    if (tid == 0) {
+        // z = L^-T t (sparse_coding.py:354): k <= 20, a couple of hundred FMAs
+        for (int i = nsel - 1; i >= 0; --i) {
+            float zi = s_t[i];
+            for (int mI = i + 1; mI < nsel; ++mI) zi = fmaf(-s_L[mI * KMAX + i], s_z[mI], zi);
+            s_z[i] = zi * s_rinv[i];
+        }
+        nnz_out[sig] = nsel;
+    }
+    __syncthreads();
+    if (tid < k) {
+        idx_out[sig * k + tid] = (tid < nsel) ? s_dx[tid] : -1;
+        coef_out[sig * k + tid] = (tid < nsel) ? s_z[tid] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic kernel: any Kp (multiple of 64) and any k <= 64.  One 256-thread workgroup per signal, the
 // correlations and the p-vectors live in a per-workgroup global scratch slab (L2-resident), L in LDS.
 // Same arithmetic, used for K > 1024 (config 3: K=4096, k=20) and for k beyond the register kernels.
@@ -482,9 +660,28 @@ int bomp_debug_variant(const float* alpha0, const float* G, int64_t N, int k, in
     return LYS_OK;
 }
 
-// true when (K,k) is served by a register-resident wave kernel
+template <int R, int KMAX, int W>
+static int launch_block(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
+                        hipStream_t stream) {
+    if (N > 0x7fffffffLL) {
+        set_error("bomp: too many signals per launch (%lld)", (long long)N);
+        return LYS_ENOSUP;
+    }
+    hipLaunchKernelGGL((bomp_block_kernel<R, KMAX, W>), dim3((unsigned)N), dim3(512), 0, stream, alpha0, G, N, k, idx,
+                       coef, nnz);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+static bool bomp_has_block_kernel(int Kp, int k) {
+    if (Kp == 2048 || Kp == 4096) return k <= 20;
+    if (Kp == 8192) return k <= 10;
+    return false;
+}
+
+// true when (K,k) is served by a register-resident kernel (no global scratch needed)
 bool bomp_has_wave_kernel(int Kp, int k) {
-    if (Kp > 1024) return false;
+    if (Kp > 1024) return bomp_has_block_kernel(Kp, k);
     const int R = Kp / 64;
     if (k <= 10) return true;
     if (k <= 20) return R <= 8;
@@ -505,6 +702,13 @@ int bomp_from_alpha0(const float* alpha0, const float* G, int Kp, int k, int64_t
         return LYS_ENOSUP;
     }
     int rc = 1;
+    if (Kp > 1024 && bomp_has_block_kernel(Kp, k)) {
+        if (Kp == 2048) return (k <= 10) ? launch_block<4, 10, 4>(alpha0, G, N, k, idx, coef, nnz, stream)
+                                         : launch_block<4, 20, 3>(alpha0, G, N, k, idx, coef, nnz, stream);
+        if (Kp == 4096) return (k <= 10) ? launch_block<8, 10, 3>(alpha0, G, N, k, idx, coef, nnz, stream)
+                                         : launch_block<8, 20, 2>(alpha0, G, N, k, idx, coef, nnz, stream);
+        return launch_block<16, 10, 2>(alpha0, G, N, k, idx, coef, nnz, stream);
+    }
     if (bomp_has_wave_kernel(Kp, k)) {
         switch (Kp / 64) {
             case 1: rc = dispatch_k<1>(alpha0, G, N, k, idx, coef, nnz, stream); break;

@@ -45,7 +45,7 @@ inline int padded_atoms(int K) {
         while (p < K) p <<= 1;
         return p;
     }
-    return ((K + 255) / 256) * 256;
+    return ((K + 2047) / 2048) * 2048;  // workgroup-per-signal kernels: 512 threads x dwordx4
 }
 inline int padded_features(int n) { return ((n + 7) / 8) * 8; }
 

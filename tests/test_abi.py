@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_host_only_entry_points(lib):
     assert lib.lys_version() >= 100
     assert [lib.lys_padded_atoms(k) for k in (1, 4, 64, 65, 256, 1000, 1024, 1025, 4096)] == \
-        [64, 64, 64, 128, 256, 1024, 1024, 1280, 4096]
+        [64, 64, 64, 128, 256, 1024, 1024, 2048, 4096]
     assert [lib.lys_padded_features(n) for n in (1, 8, 10, 64, 65)] == [8, 8, 16, 64, 72]
     assert lib.lys_bomp_workspace_bytes(64, 1024, 10, 100) == 100 * 1024 * 4
     assert lib.lys_bomp_workspace_bytes(64, 1024, 10, 10 ** 9) == (1 << 30)
