@@ -34,6 +34,8 @@ int num_cus() {
 int gemm_nt(const float*, int64_t, const float*, int64_t, float*, int64_t, int64_t, int, int, hipStream_t,
             bool stream_c = false);
 int pack_dictionary(const float*, int, int, float*, hipStream_t);
+bool alpha0_fast_path(int n, int Kp);
+int alpha0_n64(const float*, int64_t, const float*, int, float*, int, int64_t, int, hipStream_t);
 bool bomp_has_wave_kernel(int Kp, int k);
 size_t bomp_generic_scratch_bytes(int Kp, int k);
 int bomp_from_alpha0(const float*, const float*, int, int, int64_t, int32_t*, float*, int32_t*, float*, hipStream_t);
@@ -68,6 +70,18 @@ static int64_t tile_signals(int Kp) {
     int64_t t = bytes / ((int64_t)Kp * 4);
     t = (t / 512) * 512;
     return t < 512 ? 512 : t;
+}
+
+// alpha0 = X D: signal-tile-stationary kernel for n <= 64, generic NT GEMM otherwise
+static int alpha0_any(const float* X, int64_t ldx, const float* D, int ldd, float* a0, int Kp, int64_t cnt, int n,
+                      hipStream_t stream) {
+    static int use_fast = -1;
+    if (use_fast < 0) {
+        const char* e = getenv("LYS_ALPHA0_FAST");
+        use_fast = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (use_fast && alpha0_fast_path(n, Kp)) return alpha0_n64(X, ldx, D, ldd, a0, Kp, cnt, n, stream);
+    return gemm_nt(X, ldx, D, ldd, a0, Kp, cnt, Kp, n, stream, true);
 }
 
 static hipEvent_t g_events[64];
@@ -189,7 +203,7 @@ int lys_alpha0(const float* X, int64_t ldx, const float* D_packed, int n, int K,
     LYS_REQUIRE(X && D_packed && alpha0 && n > 0 && K > 0 && N >= 0 && ldx >= n, "alpha0: bad arguments");
     const int Kp = padded_atoms(K), ldd = padded_features(n);
     // the dictionary is zero-padded to ldd columns, so reading the first n columns of X is all that is needed
-    return gemm_nt(X, ldx, D_packed, ldd, alpha0, Kp, N, Kp, n, STREAM(stream));
+    return alpha0_any(X, ldx, D_packed, ldd, alpha0, Kp, N, n, STREAM(stream));
 }
 
 int lys_bomp_from_alpha0(const float* alpha0, const float* G, int K, int k, int64_t N, int32_t* idx, float* coef,
@@ -229,7 +243,7 @@ int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const fl
         // single tile: both kernels on the caller's stream
         const bool prof = g_prof.on && g_prof.used + StageProfile::PER_TILE <= StageProfile::CAP;
         if (prof && (rc = prof_mark(user))) return rc;
-        if ((rc = gemm_nt(X, ldx, D_packed, ldd, alpha0, Kp, N, Kp, n, user, true))) return rc;
+        if ((rc = alpha0_any(X, ldx, D_packed, ldd, alpha0, Kp, N, n, user))) return rc;
         if (prof && ((rc = prof_mark(user)) || (rc = prof_mark(user)))) return rc;
         if ((rc = bomp_from_alpha0(alpha0, G, Kp, k, N, idx, coef, nnz, gen, user))) return rc;
         if (prof) {
@@ -261,7 +275,7 @@ int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const fl
         const bool prof = g_prof.on && g_prof.used + StageProfile::PER_TILE <= StageProfile::CAP;
         if (piped && t >= 2) LYS_CHECK_HIP(hipStreamWaitEvent(sg, pp->ev_omp[b], 0));  // buffer b is free again
         if (prof && (rc = prof_mark(sg))) return rc;
-        if ((rc = gemm_nt(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, Kp, n, sg, true))) return rc;
+        if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, sg))) return rc;
         if (prof && (rc = prof_mark(sg))) return rc;
         if (piped) {
             LYS_CHECK_HIP(hipEventRecord(pp->ev_gemm[b], sg));

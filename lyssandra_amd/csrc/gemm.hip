@@ -145,6 +145,129 @@ int gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, 
     return LYS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// alpha0 = X D for patches with n <= 64 (the metric shape): signal-tile-stationary variant.
+// A workgroup keeps its 128-signal tile of X in LDS for the whole kernel and walks the atom tiles of D
+// (L2-resident, 256 KB) with the next tile prefetched into registers during the MFMA phase.  The MFMA is issued
+// with the operands swapped (rows = atoms, columns = signals) so that a lane ends up with 4 CONSECUTIVE atoms of
+// one signal per accumulator quad: the epilogue is 16 non-temporal dwordx4 stores per lane instead of 64 dword
+// stores (the plain kernel is store-issue bound: 4 KB written per 131 kFLOP).
+// ------------------------------------------------------------------------------------------------
+constexpr int A0_LD = 68;  // 64 + 4: conflict-free ds_read_b128 (68 = 4 mod 32)
+
+__global__ __launch_bounds__(256, 2) void alpha0_n64_kernel(const float* __restrict__ X, int64_t ldx,
+                                                            const float* __restrict__ D, int ldd,
+                                                            float* __restrict__ C, int Kp, int64_t N, int n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [128][68] signals
+    float* Bs = smem + 128 * A0_LD;   // [128][68] atoms
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wsig = wid >> 1, watom = wid & 1;
+    const int64_t bm = (int64_t)blockIdx.x * 128;
+    const int lrow = tid >> 4;        // 0..15
+    const int lc4 = (tid & 15) * 4;   // 0..60
+    const bool x_vec = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    // ---- stage the signal tile once (zero padded to 64 features)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = lrow + 16 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t gr = bm + r;
+        if (gr < N) {
+            const float* p = X + gr * ldx + lc4;
+            if (x_vec && lc4 + 3 < n) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (lc4 + 0 < n) v.x = p[0];
+                if (lc4 + 1 < n) v.y = p[1];
+                if (lc4 + 2 < n) v.z = p[2];
+                if (lc4 + 3 < n) v.w = p[3];
+            }
+        }
+        *reinterpret_cast<float4*>(&As[r * A0_LD + lc4]) = v;
+    }
+    // ---- first atom tile into registers (D is packed: ldd is a multiple of 8 and columns >= n are zero)
+    float4 pre[8];
+    auto fetch = [&](int bn) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = lrow + 16 * i;
+            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lc4 < ldd) pre[i] = *reinterpret_cast<const float4*>(D + (int64_t)(bn + r) * ldd + lc4);
+        }
+    };
+    fetch(0);
+    const int h = lane >> 5, l31 = lane & 31;
+    for (int bn = 0; bn < Kp; bn += 128) {
+        __syncthreads();  // previous tile's LDS reads are done (and As is visible on the first pass)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 16 * i) * A0_LD + lc4]) = pre[i];
+        __syncthreads();
+        if (bn + 128 < Kp) fetch(bn + 128);  // prefetch behind the MFMAs
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4*>(&As[(wsig * 64 + i * 32 + l31) * A0_LD + q * 8 + h * 4]);   // signals
+                b[i] = *reinterpret_cast<const float4*>(&Bs[(watom * 64 + i * 32 + l31) * A0_LD + q * 8 + h * 4]);  // atoms
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        // ---- epilogue (rows = signals): acc[i][j][r] = C[signal = wsig*64 + i*32 + (r&3) + 8(r>>2) + 4h][atom = .. + l31]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = bn + watom * 64 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = bm + wsig * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < N) __builtin_nontemporal_store(acc[i][j][r], &C[row * Kp + col]);
+                }
+            }
+    }
+}
+
+bool alpha0_fast_path(int n, int Kp) { return n <= 64 && (Kp % 128) == 0; }
+
+int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, int Kp, int64_t N, int n,
+               hipStream_t stream) {
+    if (N <= 0) return LYS_OK;
+    const size_t lds = 2 * 128 * A0_LD * sizeof(float);
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    LYS_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    const int64_t blocks = (N + 127) / 128;
+    if (blocks > 0x7fffffffLL) {
+        set_error("alpha0: grid too large");
+        return LYS_ENOSUP;
+    }
+    hipLaunchKernelGGL(alpha0_n64_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 // ---- small helpers living with the GEMM ---------------------------------------------------------
 __global__ void pack_dictionary_kernel(const float* __restrict__ src, int n, int K, float* __restrict__ dst, int ldd,
                                        int Kp) {
