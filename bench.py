@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--patches-per-gpu", dest="signals", type=int, default=1 << 20, help="patches per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ksvd", action="store_true", help="skip the auxiliary approx-K-SVD iteration timing")
     ap.add_argument("--cpu-sample", type=int, default=8000)
     args = ap.parse_args()
 
@@ -177,6 +178,8 @@ def main():
                                "flop_per_patch": f_gemm + f_omp},
             },
         }
+        if world == 1 and not args.no_ksvd:
+            result["ksvd_iteration"] = ksvd_iteration(Xs, dd, k)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(Xs, Dt, k, args.cpu_sample)
         print(json.dumps(result), flush=True)
@@ -184,6 +187,50 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def ksvd_iteration(Xs, dd0, k, iters=3):
+    """Auxiliary, NOT part of `value`: one alternation of configs[1] (approx K-SVD on the same 2^20 patches, 1024 atoms,
+    k=10) = encode + residual + atom sweep + error, timed per stage after one untimed iteration.  The sweep is HBM-bound
+    byte work: algorithmic traffic 3*4n bytes per (atom, signal) non-zero."""
+    import torch
+    from lyssandra_amd import engine
+    n, K = dd0.n, dd0.K
+    dd = engine.DeviceDictionary(n, K, dd0.device)
+    dd.set((Xs[:K] / Xs[:K].norm(dim=1, keepdim=True)).t().contiguous())   # D0 = first K patches, normalised
+    out, R, buffers = None, None, {}
+    acc = {"encode": 0.0, "residual": 0.0, "sweep": 0.0, "error": 0.0}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, (time.perf_counter() - t0) * 1e3
+
+    nnz_tot = 0
+    err = 0.0
+    for it in range(iters + 1):
+        out, t_e = timed(lambda: engine.bomp_encode(Xs, dd, k, out=out))
+        idx, coef, nnz = out
+        (R, _), t_r = timed(lambda: engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False, out=R))
+        _, t_s = timed(lambda: engine.ksvd_cycle(R, dd, idx, coef, nnz, buffers=buffers))
+        err, t_x = timed(lambda: engine.approx_error(Xs, dd, idx, coef, nnz))
+        if it > 0:
+            acc["encode"] += t_e
+            acc["residual"] += t_r
+            acc["sweep"] += t_s
+            acc["error"] += t_x
+            nnz_tot = int(nnz.sum().item())
+    ms = {kk: v / iters for kk, v in acc.items()}
+    sweep_gbs = 3 * 4 * n * nnz_tot / (ms["sweep"] * 1e-3) / 1e9
+    return {"workload": "approx K-SVD alternation, %d patches, K=%d, k=%d (configs[1]); mean of %d iterations"
+                        % (Xs.shape[0], K, k, iters),
+            "ms": ms, "ms_total": sum(ms.values()),
+            "sweep_roofline": {"bound": "hbm", "achieved": sweep_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": sweep_gbs / PEAK_HBM_GBS,
+                               "note": "2K dependent launches per sweep: latency-bound (DESIGN.md 3.4)"},
+            "final_error": err}
 
 
 def cpu_baseline(Xs, Dt, k, sample):

@@ -116,6 +116,13 @@ int lys_ksvd_atom_apply(int atom, float* R, int64_t ldr, int n, int k,
 int lys_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k,
                    const int32_t* row_ptr, const int32_t* entry, float* coef,
                    double* sbuf, float* D_packed, float* D_next, void* stream);
+/*
+ * Same cycle with phase 2 of atom a-1 and phase 1 of atom a fused into one launch (K+1 dependent launches
+ * instead of 2K); needs the support rows `idx` to decide which team owns a signal that uses both atoms.
+ */
+int lys_ksvd_sweep_fused(float* R, int64_t ldr, int n, int K, int k,
+                         const int32_t* row_ptr, const int32_t* entry, const int32_t* idx, float* coef,
+                         double* sbuf, float* D_packed, float* D_next, void* stream);
 int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, float* D_packed, void* stream);
 
 /* ---- online dictionary learning (online_dict_learn.py:84-98) ---------------------------------- */

@@ -354,6 +354,202 @@ __global__ __launch_bounds__(256) void ksvd_apply_kernel(int atom, float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused single-GPU step: [phase 2 of atom a-1] + [phase 1 of atom a] in ONE launch, so a sweep is K+1 dependent
+// launches instead of 2K.  A signal that uses both atoms is owned by the team that meets it in omega_a (it applies
+// the pending update of atom a-1 to its registers first, then accumulates for atom a); the team that meets it in
+// omega_{a-1} skips it.  Membership is decided from the signal's own k-entry support row, no merged list needed.
+// ---------------------------------------------------------------------------------------------
+template <int FB>
+__global__ __launch_bounds__(256) void ksvd_fused_kernel(int atom, int K, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                         const int32_t* __restrict__ row_ptr,
+                                                         const int32_t* __restrict__ entry,
+                                                         const int32_t* __restrict__ idx, float* __restrict__ coef,
+                                                         double* __restrict__ sbuf, const float* __restrict__ D,
+                                                         int ldd, float* __restrict__ Dnext) {
+    __shared__ float s_acc[16][FB * 64 + 1];
+    const int prev = atom - 1;
+    const bool have_prev = prev >= 0, have_cur = atom < K;
+    const int pbeg = have_prev ? row_ptr[prev] : 0, pend = have_prev ? row_ptr[prev + 1] : 0;
+    const int cbeg = have_cur ? row_ptr[atom] : 0, cend = have_cur ? row_ptr[atom + 1] : 0;
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    // the two passes own disjoint signals, so they run side by side: the lower half of the grid does pass A
+    // (pending updates of atom a-1), the upper half pass B (accumulation for atom a) -- one latency chain, not two
+    const int half = gridDim.x / 2;
+    const bool both = have_prev && have_cur;
+    const bool do_a = have_prev && (!both || (int)blockIdx.x < half);
+    const bool do_b = have_cur && (!both || (int)blockIdx.x >= half);
+    const int blk = both ? ((int)blockIdx.x % half) : (int)blockIdx.x;
+    const int nblk = both ? half : (int)gridDim.x;
+    const int gteam = blk * 16 + team, nteams = nblk * 16;
+    const bool blk_prev = do_a && (pbeg + blk * 16 < pend), blk_cur = do_b && (cbeg + blk * 16 < cend);
+    if (!blk_prev && !blk_cur && !(blockIdx.x == 0 && have_prev)) return;  // uniform per block
+
+    // ---- d_new of the previous atom (fp64, every team redundantly; block 0 / team 0 publishes it)
+    float4 dold[FB], dnew[FB];
+    float dd = 0.f;
+    if (have_prev) {
+        const double* s = sbuf + (int64_t)prev * (n + 1);
+        const double sumsq = s[n];
+        double v[FB][4];
+        double nrm2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            dold[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < n) dold[b] = *reinterpret_cast<const float4*>(D + (int64_t)prev * ldd + f);
+            const float od[4] = {dold[b].x, dold[b].y, dold[b].z, dold[b].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[b][c] = (f + c < n) ? s[f + c] + (double)od[c] * sumsq : 0.0;
+                nrm2 += v[b][c] * v[b][c];
+            }
+        }
+        nrm2 = row16_sum_d(nrm2);
+        const double scale = 1.0 / (sqrt(nrm2) + 2.220446049250313e-16);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            dnew[b] = make_float4((float)(v[b][0] * scale), (float)(v[b][1] * scale), (float)(v[b][2] * scale),
+                                  (float)(v[b][3] * scale));
+            dd = fmaf(dold[b].x, dnew[b].x, dd);
+            dd = fmaf(dold[b].y, dnew[b].y, dd);
+            dd = fmaf(dold[b].z, dnew[b].z, dd);
+            dd = fmaf(dold[b].w, dnew[b].w, dd);
+        }
+        dd = row16_sum(dd);
+        if (blockIdx.x == 0 && team == 0) {
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                const int f = 64 * b + 4 * q;
+                if (f < n) *reinterpret_cast<float4*>(Dnext + (int64_t)prev * ldd + f) = dnew[b];
+            }
+        }
+    }
+    // apply the pending update of `prev` to the residual row held in r[] (coefficient slot ss_prev)
+    auto apply_prev = [&](float4 (&r)[FB], int ss_prev) {
+        const float xo = coef[ss_prev];
+        float dot = 0.f;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            dot = fmaf(r[b].x, dnew[b].x, dot);
+            dot = fmaf(r[b].y, dnew[b].y, dot);
+            dot = fmaf(r[b].z, dnew[b].z, dot);
+            dot = fmaf(r[b].w, dnew[b].w, dot);
+        }
+        dot = row16_sum(dot);
+        const float xn = fmaf(xo, dd, dot);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            r[b].x = fmaf(-dnew[b].x, xn, fmaf(dold[b].x, xo, r[b].x));
+            r[b].y = fmaf(-dnew[b].y, xn, fmaf(dold[b].y, xo, r[b].y));
+            r[b].z = fmaf(-dnew[b].z, xn, fmaf(dold[b].z, xo, r[b].z));
+            r[b].w = fmaf(-dnew[b].w, xn, fmaf(dold[b].w, xo, r[b].w));
+        }
+        if (q == 0) coef[ss_prev] = xn;
+    };
+    auto load_row = [&](float4 (&r)[FB], int64_t sig) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            r[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < n) r[b] = *reinterpret_cast<const float4*>(R + sig * ldr + f);
+        }
+    };
+    auto store_row = [&](const float4 (&r)[FB], int64_t sig) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (f < n) *reinterpret_cast<float4*>(R + sig * ldr + f) = r[b];
+        }
+    };
+    // slot of atom `a` (with a non-zero coefficient) in the support row of `sig`, or -1.  Lane q scans slots q, q+16, ..
+    auto find_slot = [&](int64_t sig, int a) -> int {
+        int found = -1;
+        for (int j = q; j < k; j += 16) {
+            if (idx[sig * k + j] == a && coef[sig * k + j] != 0.f) found = j;
+        }
+        // max over the 16 lanes of the team (row-local DPP)
+        found = max(found, dpp_i<0xB1>(found));
+        found = max(found, dpp_i<0x4E>(found));
+        found = max(found, dpp_i<0x124>(found));
+        found = max(found, dpp_i<0x128>(found));
+        return found;
+    };
+
+    // ---- pass A: signals of omega_prev that do NOT use `atom` (those are owned by pass B)
+    if (do_a) {
+        for (int e = pbeg + gteam; e < pend; e += nteams) {
+            const int ss = entry[e];
+            const int64_t sig = ss / k;
+            if (have_cur && find_slot(sig, atom) >= 0) continue;  // uniform per team
+            float4 r[FB];
+            load_row(r, sig);
+            apply_prev(r, ss);
+            store_row(r, sig);
+        }
+    }
+    // ---- pass B: signals of omega_atom: pending update first (if the signal also used `prev`), then accumulate
+    if (!do_b) return;
+    float4 acc[FB];
+    float sq = 0.f;
+#pragma unroll
+    for (int b = 0; b < FB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = cbeg + gteam; e < cend; e += nteams) {
+        const int ss = entry[e];
+        const int64_t sig = ss / k;
+        const float x = coef[ss];
+        float4 r[FB];
+        load_row(r, sig);
+        if (have_prev) {
+            const int sp = find_slot(sig, prev);
+            if (sp >= 0) {
+                apply_prev(r, (int)(sig * k + sp));
+                store_row(r, sig);
+            }
+        }
+        sq = fmaf(x, x, sq);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            acc[b].x = fmaf(r[b].x, x, acc[b].x);
+            acc[b].y = fmaf(r[b].y, x, acc[b].y);
+            acc[b].z = fmaf(r[b].z, x, acc[b].z);
+            acc[b].w = fmaf(r[b].w, x, acc[b].w);
+        }
+    }
+    if (!blk_cur) return;  // uniform per block: no team of this block had an entry of `atom`
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        s_acc[team][64 * b + 4 * q + 0] = acc[b].x;
+        s_acc[team][64 * b + 4 * q + 1] = acc[b].y;
+        s_acc[team][64 * b + 4 * q + 2] = acc[b].z;
+        s_acc[team][64 * b + 4 * q + 3] = acc[b].w;
+    }
+    if (q == 0) s_acc[team][FB * 64] = sq;
+    __syncthreads();
+    double* dst = sbuf + (int64_t)atom * (n + 1);
+    for (int f = threadIdx.x; f <= n; f += 256) {
+        const int src = (f == n) ? FB * 64 : f;
+        double tot = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) tot += (double)s_acc[t][src];
+        atomicAdd(dst + f, tot);
+    }
+}
+
+int ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,
+                    const int32_t* idx, float* coef, double* sbuf, const float* D, float* Dnext, hipStream_t stream) {
+    const int ldd = padded_features(n);
+    const int fb = (n <= 64) ? 1 : (n <= 128) ? 2 : (n <= 256) ? 4 : 0;
+    switch (fb) {
+        case 1: hipLaunchKernelGGL(ksvd_fused_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
+        case 2: hipLaunchKernelGGL(ksvd_fused_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
+        case 4: hipLaunchKernelGGL(ksvd_fused_kernel<4>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
+        default: set_error("ksvd: n = %d > 256 not supported", n); return LYS_ENOSUP;
+    }
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 static int fb_of(int n) { return (n <= 64) ? 1 : (n <= 128) ? 2 : (n <= 256) ? 4 : 0; }
 
 int ksvd_atom_accumulate(int atom, const float* R, int64_t ldr, int n, int k, const int32_t* row_ptr,
@@ -416,6 +612,16 @@ struct SweepGraphCache {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 static SweepGraphCache g_sweep_cache[64];
+
+int ksvd_sweep_fused(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
+                     const int32_t* idx, float* coef, double* sbuf, float* D, float* Dnext, hipStream_t stream) {
+    LYS_CHECK_HIP(hipMemsetAsync(sbuf, 0, (size_t)K * (n + 1) * sizeof(double), stream));
+    for (int a = 0; a <= K; ++a) {
+        const int rc = ksvd_fused_step(a, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, Dnext, stream);
+        if (rc) return rc;
+    }
+    return ksvd_commit(n, K, row_ptr, Dnext, D, stream);
+}
 
 static int ksvd_sweep_eager(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
                             float* coef, double* sbuf, float* D, float* Dnext, hipStream_t stream) {

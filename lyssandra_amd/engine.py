@@ -252,7 +252,7 @@ class HipKsvdOps(object):
     def __init__(self, R, dd, idx, coef, nnz, buffers=None):
         torch = _torch()
         self.lib = _lib.load()
-        self.R, self.dd, self.coef = R, dd, coef
+        self.R, self.dd, self.coef, self.idx = R, dd, coef, idx
         self.k = int(idx.shape[1])
         N = int(idx.shape[0])
         if buffers is None:
@@ -297,10 +297,17 @@ class HipKsvdOps(object):
         self.dd.invalidate()
 
     def sweep_single_gpu(self):
-        """All atoms of one cycle in one C call (no per-atom Python / collective)."""
-        _lib.check(self.lib.lys_ksvd_sweep(_ptr(self.R), self.R.stride(0), self.dd.n, self.dd.K, self.k,
-                                           _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.coef), _ptr(self.sbuf),
-                                           _ptr(self.dd.D), _ptr(self.Dnext), _stream()), "lys_ksvd_sweep")
+        """All atoms of one cycle in one C call (no per-atom Python / collective), fused K+1-launch form."""
+        import os
+        if os.environ.get("LYS_KSVD_FUSED", "1") != "0":
+            _lib.check(self.lib.lys_ksvd_sweep_fused(_ptr(self.R), self.R.stride(0), self.dd.n, self.dd.K, self.k,
+                                                     _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.idx),
+                                                     _ptr(self.coef), _ptr(self.sbuf), _ptr(self.dd.D),
+                                                     _ptr(self.Dnext), _stream()), "lys_ksvd_sweep_fused")
+        else:
+            _lib.check(self.lib.lys_ksvd_sweep(_ptr(self.R), self.R.stride(0), self.dd.n, self.dd.K, self.k,
+                                               _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.coef), _ptr(self.sbuf),
+                                               _ptr(self.dd.D), _ptr(self.Dnext), _stream()), "lys_ksvd_sweep")
         self.dd.invalidate()
         counts = self.local_counts()
         return _torch().nonzero(counts == 0).flatten().cpu().numpy().tolist()
