@@ -261,18 +261,20 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
     }
 }
 
-template <int R, int KMAX, int WAVES_PER_SIMD, int NLDS = 0, int VAR = 0>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void bomp_wave_kernel(const float* __restrict__ alpha0,
-                                                                        const float* __restrict__ G, int64_t N, int k,
-                                                                        int32_t* __restrict__ idx_out,
-                                                                        float* __restrict__ coef_out,
-                                                                        int32_t* __restrict__ nnz_out) {
+// BW = waves per workgroup.  (A persistent variant that prefetches the next signal's alpha0 row into 16 more VGPRs
+// was tried and rejected: the loop-carried registers push the 3-waves/SIMD build into scratch, 4.5x slower.)
+template <int R, int KMAX, int WAVES_PER_SIMD, int NLDS = 0, int VAR = 0, int BW = 4>
+__global__ __launch_bounds__(64 * BW, WAVES_PER_SIMD) void bomp_wave_kernel(const float* __restrict__ alpha0,
+                                                                           const float* __restrict__ G, int64_t N,
+                                                                           int k, int32_t* __restrict__ idx_out,
+                                                                           float* __restrict__ coef_out,
+                                                                           int32_t* __restrict__ nnz_out) {
     using L = Lay<R>;
     static_assert(NLDS == 0 || L::V == 4, "LDS-resident vectors need the dwordx4 layout");
-    __shared__ f32x4 s_p[NLDS > 0 ? 4 * NLDS * L::C * 64 : 1];
+    __shared__ f32x4 s_p[NLDS > 0 ? BW * NLDS * L::C * 64 : 1];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
-    const int64_t sig = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t sig = (int64_t)blockIdx.x * BW + wid;
     if (sig >= N) return;
 
     OmpState<R, KMAX, NLDS> s;
@@ -654,6 +656,8 @@ int bomp_debug_variant(const float* alpha0, const float* G, int64_t N, int k, in
         case 10: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 6>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
         case 11: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 7>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
         case 12: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 8>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 13: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 1>), dim3((unsigned)N), dim3(64), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 14: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 2>), dim3((unsigned)((N + 1) / 2)), dim3(128), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
         default: set_error("unknown variant %d", variant); return LYS_EINVAL;
     }
     LYS_LAUNCH_CHECK();
