@@ -66,6 +66,24 @@ int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const fl
                     int n, int K, int k, int64_t N,
                     int32_t* idx, float* coef, int32_t* nnz,
                     void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * Same driver with the reference's plain OMP (`_omp`, sparse_coding.py:19-57, `algorithm='omp'` with a fixed
+ * n_nonzero_coefs): identical greedy selection, but the Cholesky pivots use the TRUE Gram diagonal G[kk][kk]
+ * (the reference inverts G[Dx,Dx]) -- differs from Batch-OMP only for non-unit-norm dictionaries.
+ */
+int lys_omp_encode(const float* X, int64_t ldx, const float* D_packed, const float* G,
+                   int n, int K, int k, int64_t N,
+                   int32_t* idx, float* coef, int32_t* nnz,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * `algorithm='thresh'` (`thresholding`, sparse_coding.py:416-425): the k largest SIGNED correlations of every
+ * signal, coefficient = correlation; slots in descending order; k in [1, K]; K <= 1024.  Workspace as for
+ * lys_bomp_encode.
+ */
+int lys_thresh_encode(const float* X, int64_t ldx, const float* D_packed,
+                      int n, int K, int k, int64_t N,
+                      int32_t* idx, float* coef, int32_t* nnz,
+                      void* workspace, size_t workspace_bytes, void* stream);
 /* Only the alpha0 = X D GEMM of the above (timing / MFMA-stage measurement). alpha0 is [N][Kp]. */
 int lys_alpha0(const float* X, int64_t ldx, const float* D_packed, int n, int K, int64_t N,
                float* alpha0, void* stream);

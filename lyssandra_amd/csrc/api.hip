@@ -38,7 +38,9 @@ bool alpha0_fast_path(int n, int Kp);
 int alpha0_n64(const float*, int64_t, const float*, int, float*, int, int64_t, int, hipStream_t);
 bool bomp_has_wave_kernel(int Kp, int k);
 size_t bomp_generic_scratch_bytes(int Kp, int k);
-int bomp_from_alpha0(const float*, const float*, int, int, int64_t, int32_t*, float*, int32_t*, float*, hipStream_t);
+int bomp_from_alpha0(const float*, const float*, int, int, int64_t, int32_t*, float*, int32_t*, float*, hipStream_t,
+                     int unit_diag = 1);
+int thresh_from_alpha0(const float*, int, int, int, int64_t, int32_t*, float*, int32_t*, hipStream_t);
 int bomp_debug_variant(const float*, const float*, int64_t, int, int32_t*, float*, int32_t*, int, int, hipStream_t);
 int residual(const float*, int64_t, const float*, int, int, int, int64_t, const int32_t*, const float*, const int32_t*,
              float*, int64_t, double*, hipStream_t);
@@ -220,15 +222,18 @@ int lys_bomp_from_alpha0(const float* alpha0, const float* G, int K, int k, int6
     return bomp_from_alpha0(alpha0, G, Kp, k, N, idx, coef, nnz, nullptr, STREAM(stream));
 }
 
-int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K, int k, int64_t N,
-                    int32_t* idx, float* coef, int32_t* nnz, void* workspace, size_t workspace_bytes, void* stream) {
-    LYS_REQUIRE(X && D_packed && G && idx && coef && nnz, "bomp_encode: null pointer");
+// mode 0: Batch-OMP (unit Gram diagonal hard-coded, sparse_coding.py:302-367); 1: OMP with the true Gram diagonal
+// (`_omp`, :19-57); 2: thresholding (:416-425, G unused)
+static int encode_tiles(int mode, const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K, int k,
+                        int64_t N, int32_t* idx, float* coef, int32_t* nnz, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    LYS_REQUIRE(X && D_packed && (G || mode == 2) && idx && coef && nnz, "encode: null pointer");
     LYS_REQUIRE(n > 0 && K > 0 && N >= 0 && ldx >= n, "bomp_encode: bad shape n=%d K=%d N=%lld ldx=%lld", n, K,
                 (long long)N, (long long)ldx);
-    LYS_REQUIRE(k >= 1 && k <= 64, "n_nonzero_coefs must be in [1,64], got %d", k);
+    LYS_REQUIRE(mode == 2 || (k >= 1 && k <= 64), "n_nonzero_coefs must be in [1,64], got %d", k);
     if (N == 0) return LYS_OK;
     const int Kp = padded_atoms(K), ldd = padded_features(n);
-    const bool wave = bomp_has_wave_kernel(Kp, k);
+    const bool wave = (mode == 2) || bomp_has_wave_kernel(Kp, k);
     const size_t gen_bytes = wave ? 0 : bomp_generic_scratch_bytes(Kp, k);
     if (workspace == nullptr || workspace_bytes <= gen_bytes ||
         (workspace_bytes - gen_bytes) < (size_t)Kp * sizeof(float)) {
@@ -247,7 +252,9 @@ int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const fl
         if (prof && (rc = prof_mark(user))) return rc;
         if ((rc = alpha0_any(X, ldx, D_packed, ldd, alpha0, Kp, N, n, user))) return rc;
         if (prof && ((rc = prof_mark(user)) || (rc = prof_mark(user)))) return rc;
-        if ((rc = bomp_from_alpha0(alpha0, G, Kp, k, N, idx, coef, nnz, gen, user))) return rc;
+        if ((rc = (mode == 2) ? thresh_from_alpha0(alpha0, K, Kp, k, N, idx, coef, nnz, user)
+                              : bomp_from_alpha0(alpha0, G, Kp, k, N, idx, coef, nnz, gen, user, mode == 0)))
+            return rc;
         if (prof) {
             if ((rc = prof_mark(user))) return rc;
             g_prof.signals += N;
@@ -284,7 +291,9 @@ int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const fl
             LYS_CHECK_HIP(hipStreamWaitEvent(so, pp->ev_gemm[b], 0));
         }
         if (prof && (rc = prof_mark(so))) return rc;
-        if ((rc = bomp_from_alpha0(a0, G, Kp, k, cnt, idx + s0 * k, coef + s0 * k, nnz + s0, gen, so))) return rc;
+        if ((rc = (mode == 2) ? thresh_from_alpha0(a0, K, Kp, k, cnt, idx + s0 * k, coef + s0 * k, nnz + s0, so)
+                              : bomp_from_alpha0(a0, G, Kp, k, cnt, idx + s0 * k, coef + s0 * k, nnz + s0, gen, so, mode == 0)))
+            return rc;
         if (prof) {
             if ((rc = prof_mark(so))) return rc;
             g_prof.signals += cnt;
@@ -296,6 +305,21 @@ int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const fl
         LYS_CHECK_HIP(hipStreamWaitEvent(user, pp->ev_omp[(t - 1) & 1], 0));
     }
     return LYS_OK;
+}
+
+int lys_bomp_encode(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K, int k, int64_t N,
+                    int32_t* idx, float* coef, int32_t* nnz, void* workspace, size_t workspace_bytes, void* stream) {
+    return encode_tiles(0, X, ldx, D_packed, G, n, K, k, N, idx, coef, nnz, workspace, workspace_bytes, stream);
+}
+
+int lys_omp_encode(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K, int k, int64_t N,
+                   int32_t* idx, float* coef, int32_t* nnz, void* workspace, size_t workspace_bytes, void* stream) {
+    return encode_tiles(1, X, ldx, D_packed, G, n, K, k, N, idx, coef, nnz, workspace, workspace_bytes, stream);
+}
+
+int lys_thresh_encode(const float* X, int64_t ldx, const float* D_packed, int n, int K, int k, int64_t N, int32_t* idx,
+                      float* coef, int32_t* nnz, void* workspace, size_t workspace_bytes, void* stream) {
+    return encode_tiles(2, X, ldx, D_packed, nullptr, n, K, k, N, idx, coef, nnz, workspace, workspace_bytes, stream);
 }
 
 int lys_residual(const float* X, int64_t ldx, const float* D_packed, int n, int K, int k, int64_t N,

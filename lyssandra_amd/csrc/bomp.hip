@@ -152,7 +152,7 @@ constexpr float NOISE_REL = 4e-6f;
 //   4: Gram rows restricted to kk & 255 (1 MB, L2-resident)   5: kk & 63 (256 KB)
 template <int R, int KMAX, int NLDS, int J, int VAR = 0>
 __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const float* __restrict__ G, int k, int lane,
-                                          f32x4* __restrict__ lds /* [NLDS][R/4][64] of this wave */) {
+                                          f32x4* __restrict__ lds /* [NLDS][R/4][64] of this wave */, int unit_diag) {
     using L = Lay<R>;
     if constexpr (J < KMAX) {
         if (J >= k) return;
@@ -188,10 +188,13 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
             }
         }
         if constexpr (J > NLDS) extract_case<R, KMAX, NLDS, J, 0>(s.p, rown, Lown, w);
-        float vs = 1.f;
+        // Cholesky pivot: batch_omp hard-codes a unit Gram diagonal (:333-349); 'omp' (`_omp`, :44-52) inverts the
+        // true G[Dx,Dx], i.e. uses G[kk][kk] (wave-uniform scalar load, only taken on the 'omp' path)
+        const float gkk = unit_diag ? 1.f : G[(int64_t)kk * L::Kp + kk];
+        float vs = gkk;
 #pragma unroll
         for (int i = 0; i < J; ++i) vs = fmaf(-w[i], w[i], vs);
-        if (J > 0 && vs < EPS32_F) return;  // reference: vs < eps (:335,345); the fp32 engine uses fp32 eps
+        if ((J > 0 || !unit_diag) && vs < EPS32_F * gkk) return;  // reference: vs < eps (:335,345) / singular G (:48-51)
         // 1/sqrt(vs): hardware rsq (1 ulp) + one Newton step instead of an IEEE sqrt and an IEEE divide
         float inv;
         if constexpr (VAR == 3) {
@@ -257,7 +260,7 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
         s.rinv = writelane_f(inv, J, s.rinv, lane);
         s.dxv = writelane_i(kk, J, s.dxv, lane);
         s.nsel = J + 1;
-        omp_steps<R, KMAX, NLDS, J + 1, VAR>(s, G, k, lane, lds);
+        omp_steps<R, KMAX, NLDS, J + 1, VAR>(s, G, k, lane, lds, unit_diag);
     }
 }
 
@@ -268,7 +271,8 @@ __global__ __launch_bounds__(64 * BW, WAVES_PER_SIMD) void bomp_wave_kernel(cons
                                                                            const float* __restrict__ G, int64_t N,
                                                                            int k, int32_t* __restrict__ idx_out,
                                                                            float* __restrict__ coef_out,
-                                                                           int32_t* __restrict__ nnz_out) {
+                                                                           int32_t* __restrict__ nnz_out,
+                                                                           int unit_diag) {
     using L = Lay<R>;
     static_assert(NLDS == 0 || L::V == 4, "LDS-resident vectors need the dwordx4 layout");
     __shared__ f32x4 s_p[NLDS > 0 ? BW * NLDS * L::C * 64 : 1];
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(64 * BW, WAVES_PER_SIMD) void bomp_wave_kernel(cons
     s.m0 = 0.f;
     s.dxv = -1;
     s.nsel = 0;
-    omp_steps<R, KMAX, NLDS, 0, VAR>(s, G, k, lane, s_p + wid * (NLDS * L::C * 64));
+    omp_steps<R, KMAX, NLDS, 0, VAR>(s, G, k, lane, s_p + wid * (NLDS * L::C * 64), unit_diag);
     const int nsel = s.nsel;
 
     // z = L^-T t  (second triangular solve, sparse_coding.py:354), column-oriented over lanes
@@ -304,6 +308,85 @@ __global__ __launch_bounds__(64 * BW, WAVES_PER_SIMD) void bomp_wave_kernel(cons
         coef_out[sig * k + lane] = (lane < nsel) ? zout : 0.f;
     }
     if (lane == 0) nnz_out[sig] = nsel;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 'thresh' encoder (lyssa/sparse_coding.py:416-425): keep the k largest SIGNED correlations of
+// every signal, coefficient = the correlation itself.  One wave per signal, alpha0 row in registers, k rounds of
+// (wave max over an order-preserving integer key, owner lane masks its element).  Output slots are in descending
+// order of the correlation (the reference's `argsort()[::-1][:k]`).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ordered_key(float x) {  // monotone map float -> unsigned (no NaN handling)
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(unsigned kx) {
+    const unsigned b = (kx & 0x80000000u) ? (kx & 0x7fffffffu) : ~kx;
+    return __builtin_bit_cast(float, b);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void thresh_wave_kernel(const float* __restrict__ alpha0, int64_t N, int K, int k,
+                                                           int32_t* __restrict__ idx_out, float* __restrict__ coef_out,
+                                                           int32_t* __restrict__ nnz_out) {
+    using L = Lay<R>;
+    const int lane = threadIdx.x & 63;
+    const int64_t sig = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sig >= N) return;
+    float a[R];
+    load_row<R, true>(alpha0 + sig * L::Kp, lane, a);
+    unsigned key[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) key[r] = (L::atom(r, lane) < K) ? ordered_key(a[r]) : 0u;  // padded atoms never win
+    for (int j = 0; j < k; ++j) {
+        unsigned best = key[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) best = max(best, key[r]);
+        unsigned u = best;
+        u = max(u, dpp_u0<0xB1>(u));
+        u = max(u, dpp_u0<0x4E>(u));
+        u = max(u, dpp_u0<0x124>(u));
+        u = max(u, dpp_u0<0x128>(u));
+        u = max(u, dpp_u0<0x142>(u));
+        u = max(u, dpp_u0<0x143>(u));
+        const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)u, 63);
+        // lowest atom index among equal keys
+        int cand = 0x7fffffff;
+#pragma unroll
+        for (int r = R - 1; r >= 0; --r) cand = (key[r] == m) ? L::atom(r, lane) : cand;
+        const int kk = wave_min_i(cand);
+#pragma unroll
+        for (int r = 0; r < R; ++r) key[r] = (L::atom(r, lane) == kk) ? 0u : key[r];
+        if (lane == 0) {
+            idx_out[sig * k + j] = kk;
+            coef_out[sig * k + j] = key_to_float(m);
+        }
+    }
+    if (lane == 0) nnz_out[sig] = k;
+}
+
+int thresh_from_alpha0(const float* alpha0, int K, int Kp, int k, int64_t N, int32_t* idx, float* coef, int32_t* nnz,
+                       hipStream_t stream) {
+    if (N <= 0) return LYS_OK;
+    if (Kp > 1024) {
+        set_error("thresh: K = %d > 1024 is not implemented", K);
+        return LYS_ENOSUP;
+    }
+    if (k < 1 || k > K) {
+        set_error("thresh: n_nonzero_coefs must be in [1, K], got %d", k);
+        return LYS_EINVAL;
+    }
+    const dim3 grid((unsigned)((N + 3) / 4)), block(256);
+    switch (Kp / 64) {
+        case 1: hipLaunchKernelGGL(thresh_wave_kernel<1>, grid, block, 0, stream, alpha0, N, K, k, idx, coef, nnz); break;
+        case 2: hipLaunchKernelGGL(thresh_wave_kernel<2>, grid, block, 0, stream, alpha0, N, K, k, idx, coef, nnz); break;
+        case 4: hipLaunchKernelGGL(thresh_wave_kernel<4>, grid, block, 0, stream, alpha0, N, K, k, idx, coef, nnz); break;
+        case 8: hipLaunchKernelGGL(thresh_wave_kernel<8>, grid, block, 0, stream, alpha0, N, K, k, idx, coef, nnz); break;
+        case 16: hipLaunchKernelGGL(thresh_wave_kernel<16>, grid, block, 0, stream, alpha0, N, K, k, idx, coef, nnz); break;
+        default: set_error("thresh: unsupported padded K %d", Kp); return LYS_ENOSUP;
+    }
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -344,7 +427,7 @@ __device__ __forceinline__ void blk_publish(const BlkState<R, KMAX>& s, int r, f
 template <int R, int KMAX, int J>
 __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __restrict__ G, int Kp, int k, int tid,
                                           float* s_max, int* s_idx, float* s_w, float* s_akk, float* s_L, float* s_t,
-                                          float* s_rinv, int* s_dx, int* s_nsel, float& m0) {
+                                          float* s_rinv, int* s_dx, int* s_nsel, float& m0, int unit_diag) {
     if constexpr (J < KMAX) {
         if (J >= k) return;
         const int lane = tid & 63, wid = tid >> 6;
@@ -399,13 +482,14 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
         if (tid == ((kk & 2047) >> 2)) blk_publish<R, KMAX, J, 0>(s, (kk >> 11) * 4 + (kk & 3), s_w, s_akk);
         __syncthreads();
         float w[KMAX];
-        float vs = 1.f;
+        const float gkk = unit_diag ? 1.f : G[(int64_t)kk * Kp + kk];
+        float vs = gkk;
 #pragma unroll
         for (int i = 0; i < J; ++i) {
             w[i] = s_w[i];
             vs = fmaf(-w[i], w[i], vs);
         }
-        if (J > 0 && vs < EPS32_F) return;
+        if ((J > 0 || !unit_diag) && vs < EPS32_F * gkk) return;
         float inv = __builtin_amdgcn_rsqf(vs);
         inv = inv * fmaf(-0.5f * vs, inv * inv, 1.5f);
         const float t = (*s_akk) * inv;
@@ -431,7 +515,8 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
             *s_nsel = J + 1;
         }
         // s_dx[J] is read by every thread in the next step only after that step's first barrier
-        blk_steps<R, KMAX, J + 1>(s, G, Kp, k, tid, s_max, s_idx, s_w, s_akk, s_L, s_t, s_rinv, s_dx, s_nsel, m0);
+        blk_steps<R, KMAX, J + 1>(s, G, Kp, k, tid, s_max, s_idx, s_w, s_akk, s_L, s_t, s_rinv, s_dx, s_nsel, m0,
+                                  unit_diag);
     }
 }
 
@@ -440,7 +525,7 @@ __global__ __launch_bounds__(512, W) void bomp_block_kernel(const float* __restr
                                                             const float* __restrict__ G, int64_t N, int k,
                                                             int32_t* __restrict__ idx_out,
                                                             float* __restrict__ coef_out,
-                                                            int32_t* __restrict__ nnz_out) {
+                                                            int32_t* __restrict__ nnz_out, int unit_diag) {
     constexpr int Kp = 512 * R;
     __shared__ float s_max[16];
     __shared__ int s_idx[16];
@@ -465,7 +550,7 @@ __global__ __launch_bounds__(512, W) void bomp_block_kernel(const float* __restr
     }
     __syncthreads();
     float m0 = 0.f;
-    blk_steps<R, KMAX, 0>(s, G, Kp, k, tid, s_max, s_idx, s_w, &s_akk, s_L, s_t, s_rinv, s_dx, &s_nsel, m0);
+    blk_steps<R, KMAX, 0>(s, G, Kp, k, tid, s_max, s_idx, s_w, &s_akk, s_L, s_t, s_rinv, s_dx, &s_nsel, m0, unit_diag);
     __syncthreads();
     const int nsel = s_nsel;
     if (tid == 0) {
@@ -494,7 +579,7 @@ __global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restri
                                                             float* __restrict__ scratch,  // [grid][(k+1)*Kp]
                                                             int32_t* __restrict__ idx_out,
                                                             float* __restrict__ coef_out,
-                                                            int32_t* __restrict__ nnz_out) {
+                                                            int32_t* __restrict__ nnz_out, int unit_diag) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ float s_w[64];
@@ -555,9 +640,10 @@ __global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restri
             if (tid < j) s_w[tid] = P[(int64_t)tid * Kp + kk];
             __syncthreads();
             if (tid == 0) {
-                float vs = 1.f;
+                const float gkk = unit_diag ? 1.f : G[(int64_t)kk * Kp + kk];
+                float vs = gkk;
                 for (int i = 0; i < j; ++i) vs = fmaf(-s_w[i], s_w[i], vs);
-                if (j > 0 && vs < EPS32_F) {
+                if ((j > 0 || !unit_diag) && vs < EPS32_F * gkk) {
                     s_stop = 1;
                 } else {
                     const float rho = sqrtf(vs);
@@ -604,7 +690,7 @@ __global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 template <int R, int KMAX>
 static int launch_wave(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
-                       hipStream_t stream) {
+                       hipStream_t stream, int unit_diag) {
     constexpr int regs = (KMAX + 2) * R + KMAX + 40;
     constexpr int W = (regs > 256) ? 1 : (regs > 168) ? 2 : (regs > 128) ? 3 : (regs > 96) ? 4 : 5;
     const int64_t blocks = (N + 3) / 4;
@@ -615,10 +701,10 @@ static int launch_wave(const float* alpha0, const float* G, int64_t N, int k, in
     if constexpr (R == 16 && KMAX == 10) {
         // headline shape: 3 vectors in LDS -> <= 168 VGPRs -> 3 waves/SIMD (48 KB LDS per 4-wave workgroup)
         hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N,
-                           k, idx, coef, nnz);
+                           k, idx, coef, nnz, unit_diag);
     } else {
         hipLaunchKernelGGL((bomp_wave_kernel<R, KMAX, W>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N,
-                           k, idx, coef, nnz);
+                           k, idx, coef, nnz, unit_diag);
     }
     LYS_LAUNCH_CHECK();
     return LYS_OK;
@@ -626,14 +712,14 @@ static int launch_wave(const float* alpha0, const float* G, int64_t N, int k, in
 
 template <int R>
 static int dispatch_k(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
-                      hipStream_t stream) {
-    if (k <= 5) return launch_wave<R, 5>(alpha0, G, N, k, idx, coef, nnz, stream);
-    if (k <= 10) return launch_wave<R, 10>(alpha0, G, N, k, idx, coef, nnz, stream);
+                      hipStream_t stream, int unit_diag) {
+    if (k <= 5) return launch_wave<R, 5>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
+    if (k <= 10) return launch_wave<R, 10>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
     if constexpr (R <= 8) {
-        if (k <= 20) return launch_wave<R, 20>(alpha0, G, N, k, idx, coef, nnz, stream);
+        if (k <= 20) return launch_wave<R, 20>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
     }
     if constexpr (R <= 4) {
-        if (k <= 32) return launch_wave<R, 32>(alpha0, G, N, k, idx, coef, nnz, stream);
+        if (k <= 32) return launch_wave<R, 32>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
     }
     return 1;  // not covered by a register kernel
 }
@@ -643,21 +729,21 @@ int bomp_debug_variant(const float* alpha0, const float* G, int64_t N, int k, in
                        int variant, int lds_bytes, hipStream_t stream) {
     const dim3 grid((unsigned)((N + 3) / 4)), block(256);
     switch (variant) {
-        case 0: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 1: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 1>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 2: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 2>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 3: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 3>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 4: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 5: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 6: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 1>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 7: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 3, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 8: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 4>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 9: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 5>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 10: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 6>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 11: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 7>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 12: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 8>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 13: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 1>), dim3((unsigned)N), dim3(64), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
-        case 14: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 2>), dim3((unsigned)((N + 1) / 2)), dim3(128), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz); break;
+        case 0: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 1: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 1>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 2: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 2>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 3: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 3>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 4: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 5: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 6: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 1>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 7: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 3, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 8: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 4>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 9: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 5>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 10: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 6>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 11: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 7>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 12: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 8>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 13: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 1>), dim3((unsigned)N), dim3(64), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 14: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 2>), dim3((unsigned)((N + 1) / 2)), dim3(128), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
         default: set_error("unknown variant %d", variant); return LYS_EINVAL;
     }
     LYS_LAUNCH_CHECK();
@@ -666,13 +752,13 @@ int bomp_debug_variant(const float* alpha0, const float* G, int64_t N, int k, in
 
 template <int R, int KMAX, int W>
 static int launch_block(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
-                        hipStream_t stream) {
+                        hipStream_t stream, int unit_diag) {
     if (N > 0x7fffffffLL) {
         set_error("bomp: too many signals per launch (%lld)", (long long)N);
         return LYS_ENOSUP;
     }
     hipLaunchKernelGGL((bomp_block_kernel<R, KMAX, W>), dim3((unsigned)N), dim3(512), 0, stream, alpha0, G, N, k, idx,
-                       coef, nnz);
+                       coef, nnz, unit_diag);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -699,7 +785,7 @@ size_t bomp_generic_scratch_bytes(int Kp, int k) {
 }
 
 int bomp_from_alpha0(const float* alpha0, const float* G, int Kp, int k, int64_t N, int32_t* idx, float* coef,
-                     int32_t* nnz, float* generic_scratch, hipStream_t stream) {
+                     int32_t* nnz, float* generic_scratch, hipStream_t stream, int unit_diag) {
     if (N <= 0) return LYS_OK;
     if (k < 1 || k > 64) {
         set_error("bomp: n_nonzero_coefs must be in [1,64], got %d", k);
@@ -707,19 +793,19 @@ int bomp_from_alpha0(const float* alpha0, const float* G, int Kp, int k, int64_t
     }
     int rc = 1;
     if (Kp > 1024 && bomp_has_block_kernel(Kp, k)) {
-        if (Kp == 2048) return (k <= 10) ? launch_block<4, 10, 4>(alpha0, G, N, k, idx, coef, nnz, stream)
-                                         : launch_block<4, 20, 3>(alpha0, G, N, k, idx, coef, nnz, stream);
-        if (Kp == 4096) return (k <= 10) ? launch_block<8, 10, 3>(alpha0, G, N, k, idx, coef, nnz, stream)
-                                         : launch_block<8, 20, 2>(alpha0, G, N, k, idx, coef, nnz, stream);
-        return launch_block<16, 10, 2>(alpha0, G, N, k, idx, coef, nnz, stream);
+        if (Kp == 2048) return (k <= 10) ? launch_block<4, 10, 4>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
+                                         : launch_block<4, 20, 3>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
+        if (Kp == 4096) return (k <= 10) ? launch_block<8, 10, 3>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
+                                         : launch_block<8, 20, 2>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
+        return launch_block<16, 10, 2>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
     }
     if (bomp_has_wave_kernel(Kp, k)) {
         switch (Kp / 64) {
-            case 1: rc = dispatch_k<1>(alpha0, G, N, k, idx, coef, nnz, stream); break;
-            case 2: rc = dispatch_k<2>(alpha0, G, N, k, idx, coef, nnz, stream); break;
-            case 4: rc = dispatch_k<4>(alpha0, G, N, k, idx, coef, nnz, stream); break;
-            case 8: rc = dispatch_k<8>(alpha0, G, N, k, idx, coef, nnz, stream); break;
-            case 16: rc = dispatch_k<16>(alpha0, G, N, k, idx, coef, nnz, stream); break;
+            case 1: rc = dispatch_k<1>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag); break;
+            case 2: rc = dispatch_k<2>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag); break;
+            case 4: rc = dispatch_k<4>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag); break;
+            case 8: rc = dispatch_k<8>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag); break;
+            case 16: rc = dispatch_k<16>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag); break;
             default: rc = 1;
         }
     }
@@ -730,7 +816,7 @@ int bomp_from_alpha0(const float* alpha0, const float* G, int Kp, int k, int64_t
     }
     const int grid = (int)((N < (int64_t)num_cus() * 4) ? N : (int64_t)num_cus() * 4);
     hipLaunchKernelGGL(bomp_generic_kernel, dim3(grid), dim3(256), 0, stream, alpha0, G, Kp, N, k, generic_scratch,
-                       idx, coef, nnz);
+                       idx, coef, nnz, unit_diag);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }

@@ -132,8 +132,11 @@ def release_workspaces():
 
 
 # --------------------------------------------------------------------------------------------- Batch-OMP
-def bomp_encode(Xs, dd, k, out=None):
-    """Batch-OMP of the signal-major batch ``Xs`` [N, >=n] against ``dd``.  Returns (idx, coef, nnz)."""
+def bomp_encode(Xs, dd, k, out=None, algorithm='bomp'):
+    """Sparse codes of the signal-major batch ``Xs`` [N, >=n] against ``dd``.  Returns (idx, coef, nnz).
+
+    algorithm: 'bomp' (Batch-OMP, sparse_coding.py:302-367), 'omp' (`_omp` with the true Gram diagonal, :19-57) or
+    'thresh' (k largest signed correlations, :416-425)."""
     torch = _torch()
     lib = _lib.load()
     N = int(Xs.shape[0])
@@ -149,12 +152,18 @@ def bomp_encode(Xs, dd, k, out=None):
         idx, coef, nnz = out
     if N == 0:
         return idx, coef, nnz
-    G = dd.gram()
-    ws_bytes = lib.lys_bomp_workspace_bytes(dd.n, dd.K, k, N)
+    ws_bytes = lib.lys_bomp_workspace_bytes(dd.n, dd.K, min(k, 64), N)
     ws = _workspace(ws_bytes, dd.device, "bomp")
-    _lib.check(lib.lys_bomp_encode(_ptr(Xs), Xs.stride(0), _ptr(dd.D), _ptr(G), dd.n, dd.K, k, N,
-                                   _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(ws), ws.numel(), _stream()),
-               "lys_bomp_encode")
+    if algorithm == 'thresh':
+        _lib.check(lib.lys_thresh_encode(_ptr(Xs), Xs.stride(0), _ptr(dd.D), dd.n, dd.K, k, N,
+                                         _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(ws), ws.numel(), _stream()),
+                   "lys_thresh_encode")
+        return idx, coef, nnz
+    G = dd.gram()
+    fn = lib.lys_bomp_encode if algorithm == 'bomp' else lib.lys_omp_encode
+    _lib.check(fn(_ptr(Xs), Xs.stride(0), _ptr(dd.D), _ptr(G), dd.n, dd.K, k, N,
+                  _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(ws), ws.numel(), _stream()),
+               "lys_%s_encode" % algorithm)
     return idx, coef, nnz
 
 

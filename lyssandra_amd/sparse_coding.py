@@ -7,7 +7,8 @@ Same constructor, attributes and call contract as the reference class:
                                  # -> NEW dense float64 (n_atoms, n_samples), like the reference
 
 ``'bomp'`` runs entirely in liblyssa_hip.so (fp32 MFMA GEMMs for G = D'D and alpha0 = D'X, wave-per-signal
-greedy/Cholesky kernel).  There is NO CPU fallback: without the library or without a GPU the call raises.
+greedy/Cholesky kernel); ``'omp'`` (fixed ``n_nonzero_coefs``) and ``'thresh'`` ride on the same engine (SURVEY 8f
+rank 1).  There is NO CPU fallback: without the library or without a GPU the call raises.
 Unknown algorithms raise ``ValueError("Sparse optimizer not found.")`` exactly like sparse_coding.py:705-706;
 the reference's other algorithms are outside the accelerated path and raise NotImplementedError.
 
@@ -66,31 +67,35 @@ class sparse_encoder(object):
     def encode_sparse(self, X, D):
         """Same inputs as ``encode``; returns the device-resident triplet (idx [N,k], coef [N,k], nnz [N])."""
         self._check_algorithm()
-        k = self._k()
         Xs = engine.signals_to_device(X, self.device)
         dd = self._dictionary(D)
-        return engine.bomp_encode(Xs, dd, k)
+        return engine.bomp_encode(Xs, dd, self._k(dd.K), algorithm=self.algorithm)
 
     def encode_device(self, Xs, dd, out=None):
         """Device-resident form: ``Xs`` signal-major fp32 cuda tensor [N, n], ``dd`` an engine.DeviceDictionary;
         ``out`` = a previously returned triplet to overwrite (stable buffers for iterative learners)."""
         self._check_algorithm()
-        return engine.bomp_encode(Xs, dd, self._k(), out=out)
+        return engine.bomp_encode(Xs, dd, self._k(dd.K), out=out, algorithm=self.algorithm)
 
     # -- helpers ---------------------------------------------------------------------------------------
-    def _k(self):
+    def _k(self, n_atoms=None):
         k = self.params.get('n_nonzero_coefs')
+        if self.algorithm == 'thresh' and self.params.get('nonzero_percentage') is not None:
+            # thresholding(): nonzero_percentage overrides n_nonzero_coefs (sparse_coding.py:419-420)
+            k = int(np.floor(self.params.get('nonzero_percentage') * n_atoms))
         if k is None:
+            if self.algorithm == 'omp' and self.params.get('tol') is not None:
+                raise NotImplementedError("error-constrained 'omp' (tol without n_nonzero_coefs) is not accelerated")
             # the reference dies with a TypeError in np.zeros((None, None)) (sparse_coding.py:317)
-            raise ValueError("params['n_nonzero_coefs'] is required for algorithm='bomp'")
+            raise ValueError("params['n_nonzero_coefs'] is required for algorithm=%r" % (self.algorithm,))
         return int(k)
 
     def _check_algorithm(self):
-        if self.algorithm == 'bomp':
+        if self.algorithm in ('bomp', 'omp', 'thresh'):
             return
         if self.algorithm in _REFERENCE_ALGORITHMS:
             raise NotImplementedError(
-                "algorithm=%r is outside the MI355X-accelerated path (only 'bomp' is implemented; "
+                "algorithm=%r is outside the MI355X-accelerated path ('bomp', 'omp', 'thresh' are implemented; "
                 "there is deliberately no CPU fallback in this package)" % (self.algorithm,))
         raise ValueError("Sparse optimizer not found.")  # sparse_coding.py:705-706
 

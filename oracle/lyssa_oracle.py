@@ -182,6 +182,61 @@ def densify(idx, coef, nnz, K):
     return Z
 
 
+# --------------------------------------------------------------------------- 'omp' and 'thresh' 
+def omp_signal(x, D, Gram, alpha, n_nonzero_coefs):
+    """lyssa/sparse_coding.py:19-57 (`_omp`, fixed sparsity): residual-domain OMP.  argmax|alpha| :39, stop on
+    re-selection :40-41, z[Dx] = inv(G[Dx,Dx]) (D'x)[Dx] :44-52 (TRUE Gram diagonal, unlike batch_omp),
+    r = x - D[:,Dx] z :53, alpha = D'r :54; loop while i < k and ||r|| > 1e-10 :27-31."""
+    K = D.shape[1]
+    Dx = []
+    z = np.zeros(K)
+    r = np.copy(x)
+    i = 0
+    a0 = np.dot(D.T, x)
+    while i < n_nonzero_coefs and norm(r) > 1e-10:
+        kk = int(np.argmax(np.abs(alpha)))
+        if kk in Dx:
+            break
+        Dx.append(kk)
+        Gs = np.atleast_2d(Gram[Dx, :][:, Dx])
+        try:
+            Gi = np.linalg.inv(Gs)
+        except np.linalg.LinAlgError:
+            break
+        z[Dx] = np.dot(Gi, a0[Dx])
+        r = x - np.dot(D[:, Dx], z[Dx])
+        alpha = np.dot(D.T, r)
+        i += 1
+    return z
+
+
+def omp_encode(X, D, k):
+    """sparse_encoder 'omp' branch: lyssa/sparse_coding.py:620-627 + `omp` :60-66."""
+    Gram = fast_dot(D.T, D)
+    Alpha = fast_dot(D.T, X)
+    Z = np.zeros((D.shape[1], X.shape[1]))
+    for i in range(X.shape[1]):
+        Z[:, i] = omp_signal(X[:, i], D, Gram, Alpha[:, i], k)
+    return Z
+
+
+def thresholding(Alpha, nonzero_percentage=None, n_nonzero_coefs=None):
+    """lyssa/sparse_coding.py:416-425: keep the k largest SIGNED correlations of every column."""
+    K, N = Alpha.shape
+    Z = np.zeros((K, N))
+    if nonzero_percentage is not None:
+        n_nonzero_coefs = int(np.floor(nonzero_percentage * K))
+    for i in range(N):
+        idx = Alpha[:, i].argsort()[::-1][:n_nonzero_coefs]
+        Z[idx, i] = Alpha[idx, i]
+    return Z
+
+
+def thresh_encode(X, D, n_nonzero_coefs=None, nonzero_percentage=None):
+    """sparse_encoder 'thresh' branch: lyssa/sparse_coding.py:637-642."""
+    return thresholding(fast_dot(D.T, X), nonzero_percentage=nonzero_percentage, n_nonzero_coefs=n_nonzero_coefs)
+
+
 # --------------------------------------------------------------------------- dictionary helpers
 def approx_error(D, Z, X):
     """lyssa/dict_learning/utils.py:14-19 -- ||X - DZ||_F^2."""

@@ -233,6 +233,23 @@ def main():
     out["warm_D"], out["warm_A"], out["warm_B"] = coder.D, coder.A, coder.B
     np.savez_compressed(os.path.join(OUT, "F6.npz"), **out)
 
+    # ---------------- F7: 'omp' and 'thresh' encoders
+    rs = np.random.RandomState(107)
+    out = {}
+    D = make_dict(rs, 32, 200)
+    X7 = f32(rs.randn(32, 120))
+    Dn = f32(D * (0.5 + rs.rand(200))[None, :])          # non-unit-norm: 'omp' uses the true Gram diagonal
+    for tag, DD in (("unit", D), ("nonunit", Dn)):
+        se = sparse_encoder(algorithm='omp', params={'n_nonzero_coefs': 6}, n_jobs=1, verbose=False)
+        out["omp_%s_Z" % tag] = quiet(se.encode, X7, DD)
+    out["X"], out["D"], out["Dn"] = X7.astype(np.float32), D.astype(np.float32), Dn.astype(np.float32)
+    se = sparse_encoder(algorithm='thresh', params={'n_nonzero_coefs': 7}, n_jobs=1, verbose=False)
+    out["thresh_k7_Z"] = quiet(se.encode, X7, D)
+    se = sparse_encoder(algorithm='thresh', params={'nonzero_percentage': 0.4}, n_jobs=1, verbose=False)
+    out["thresh_p40_Z"] = quiet(se.encode, X7, D)
+    np.savez_compressed(os.path.join(OUT, "F7.npz"), **out)
+    print("F7 omp nnz", (out["omp_unit_Z"] != 0).sum(0)[:5], "thresh nnz", (out["thresh_p40_Z"] != 0).sum(0)[:3])
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)
 

@@ -549,3 +549,45 @@ def test_bomp_early_termination_and_small_k(eng):
         ok = gap >= TIE_GAP
         assert np.array_equal(i2[ok], oi[ok]) and np.all(n2 == k)
         assert np.max(np.abs(c2 - oc)[ok]) < 1e-5 * np.abs(oc).max()
+
+
+# ------------------------------------------------------------------------------------------------ 'omp' / 'thresh'
+def test_omp_and_thresh_encoders(eng):
+    """SURVEY 8f rank 1 on the same engine: `algorithm='omp'` (true Gram diagonal) and `algorithm='thresh'`."""
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    from oracle import lyssa_oracle as orc
+    g = load_golden("F7")
+    X, D, Dn = g["X"].astype(np.float64), g["D"].astype(np.float64), g["Dn"].astype(np.float64)
+    for tag, DD in (("unit", D), ("nonunit", Dn)):
+        Zr = g["omp_%s_Z" % tag]
+        Z = sparse_encoder(algorithm='omp', params={'n_nonzero_coefs': 6}, verbose=False).encode(X, DD)
+        _, _, _, gap = orc.bomp_encode_sparse(X, DD / np.linalg.norm(DD, axis=0, keepdims=True), 6)
+        same = np.array([np.array_equal(Z[:, i] != 0, Zr[:, i] != 0) for i in range(X.shape[1])])
+        assert same.mean() > 0.95                                  # tie signals may differ
+        err = np.abs(Z - Zr)[:, same].max() / np.abs(Zr).max()
+        assert err < 1e-5, (tag, err)
+    # non-unit-norm: 'bomp' (unit diagonal hard-coded) must NOT equal 'omp' -- the engine keeps both behaviours
+    Zb = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 6}, verbose=False).encode(X, Dn)
+    assert np.abs(Zb - g["omp_nonunit_Z"]).max() > 1e-3
+    for params, key in (({'n_nonzero_coefs': 7}, "thresh_k7_Z"), ({'nonzero_percentage': 0.4}, "thresh_p40_Z")):
+        Z = sparse_encoder(algorithm='thresh', params=params, verbose=False).encode(X, D)
+        Zr = g[key]
+        assert Z.shape == Zr.shape
+        assert (Z != 0).sum() == (Zr != 0).sum()
+        agree = np.mean((Z != 0) == (Zr != 0))
+        assert agree > 0.9995                                      # fp32 correlations: k-th / (k+1)-th may swap
+        both = (Z != 0) & (Zr != 0)
+        assert np.max(np.abs(Z - Zr)[both]) < 1e-5 * np.abs(Zr).max()
+    # thresh at the metric shape: descending order, k distinct atoms, values = correlations
+    import torch
+    rs = np.random.RandomState(3)
+    Dm = rs.randn(64, 1024)
+    Dm /= np.linalg.norm(Dm, axis=0, keepdims=True)
+    Xm = rs.randn(64, 500)
+    Xs = eng.signals_to_device(Xm)
+    dd = eng.DeviceDictionary.from_host(Dm)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, 20, algorithm='thresh')
+    A = (Xs @ dd.D[:1024, :64].t())
+    top = torch.topk(A, 20, dim=1)
+    assert torch.equal(idx.long(), top.indices) or (idx.long() == top.indices).float().mean() > 0.999
+    assert torch.allclose(coef, top.values, rtol=1e-5, atol=1e-5) and int(nnz.min()) == 20

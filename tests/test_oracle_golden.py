@@ -165,3 +165,17 @@ def test_omp_invariants():
         assert np.allclose(coef[i, :m], ls, atol=1e-10)
         r = X[:, i] - D[:, S] @ coef[i, :m]
         assert np.max(np.abs(D[:, S].T @ r)) < 1e-10
+
+
+def test_omp_and_thresh_match_reference():
+    """`_omp` (sparse_coding.py:19-57) and `thresholding` (:416-425) against the reference."""
+    g = load_golden("F7")
+    X, D, Dn = g["X"].astype(np.float64), g["D"].astype(np.float64), g["Dn"].astype(np.float64)
+    for tag, DD in (("unit", D), ("nonunit", Dn)):
+        Z = orc.omp_encode(X, DD, 6)
+        assert np.array_equal(Z != 0, g["omp_%s_Z" % tag] != 0)
+        assert np.max(np.abs(Z - g["omp_%s_Z" % tag])) <= 1e-11
+    assert np.array_equal(orc.thresh_encode(X, D, n_nonzero_coefs=7), g["thresh_k7_Z"])
+    assert np.array_equal(orc.thresh_encode(X, D, nonzero_percentage=0.4), g["thresh_p40_Z"])
+    # on a unit-norm dictionary plain OMP and Batch-OMP are the same algorithm
+    assert np.max(np.abs(orc.omp_encode(X, D, 6) - orc.bomp_encode(X, D, 6))) < 1e-6   # D is float32-rounded: diag = 1 +- 6e-8
