@@ -163,6 +163,15 @@ int lys_axpby(float* y, float beta, const float* x, int64_t count, void* stream)
 int lys_odl_update(float* D_packed, const float* A, const float* B, int n, int K, int non_neg,
                    float* scratch, void* stream);
 
+/*
+ * Projected-gradient dictionary step (lyssa/dict_learning/gradient_descent.py:84-98, the learner driven by the
+ * reference's own test dict_learning/tests/test_dictionary_learn.py): with dA = Z Z', dB = X Z' of the batch
+ * (lys_odl_increments) D <- norm_cols(clip(D - eta (D dA - dB) + 2 mu D (G - I))); G may be NULL when mu <= 0.
+ * scratch: Kp*Kp + 2*Kp*ldd floats.
+ */
+int lys_pgd_update(float* D_packed, const float* dA, const float* dB, const float* G, int n, int K,
+                   float eta, float mu, int non_neg, float* scratch, void* stream);
+
 /* ---- small utilities --------------------------------------------------------------------------- */
 /* Column normalisation of the packed dictionary, x/(||x||+eps) (utils/math.py:65-71). */
 int lys_norm_atoms(float* D_packed, int n, int K, void* stream);

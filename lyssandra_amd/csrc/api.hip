@@ -61,6 +61,7 @@ int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const f
 int axpby(float*, float, const float*, int64_t, hipStream_t);
 int odl_update(float*, const float*, const float*, int, int, int, float*, hipStream_t);
 int norm_atoms(float*, int, int, hipStream_t);
+int pgd_update(float*, const float*, const float*, const float*, int, int, float, float, int, float*, hipStream_t);
 int densify_f64(const int32_t*, const float*, const int32_t*, int, int, int64_t, double*, hipStream_t);
 
 // alpha0 tile: how many signals per GEMM + greedy round.  Measured on MI355X (tools/omp_ab.py): the greedy kernel
@@ -386,6 +387,12 @@ int lys_odl_update(float* D_packed, const float* A, const float* B, int n, int K
                    void* stream) {
     LYS_REQUIRE(D_packed && A && B && scratch, "odl_update: null pointer");
     return odl_update(D_packed, A, B, n, K, non_neg, scratch, STREAM(stream));
+}
+
+int lys_pgd_update(float* D_packed, const float* dA, const float* dB, const float* G, int n, int K, float eta, float mu,
+                   int non_neg, float* scratch, void* stream) {
+    LYS_REQUIRE(D_packed && dA && dB && scratch && (mu <= 0.f || G), "pgd_update: null pointer");
+    return pgd_update(D_packed, dA, dB, G, n, K, eta, mu, non_neg, scratch, STREAM(stream));
 }
 
 int lys_norm_atoms(float* D_packed, int n, int K, void* stream) {

@@ -108,6 +108,58 @@ int odl_update(float* D, const float* A, const float* B, int n, int K, int non_n
     return LYS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Projected gradient step of lyssa/dict_learning/gradient_descent.py:84-98 (the learner the reference's own
+// dictionary-learning test drives):  grad = (D Z - X) Z' = D (ZZ') - X Z';  D <- D - eta*grad + 2 mu D (D'D - I)
+// (the incoherence term is ADDED in the reference, :92 -- reproduced);  clip;  norm_cols.
+// With W = -eta*ZZ' + 2 mu (G - I) (symmetric) this is  D <- norm_cols(clip(D + D W + eta X Z')): one MFMA GEMM.
+// ---------------------------------------------------------------------------------------------
+__global__ void pgd_weight_kernel(const float* __restrict__ dA, const float* __restrict__ G, float eta, float mu,
+                                  int Kp, float* __restrict__ W) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)Kp * Kp) return;
+    float w = -eta * dA[t];
+    if (G) w = fmaf(2.f * mu, G[t] - ((t / Kp) == (t % Kp) ? 1.f : 0.f), w);
+    W[t] = w;
+}
+
+__global__ __launch_bounds__(64) void pgd_apply_kernel(float* __restrict__ D, int ldd, int n, const float* __restrict__ T,
+                                                       const float* __restrict__ dB, float eta, int non_neg) {
+    const int a = blockIdx.x, lane = threadIdx.x;
+    float ss = 0.f;
+    for (int f = lane; f < n; f += 64) {
+        const int64_t o = (int64_t)a * ldd + f;
+        float d = D[o] + T[o] + eta * dB[o];
+        if (non_neg && d < 0.f) d = 0.f;
+        D[o] = d;
+        ss = fmaf(d, d, ss);
+    }
+    const float nrm = sqrtf(wave_sum_f(ss)) + EPS64_F;
+    for (int f = lane; f < n; f += 64) {
+        const int64_t o = (int64_t)a * ldd + f;
+        D[o] = D[o] / nrm;
+    }
+}
+
+int pgd_update(float* D, const float* dA, const float* dB, const float* G, int n, int K, float eta, float mu, int non_neg,
+               float* scratch, hipStream_t stream) {
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    float* W = scratch;                                   // [Kp][Kp]
+    float* Dt = W + (size_t)Kp * Kp;                      // [ldd][Kp]
+    float* T = Dt + (size_t)Kp * ldd;                     // [Kp][ldd]
+    const int64_t tot = (int64_t)Kp * Kp;
+    hipLaunchKernelGGL(pgd_weight_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, dA,
+                       (mu > 0.f) ? G : nullptr, eta, mu, Kp, W);
+    LYS_LAUNCH_CHECK();
+    int rc = transpose(D, Kp, ldd, ldd, Dt, Kp, stream);
+    if (rc) return rc;
+    rc = gemm_nt(W, Kp, Dt, Kp, T, ldd, Kp, ldd, Kp, stream);   // T_am[a][f] = sum_j W[a][j] D_am[j][f] = (D W)_am
+    if (rc) return rc;
+    hipLaunchKernelGGL(pgd_apply_kernel, dim3(K), dim3(64), 0, stream, D, ldd, n, T, dB, eta, non_neg);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 // column normalisation of the packed dictionary (utils/math.py:65-71)
 __global__ __launch_bounds__(64) void norm_atoms_kernel(float* __restrict__ D, int ldd, int n) {
     const int a = blockIdx.x, lane = threadIdx.x;

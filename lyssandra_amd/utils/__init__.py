@@ -48,6 +48,65 @@ def gen_batches(N, batch_size=None):
     return out
 
 
+def run_parallel(func=None, data=None, args=None, batched_args=None,
+                 result_shape=None, batch_size=None, n_batches=None,
+                 mmap=False, msg=None, n_jobs=None):
+    """Call-site compatible counterpart of lyssa/utils/__init__.py:40-163 for HOST functions.
+
+    Same convention (first argument of `func` = the data batch, then the batched arguments, then the fixed
+    ones) and the same batching: ``n_jobs == 1`` => one call on everything (:78-90); otherwise `n_batches` even
+    column batches (`gen_even_batches`, the last one takes the remainder) or fixed-size batches, results scattered
+    back into ``Z[:, idx]`` / ``Z[idx]`` (:143-146).  The batches run sequentially in this process: the engine's
+    parallelism is the GPU, and forking a Pool after HIP initialisation is not safe (the reference already had to
+    work around fork + OpenBLAS, sparse_coding.py:713-716).
+    """
+    is_array = isinstance(data, np.ndarray)
+    n_samples = data.shape[1] if is_array else len(data)
+    if args is None:
+        args = ()
+    Z = None
+    result_is_array = False
+    if result_shape is not None:
+        if isinstance(result_shape, tuple):
+            if mmap:
+                from ..sparse_coding import _empty_mmap
+                Z = _empty_mmap(result_shape)
+            else:
+                Z = np.zeros(result_shape)
+            result_is_array = True
+        else:
+            Z = np.zeros(result_shape)
+    if n_jobs == 1:
+        _args = [data] + list(batched_args or []) + list(args)
+        rs = func(*_args)
+        if rs is not None:
+            Z[:] = rs
+        return Z
+    if n_batches is not None:
+        idx = gen_even_batches(n_samples, n_batches)
+    else:
+        idx = gen_batches(n_samples, batch_size=batch_size)
+        n_batches = len(idx)
+
+    def _slice(x, rng):
+        if isinstance(x, np.ndarray):
+            return x[:, rng.start:rng.stop]
+        return x[rng.start:rng.stop]
+
+    for i in range(n_batches):
+        _args = [_slice(data, idx[i])] + [_slice(b, idx[i]) for b in (batched_args or [])] + list(args)
+        rs = func(*_args)
+        if rs is not None:
+            if result_is_array:
+                if rs.shape != Z[:, idx[i].start:idx[i].stop].shape:
+                    raise ValueError("result of batch %d has shape %s, expected %s"
+                                     % (i, rs.shape, Z[:, idx[i].start:idx[i].stop].shape))
+                Z[:, idx[i].start:idx[i].stop] = rs
+            else:
+                Z[idx[i].start:idx[i].stop] = rs
+    return Z
+
+
 def shard_range(N, world_size, rank):
     """Contiguous signal range of `rank`: gen_even_batches(N, world_size)[rank] as (start, stop)."""
     size = N // world_size

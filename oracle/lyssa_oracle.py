@@ -405,3 +405,18 @@ def online_dict_learn(X, n_atoms, encode=None, batch_size=None, A=None, B=None, 
             if (e > 0) and (error_curr > 0.9 * error_prev or error_curr > error_prev):
                 patience += 1
     return D, A, B
+
+
+# --------------------------------------------------------------------------- projected gradient descent
+def pgd_batch_update(D, X_batch, Z_batch, eta, mu=None, non_neg=False):
+    """One mini-batch of lyssa/dict_learning/gradient_descent.py:84-98 (grad :85, incoherence term ADDED :92,
+    clip :94-95, norm_cols :97)."""
+    grad_approx = np.dot(np.dot(D, Z_batch) - X_batch, Z_batch.T)
+    if mu is not None and mu > 0:
+        grad_incoh = 2 * mu * np.dot(D, np.dot(D.T, D) - np.eye(D.shape[1]))
+    else:
+        grad_incoh = 0
+    D = D - (eta * grad_approx) + grad_incoh
+    if non_neg:
+        D[D < 0] = 0
+    return norm_cols(D)

@@ -100,3 +100,31 @@ def test_init_dictionary_reference_unit_test():
     np.random.seed(11)
     D2, u2 = orc.init_dictionary(Xf, 7, return_unused_data=True)
     assert np.array_equal(D1, D2) and u1 == u2
+
+
+def test_run_parallel_matches_reference_semantics():
+    """lyssa/utils/__init__.py:40-163: one call for n_jobs == 1, else even column batches scattered back --
+    identical results either way (n_jobs=1 vs n_jobs=4/8 bit-identical)."""
+    from lyssandra_amd.utils import run_parallel
+    rs = np.random.RandomState(0)
+    X = rs.randn(5, 237)
+    A = rs.randn(3, 237)
+    W = rs.randn(3, 5)
+    calls = []
+
+    def f(Xb, Ab, W_):
+        calls.append(Xb.shape[1])
+        return W_ @ Xb + Ab
+
+    Z1 = run_parallel(func=f, data=X, args=[W], batched_args=[A], result_shape=(3, 237), n_batches=100, n_jobs=1)
+    assert calls == [237]
+    del calls[:]
+    Z4 = run_parallel(func=f, data=X, args=[W], batched_args=[A], result_shape=(3, 237), n_batches=100, n_jobs=4)
+    assert calls == [2] * 99 + [39] and np.array_equal(Z1, Z4) and np.array_equal(Z1, W @ X + A)
+    del calls[:]
+    Zs = run_parallel(func=f, data=X[:, :37], args=[W], batched_args=[A[:, :37]], result_shape=(3, 37), n_batches=100,
+                      n_jobs=8)
+    assert calls == [0] * 99 + [37] and np.array_equal(Zs, Z1[:, :37])      # N < 100: 99 empty batches + one of 37
+    L = run_parallel(func=lambda xs: np.array([len(x) for x in xs], dtype=float), data=["a", "bb", "ccc", "dddd", "e"],
+                     result_shape=5, batch_size=2, n_jobs=2)
+    assert L.tolist() == [1, 2, 3, 4, 1]

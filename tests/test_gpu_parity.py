@@ -591,3 +591,50 @@ def test_omp_and_thresh_encoders(eng):
     top = torch.topk(A, 20, dim=1)
     assert torch.equal(idx.long(), top.indices) or (idx.long() == top.indices).float().mean() > 0.999
     assert torch.allclose(coef, top.values, rtol=1e-5, atol=1e-5) and int(nnz.min()) == 20
+
+
+# ------------------------------------------------------------------------------------------------ reference's own tests
+def test_reference_unit_tests_restated(eng):
+    """lyssa/tests/test_sparse_coding.py:10-19 and lyssa/dict_learning/tests/test_dictionary_learn.py:11-21 run against
+    the drop-in classes with the reference's own shapes and (unseeded there, seeded here) uniform data."""
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    from lyssandra_amd.dict_learning.gradient_descent import dictionary_learner
+    np.random.seed(0)
+    n_features, n_atoms, n_nonzero_coefs, n_datapoints = 10, 4, 4, 100
+    X = np.random.rand(n_features, n_datapoints)
+    D = np.random.rand(n_features, n_atoms)
+    se = sparse_encoder(algorithm='se', params={'n_nonzero_coefs': n_nonzero_coefs})
+    with pytest.raises(Exception):
+        se.encode(X, D)
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': n_nonzero_coefs})
+    dl = dictionary_learner(n_atoms=n_atoms, sparse_coder=se, eta=0.1, batch_size=None)
+    Z = dl(X)
+    assert Z.shape == (n_atoms, n_datapoints)
+    assert dl.D.shape == (n_features, n_atoms)
+
+
+def test_projected_gradient_step_vs_oracle(eng):
+    from lyssandra_amd.dict_learning.gradient_descent import projected_grad_desc
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    from oracle import lyssa_oracle as orc
+    rs = np.random.RandomState(4)
+    n, K, k, N = 20, 30, 3, 90
+    D0 = rs.randn(n, K)
+    D0 /= np.linalg.norm(D0, axis=0, keepdims=True)
+    D0 = D0.astype(np.float32).astype(np.float64)
+    X = rs.randn(n, N).astype(np.float32).astype(np.float64)
+
+    class fixed_codes(object):          # a non-engine coder: the dense-code path, identical codes on both sides
+        verbose = False
+
+        def __call__(self, X_, D_):
+            return orc.bomp_encode(X_, D0, k)
+
+    for mu, non_neg in ((None, False), (0.05, False), (None, True)):
+        Dr = orc.pgd_batch_update(D0.copy(), X, orc.bomp_encode(X, D0, k), 0.05, mu=mu, non_neg=non_neg)
+        D = projected_grad_desc(X, n_atoms=K, sparse_coder=fixed_codes(), batch_size=None, D_init=D0.copy(), eta=0.05,
+                                mu=mu, n_epochs=1, non_neg=non_neg)
+        assert _atom_err(D, Dr) < 1e-5, (mu, non_neg, _atom_err(D, Dr))
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    D = projected_grad_desc(X, n_atoms=K, sparse_coder=se, batch_size=40, D_init=D0.copy(), eta=0.05, n_epochs=3)
+    assert D.shape == (n, K) and np.max(np.abs(np.linalg.norm(D, axis=0) - 1)) < 1e-5
