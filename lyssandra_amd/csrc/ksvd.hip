@@ -11,10 +11,90 @@
 
 namespace lys {
 
+__device__ __forceinline__ float row16_sum(float x) {  // sum over the 16 lanes of a DPP row, in every lane
+    x += dpp_f<0xB1>(x);
+    x += dpp_f<0x4E>(x);
+    x += dpp_f<0x124>(x);
+    x += dpp_f<0x128>(x);
+    return x;
+}
+
 // ---------------------------------------------------------------------------------------------
 // R = X - D Z  and  err += ||R||^2      (ksvd.py:103, dict_learning/utils.py:14-19)
-// one wave per signal, lane f handles features f, f+64, ...
+// A 16-lane DPP row ("team") owns a signal: lane q moves features 64b + 4q .. +3 with one dwordx4 per 64 features
+// (a 64-dim patch = one 256-B row per team), the k selected atoms are gathered as 256-B rows of the L2-resident
+// dictionary.  Falls back to one feature per lane for n > 256 or unaligned rows.
 // ---------------------------------------------------------------------------------------------
+template <int FB>
+__global__ __launch_bounds__(256) void residual_team_kernel(const float* __restrict__ X, int64_t ldx,
+                                                            const float* __restrict__ D, int ldd, int n, int k,
+                                                            int64_t N, const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ coef,
+                                                            const int32_t* __restrict__ nnz, float* __restrict__ R,
+                                                            int64_t ldr, double* __restrict__ err) {
+    __shared__ double s_part[16];
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int64_t gteam = (int64_t)blockIdx.x * 16 + team, nteams = (int64_t)gridDim.x * 16;
+    double acc = 0.0;
+    for (int64_t s = gteam; s < N; s += nteams) {
+        const int m = nnz[s];
+        float4 r[FB];
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            r[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < n) {
+                if (f + 3 < n) {
+                    r[b] = *reinterpret_cast<const float4*>(X + s * ldx + f);
+                } else {  // ragged tail of an n that is not a multiple of 4
+                    const float* p = X + s * ldx + f;
+                    r[b].x = p[0];
+                    if (f + 1 < n) r[b].y = p[1];
+                    if (f + 2 < n) r[b].z = p[2];
+                }
+            }
+        }
+        for (int j = 0; j < m; ++j) {
+            const int a = idx[s * k + j];
+            const float c = coef[s * k + j];
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                const int f = 64 * b + 4 * q;
+                if (f < ldd) {  // packed dictionary: ldd is a multiple of 8, columns >= n are zero
+                    const float4 d = *reinterpret_cast<const float4*>(D + (int64_t)a * ldd + f);
+                    r[b].x = fmaf(-c, d.x, r[b].x);
+                    r[b].y = fmaf(-c, d.y, r[b].y);
+                    r[b].z = fmaf(-c, d.z, r[b].z);
+                    r[b].w = fmaf(-c, d.w, r[b].w);
+                }
+            }
+        }
+        float e2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (f < n) {
+                if (R) *reinterpret_cast<float4*>(R + s * ldr + f) = r[b];  // padded columns of R receive zeros
+                e2 = fmaf(r[b].x, r[b].x, e2);
+                e2 = fmaf(r[b].y, r[b].y, e2);
+                e2 = fmaf(r[b].z, r[b].z, e2);
+                e2 = fmaf(r[b].w, r[b].w, e2);
+            }
+        }
+        acc += (double)row16_sum(e2);
+    }
+    if (err) {
+        if (q == 0) s_part[team] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) tot += s_part[t];
+            atomicAdd(err, tot);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__ X, int64_t ldx,
                                                        const float* __restrict__ D, int ldd, int n, int k, int64_t N,
                                                        const int32_t* __restrict__ idx,
@@ -50,8 +130,23 @@ int residual(const float* X, int64_t ldx, const float* D, int n, int K, int k, i
              const float* coef, const int32_t* nnz, float* R, int64_t ldr, double* err, hipStream_t stream) {
     if (N <= 0) return LYS_OK;
     const int ldd = padded_features(n);
-    int64_t blocks = (N + 3) / 4;
+    const bool aligned = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+                         (R == nullptr || (((ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0)));
     const int64_t cap = (int64_t)num_cus() * 8;
+    if (aligned && n <= 256) {
+        int64_t blocks = (N + 15) / 16;
+        if (blocks > cap) blocks = cap;
+        const dim3 g((unsigned)blocks), b(256);
+        if (n <= 64)
+            hipLaunchKernelGGL(residual_team_kernel<1>, g, b, 0, stream, X, ldx, D, ldd, n, k, N, idx, coef, nnz, R, ldr, err);
+        else if (n <= 128)
+            hipLaunchKernelGGL(residual_team_kernel<2>, g, b, 0, stream, X, ldx, D, ldd, n, k, N, idx, coef, nnz, R, ldr, err);
+        else
+            hipLaunchKernelGGL(residual_team_kernel<4>, g, b, 0, stream, X, ldx, D, ldd, n, k, N, idx, coef, nnz, R, ldr, err);
+        LYS_LAUNCH_CHECK();
+        return LYS_OK;
+    }
+    int64_t blocks = (N + 3) / 4;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, ldx, D, ldd, n, k, N, idx,
                        coef, nnz, R, ldr, err);
@@ -201,13 +296,6 @@ int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K
 // approximate K-SVD, one atom (ksvd.py:111-123).  A "team" = one 16-lane DPP row; lane q of a team owns
 // features 64*b + 4*q .. +3 for b < FB (n <= 64*FB).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float row16_sum(float x) {  // sum over the 16 lanes of a DPP row, in every lane
-    x += dpp_f<0xB1>(x);
-    x += dpp_f<0x4E>(x);
-    x += dpp_f<0x124>(x);
-    x += dpp_f<0x128>(x);
-    return x;
-}
 __device__ __forceinline__ double row16_sum_d(double x) {
     for (int off = 1; off < 16; off <<= 1) x += __shfl_xor(x, off, 16);
     return x;
