@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * BW, WAVES_PER_SIMD) void bomp_wave_kernel(cons
     if (sig >= N) return;
 
     OmpState<R, KMAX, NLDS> s;
-    load_row<R, true>(alpha0 + sig * L::Kp, lane, s.a);
+    load_row<R, true>(alpha0 + (VAR == 9 ? (sig & 63) : sig) * L::Kp, lane, s.a);  // VAR 9: alpha0 rows L2-hot (ablation)
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) s.Lrow[j] = 0.f;
     s.tv = 0.f;
@@ -744,6 +744,7 @@ int bomp_debug_variant(const float* alpha0, const float* G, int64_t N, int k, in
         case 12: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 8>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
         case 13: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 1>), dim3((unsigned)N), dim3(64), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
         case 14: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 2>), dim3((unsigned)((N + 1) / 2)), dim3(128), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
+        case 15: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 9>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
         default: set_error("unknown variant %d", variant); return LYS_EINVAL;
     }
     LYS_LAUNCH_CHECK();
