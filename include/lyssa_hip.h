@@ -141,6 +141,13 @@ int lys_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k,
 int lys_ksvd_sweep_fused(float* R, int64_t ldr, int n, int K, int k,
                          const int32_t* row_ptr, const int32_t* entry, const int32_t* idx, float* coef,
                          double* sbuf, float* D_packed, float* D_next, void* stream);
+/*
+ * One step of the fused form, atom in [0, K]: applies the pending update of atom-1 (from sbuf[atom-1], which must be
+ * complete -- all-reduced in a multi-GPU run) and accumulates sbuf[atom].  atom = K only applies the last update.
+ */
+int lys_ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k,
+                        const int32_t* row_ptr, const int32_t* entry, const int32_t* idx, float* coef,
+                        double* sbuf, const float* D_packed, float* D_next, void* stream);
 int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, float* D_packed, void* stream);
 
 /* ---- online dictionary learning (online_dict_learn.py:84-98) ---------------------------------- */

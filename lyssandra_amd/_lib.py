@@ -39,6 +39,7 @@ SIGNATURES = {
     "lys_ksvd_atom_apply": (_I, [_I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "lys_ksvd_sweep": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "lys_ksvd_sweep_fused": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "lys_ksvd_fused_step": (_I, [_I, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lys_ksvd_commit": (_I, [_I, _I, _P, _P, _P, _P]),
     "lys_odl_increments": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lys_axpby": (_I, [_P, _F, _P, _L, _P]),

@@ -56,6 +56,8 @@ int ksvd_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, f
                hipStream_t);
 int ksvd_sweep_fused(float*, int64_t, int, int, int, const int32_t*, const int32_t*, const int32_t*, float*, double*,
                      float*, float*, hipStream_t);
+int ksvd_fused_step(int, int, float*, int64_t, int, int, const int32_t*, const int32_t*, const int32_t*, float*, double*,
+                    const float*, float*, hipStream_t);
 int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const float*, const int32_t*, const int32_t*,
                    const int32_t*, float*, float*, hipStream_t);
 int axpby(float*, float, const float*, int64_t, hipStream_t);
@@ -364,6 +366,15 @@ int lys_ksvd_sweep_fused(float* R, int64_t ldr, int n, int K, int k, const int32
     LYS_REQUIRE(R && row_ptr && entry && idx && coef && sbuf && D_packed && D_next && (ldr % 4) == 0,
                 "ksvd_sweep_fused: bad arguments");
     return ksvd_sweep_fused(R, ldr, n, K, k, row_ptr, entry, idx, coef, sbuf, D_packed, D_next, STREAM(stream));
+}
+
+int lys_ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr,
+                        const int32_t* entry, const int32_t* idx, float* coef, double* sbuf, const float* D_packed,
+                        float* D_next, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && idx && coef && sbuf && D_packed && D_next && (ldr % 4) == 0 && atom >= 0 &&
+                    atom <= K,
+                "ksvd_fused_step: bad arguments");
+    return ksvd_fused_step(atom, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D_packed, D_next, STREAM(stream));
 }
 
 int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, float* D_packed, void* stream) {

@@ -54,6 +54,32 @@ def local_shard(X, group=None):
     return X[:, s:e], (s, e)
 
 
+def shard_minibatches(X, batch_size, group=None):
+    """Columns of this rank such that LOCAL mini-batch b is this rank's shard of GLOBAL mini-batch b.
+
+    The reference walks the signals in consecutive batches (`gen_batches`, lyssa/utils/__init__.py:183-201).  To
+    keep exactly that sequence of (global) batches under data parallelism every rank takes the `shard_range` slice
+    of EACH batch; running `online_dict_learn(..., batch_size=local_batch_size, group=...)` on the result then
+    processes the same global batches as a single process would.  Requires every batch (the remainder batch
+    included) to split into equal shards.  Returns (X_local, local_batch_size).
+    """
+    from .utils import gen_batches
+    ws, rk = world(group)
+    N = X.shape[1]
+    cols = []
+    local_bs = None
+    for b in gen_batches(N, batch_size):
+        n_b = b.stop - b.start
+        if n_b % ws != 0:
+            raise ValueError("mini-batch of %d signals does not split evenly over %d ranks" % (n_b, ws))
+        s, e = shard_range(n_b, ws, rk)
+        if local_bs is None:
+            local_bs = e - s
+        cols.append(np.arange(b.start + s, b.start + e))
+    idx = np.concatenate(cols) if cols else np.zeros(0, dtype=int)
+    return X[:, idx], (local_bs if batch_size is not None else None)
+
+
 # ------------------------------------------------------------------------------------------------ approx K-SVD
 def ksvd_cycle_sharded(ops, K, group=None):
     """One dictionary-update cycle over signal shards.  `ops` provides, for the LOCAL shard:
@@ -62,16 +88,24 @@ def ksvd_cycle_sharded(ops, K, group=None):
         ops.accumulate(a)         -> enqueue phase 1 of atom a into ops.stats(a)
         ops.stats(a)              -> fp64 tensor [n+1] (view into the statistics buffer) to be all-reduced
         ops.apply(a)              -> phase 2 of atom a from the reduced statistics (also publishes d_new)
+        ops.fused_step(a)         -> optional: apply(a-1) + accumulate(a) in one launch, a in [0, K]
         ops.commit(global_counts) -> D[a] <- d_new for every atom that is used on ANY rank
 
     Returns the list of atoms unused on every rank (ksvd.py:111-115).  Atoms are visited strictly in order.
     """
     counts = ops.local_counts()
     allreduce_sum_(counts, group)
-    for a in range(K):
-        ops.accumulate(a)
-        allreduce_sum_(ops.stats(a), group)
-        ops.apply(a)
+    if hasattr(ops, "fused_step"):
+        # one launch per atom: [pending update of a-1] + [accumulation for a], then the all-reduce of stats(a)
+        for a in range(K + 1):
+            ops.fused_step(a)
+            if a < K:
+                allreduce_sum_(ops.stats(a), group)
+    else:
+        for a in range(K):
+            ops.accumulate(a)
+            allreduce_sum_(ops.stats(a), group)
+            ops.apply(a)
     ops.commit(counts)
     return [int(a) for a in (counts == 0).nonzero().flatten().tolist()]
 

@@ -297,6 +297,13 @@ class HipKsvdOps(object):
                                                 _ptr(self.sbuf), _ptr(self.dd.D), _ptr(self.Dnext), _stream()),
                    "lys_ksvd_atom_apply")
 
+    def fused_step(self, a):
+        """[pending update of atom a-1] + [accumulation for atom a] in one launch (a = K: only the last update)."""
+        _lib.check(self.lib.lys_ksvd_fused_step(a, self.dd.K, _ptr(self.R), self.R.stride(0), self.dd.n, self.k,
+                                                _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.idx), _ptr(self.coef),
+                                                _ptr(self.sbuf), _ptr(self.dd.D), _ptr(self.Dnext), _stream()),
+                   "lys_ksvd_fused_step")
+
     def commit(self, global_counts):
         torch = _torch()
         used = torch.zeros((self.dd.K + 1,), dtype=torch.int32, device=self.dd.device)

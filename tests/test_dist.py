@@ -118,6 +118,12 @@ def _worker(rank, world, port, out):
         assert np.max(np.abs(Di - Dfull)) < 1e-14 and unused_data == unused_full and 7 not in unused_data
         col = ld.fetch_global_column(Xl, span, 150)
         assert np.array_equal(col, X[:, 150])
+        # ---- mini-batch sharding: local batch b == this rank's slice of global batch b
+        Xm = np.arange(2 * 20.0).reshape(2, 20)
+        Xloc, lbs = ld.shard_minibatches(Xm, 8)                 # global batches 8, 8, 4 -> local 4, 4, 2
+        assert lbs == 4 and Xloc.shape == (2, 10)
+        exp = [c for b0, nb in ((0, 8), (8, 8), (16, 4)) for c in range(b0 + rank * nb // 2, b0 + (rank + 1) * nb // 2)]
+        assert Xloc[0].tolist() == [float(c) for c in exp]
         # ---- scalar reduction used for the error
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         ld.allreduce_sum_(t)

@@ -422,8 +422,21 @@ def _sharded_worker(rank, world, port, out):
         D_after_ksvd = dd.to_host()
         state = eng.OdlState(dd)
         state.batch_update(Xs, idx, coef, nnz, 0.0, group=dist.group.WORLD)   # also updates dd.D (online DL)
-        out[rank] = dict(D=D_after_ksvd, unused=unused, span=span, coef=coef.cpu().numpy(), A=state.A_host(),
-                         D_odl=dd.to_host())
+        res = dict(D=D_after_ksvd, unused=unused, span=span, coef=coef.cpu().numpy(), A=state.A_host(),
+                   D_odl=dd.to_host())
+        # ---- the drop-in learners end to end on shards
+        from lyssandra_amd.dict_learning.ksvd import ksvd_dict_learn
+        from lyssandra_amd.dict_learning.online_dict_learn import online_dict_learn
+        from lyssandra_amd.sparse_coding import sparse_encoder
+        se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+        np.random.seed(99)                                   # same RNG state on every rank
+        Dk, _ = ksvd_dict_learn(Xl, 48, init_dict='data', sparse_coder=se, max_iter=2, approx=True, verbose=False,
+                                return_codes=False, group=dist.group.WORLD, shard_span=span, n_total=X.shape[1])
+        Xb, lbs = ld.shard_minibatches(X, 500)
+        Do, Ao, Bo = online_dict_learn(Xb, K, sparse_coder=se, batch_size=lbs, D_init=D0.copy(), beta=0.9, n_epochs=1,
+                                       group=dist.group.WORLD)
+        res.update(Dk=Dk, Do=Do, Ao=Ao)
+        out[rank] = res
     finally:
         dist.destroy_process_group()
 
@@ -457,6 +470,19 @@ def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
     assert np.max(np.abs(st2.A_host() - r0["A"])) < 1e-5 * np.abs(r0["A"]).max()
     assert np.array_equal(r0["D_odl"], r1["D_odl"])
     assert _atom_err(r0["D_odl"], dd.to_host()) < 1e-5
+    # drop-in learners on 2 shards == the same learners on one GPU with the full data
+    from lyssandra_amd.dict_learning.ksvd import ksvd_dict_learn
+    from lyssandra_amd.dict_learning.online_dict_learn import online_dict_learn
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    np.random.seed(99)
+    Dk, _ = ksvd_dict_learn(X, 48, init_dict='data', sparse_coder=se, max_iter=2, approx=True, verbose=False,
+                            return_codes=False)
+    assert np.array_equal(r0["Dk"], r1["Dk"]) and _atom_err(r0["Dk"], Dk) < 1e-4
+    Do, Ao, Bo = online_dict_learn(X, D0.shape[1], sparse_coder=se, batch_size=500, D_init=D0.copy(), beta=0.9,
+                                   n_epochs=1)
+    assert np.array_equal(r0["Do"], r1["Do"]) and _atom_err(r0["Do"], Do) < 1e-4
+    assert np.max(np.abs(r0["Ao"] - Ao)) < 1e-4 * np.abs(Ao).max()
 
 
 # ------------------------------------------------------------------------------------------------ more shapes
