@@ -179,6 +179,31 @@ int lys_odl_update(float* D_packed, const float* A, const float* B, int n, int K
 int lys_pgd_update(float* D_packed, const float* dA, const float* dB, const float* G, int n, int K,
                    float eta, float mu, int non_neg, float* scratch, void* stream);
 
+/* ---- producers of the signal matrix ------------------------------------------ */
+/*
+ * Dense grid of overlapping patches of one image (H x W x C, row-major, dtype 0 = uint8 / 1 = float32, device
+ * memory) written signal-major into X [n_patches][ldx]: patch (i, j) starts at pixel (i*step, j*step), patches in
+ * row-major grid order, features = C-order flatten of (patch, patch, C) -- `grid_patches`,
+ * lyssa/utils/img.py:420-489.  n_patches = ((H-patch)/step+1) * ((W-patch)/step+1) (`compute_n_patches`, :258-273).
+ * Fused per-patch preprocessing (lyssa/feature_extract/preproc.py:46-80): x *= scale ('scaling' = 1/255),
+ * center ('local_centering'), normalize (x/(||x||+eps); center+normalize = 'contrast_normalization').
+ */
+int lys_grid_patches(const void* img, int dtype, int H, int W, int C, int patch_size, int step_size, float scale,
+                     int center, int normalize, float* X, int64_t ldx, void* stream);
+/* The same per-signal preprocessing in place on an existing signal-major matrix. */
+int lys_preproc_signals(float* X, int64_t ldx, int n, int64_t N, float scale, int center, int normalize,
+                        void* stream);
+
+/* ---- consumer of the codes --------------------------------------------------- */
+/*
+ * ScSPM spatial-pyramid max pooling of |z| from the sparse triplet (lyssa/feature_extract/spatial_pyramid.py:57-97,
+ * pooling.py:4-7): out[c][a] = max |coef| over the patches whose cell id (per level, already offset; < 0 = none) is
+ * c.  cell int32 [n_levels][N]; out fp32 [n_cells][K] (zeroed inside); optional per-cell x/(||x||+eps).
+ */
+int lys_pool_max_abs(const int32_t* idx, const float* coef, const int32_t* nnz, int k, int64_t N,
+                     const int32_t* cell, int n_levels, int K, int n_cells, float* out, int l2_normalize,
+                     void* stream);
+
 /* ---- small utilities --------------------------------------------------------------------------- */
 /* Column normalisation of the packed dictionary, x/(||x||+eps) (utils/math.py:65-71). */
 int lys_norm_atoms(float* D_packed, int n, int K, void* stream);

@@ -63,6 +63,10 @@ int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const f
 int axpby(float*, float, const float*, int64_t, hipStream_t);
 int odl_update(float*, const float*, const float*, int, int, int, float*, hipStream_t);
 int norm_atoms(float*, int, int, hipStream_t);
+int grid_patches(const void*, int, int, int, int, int, int, float, int, int, float*, int64_t, hipStream_t);
+int preproc_signals(float*, int64_t, int, int64_t, float, int, int, hipStream_t);
+int pool_max_abs(const int32_t*, const float*, const int32_t*, int, int64_t, const int32_t*, int, int, int, float*, int,
+                 hipStream_t);
 int pgd_update(float*, const float*, const float*, const float*, int, int, float, float, int, float*, hipStream_t);
 int densify_f64(const int32_t*, const float*, const int32_t*, int, int, int64_t, double*, hipStream_t);
 
@@ -404,6 +408,24 @@ int lys_pgd_update(float* D_packed, const float* dA, const float* dB, const floa
                    int non_neg, float* scratch, void* stream) {
     LYS_REQUIRE(D_packed && dA && dB && scratch && (mu <= 0.f || G), "pgd_update: null pointer");
     return pgd_update(D_packed, dA, dB, G, n, K, eta, mu, non_neg, scratch, STREAM(stream));
+}
+
+int lys_grid_patches(const void* img, int dtype, int H, int W, int C, int patch_size, int step_size, float scale,
+                     int center, int normalize, float* X, int64_t ldx, void* stream) {
+    LYS_REQUIRE(img && X && ldx >= (int64_t)patch_size * patch_size * C, "grid_patches: bad arguments");
+    return grid_patches(img, dtype, H, W, C, patch_size, step_size, scale, center, normalize, X, ldx, STREAM(stream));
+}
+
+int lys_preproc_signals(float* X, int64_t ldx, int n, int64_t N, float scale, int center, int normalize,
+                        void* stream) {
+    LYS_REQUIRE(X && ldx >= n && n > 0 && N >= 0, "preproc_signals: bad arguments");
+    return preproc_signals(X, ldx, n, N, scale, center, normalize, STREAM(stream));
+}
+
+int lys_pool_max_abs(const int32_t* idx, const float* coef, const int32_t* nnz, int k, int64_t N, const int32_t* cell,
+                     int n_levels, int K, int n_cells, float* out, int l2_normalize, void* stream) {
+    LYS_REQUIRE(idx && coef && nnz && cell && out && n_levels >= 1 && K > 0 && n_cells > 0, "pool_max_abs: bad arguments");
+    return pool_max_abs(idx, coef, nnz, k, N, cell, n_levels, K, n_cells, out, l2_normalize, STREAM(stream));
 }
 
 int lys_norm_atoms(float* D_packed, int n, int K, void* stream) {

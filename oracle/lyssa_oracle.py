@@ -420,3 +420,60 @@ def pgd_batch_update(D, X_batch, Z_batch, eta, mu=None, non_neg=False):
     if non_neg:
         D[D < 0] = 0
     return norm_cols(D)
+
+
+# --------------------------------------------------------------------------- patches / preprocessing
+def grid_patches(img, patch_size, step_size):
+    """lyssa/utils/img.py:420-477 (no random subset): (patch_size^2 * C, n_patches), patches in row-major grid order,
+    features = C-order flatten of (patch_size, patch_size, C)."""
+    img = np.asarray(img)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    H, W, C = img.shape
+    n_ph = (H - patch_size) // step_size + 1
+    n_pw = (W - patch_size) // step_size + 1
+    out = np.zeros((patch_size * patch_size * C, n_ph * n_pw), dtype=img.dtype)
+    for i in range(n_ph):
+        for j in range(n_pw):
+            out[:, i * n_pw + j] = img[i * step_size:i * step_size + patch_size,
+                                       j * step_size:j * step_size + patch_size, :].reshape(-1)
+    return out
+
+
+def preproc(name, X):
+    """lyssa/feature_extract/preproc.py:46-80, the per-datapoint operations."""
+    X = np.array(X, dtype=np.float64)
+    if name == 'scaling':
+        return X / 255.
+    if name == 'local_centering':
+        return X - X.mean(axis=0)[np.newaxis, :]
+    if name == 'contrast_normalization':
+        return norm_cols(X - X.mean(axis=0)[np.newaxis, :])
+    if name == 'normalization':
+        return norm_cols(X)
+    raise ValueError(name)
+
+
+# --------------------------------------------------------------------------- ScSPM pooling (SURVEY 8f rank 3)
+def spm_pool(Z, pos, patch_size, imsize, levels=(1, 2, 4), l2=False):
+    """Pooling loop of lyssa/feature_extract/spatial_pyramid.py:57-97 with sc_max_pooling (pooling.py:4-7) and the
+    optional l2_normalizer (preproc.py:8-16): dense codes Z (K, n_patches) of one image -> flattened pyramid."""
+    py, px = pos[:, 0], pos[:, 1]
+    cy = py + float(patch_size) / 2 - 0.5
+    cx = px + float(patch_size) / 2 - 0.5
+    K = Z.shape[0]
+    n_cells = int(np.sum(np.array(levels) ** 2))
+    pooled = np.zeros((n_cells, K))
+    cnt = 0
+    for lev in levels:
+        wunit = float(imsize[1]) / lev
+        hunit = float(imsize[0]) / lev
+        binidx = np.floor(cy / hunit) * lev + np.floor(cx / wunit)
+        for j in range(lev * lev):
+            pidx = np.nonzero(binidx == j)[0]
+            if len(pidx) > 0:
+                pooled[cnt, :] = np.max(np.abs(Z[:, pidx]), axis=1)
+                if l2:
+                    pooled[cnt, :] = normalize(pooled[cnt, :])
+            cnt += 1
+    return pooled.flatten()

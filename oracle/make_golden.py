@@ -250,6 +250,55 @@ def main():
     np.savez_compressed(os.path.join(OUT, "F7.npz"), **out)
     print("F7 omp nnz", (out["omp_unit_Z"] != 0).sum(0)[:5], "thresh nnz", (out["thresh_p40_Z"] != 0).sum(0)[:3])
 
+    # ---------------- F8: grid_patches + per-patch preproc
+    from lyssa.utils.img import grid_patches as ref_grid
+    from lyssa.feature_extract.preproc import preproc as ref_preproc
+    rs = np.random.RandomState(108)
+    out = {}
+    img_u8 = rs.randint(0, 256, size=(37, 52)).astype(np.uint8)
+    img_rgb = rs.rand(30, 41, 3).astype(np.float32)
+    out["img_u8"], out["img_rgb"] = img_u8, img_rgb
+    out["u8_p8_s3"] = np.array(quiet(ref_grid, img_u8, patch_size=8, step_size=3))
+    out["u8_p16_s7"] = np.array(quiet(ref_grid, img_u8, patch_size=16, step_size=7))
+    out["rgb_p8_s5"] = np.array(quiet(ref_grid, img_rgb, patch_size=8, step_size=5))
+    base = out["u8_p8_s3"].astype(np.float64)
+    for name in ("scaling", "local_centering", "contrast_normalization", "normalization"):
+        out["pre_" + name] = quiet(ref_preproc(name), base.copy())
+    np.savez_compressed(os.path.join(OUT, "F8.npz"), **out)
+    print("F8 shapes", out["u8_p8_s3"].shape, out["u8_p16_s7"].shape, out["rgb_p8_s5"].shape)
+
+    # ---------------- F9: ScSPM spatial-pyramid pooling through the reference's own encode()
+    from lyssa.feature_extract.spatial_pyramid import sc_spm_extractor
+    from lyssa.feature_extract.pooling import sc_max_pooling
+    from lyssa.feature_extract.preproc import l2_normalizer
+    rs = np.random.RandomState(109)
+    H9, W9, ps9, K9 = 45, 62, 8, 50
+    ys, xs = np.meshgrid(np.arange(0, H9 - ps9 + 1, 3), np.arange(0, W9 - ps9 + 1, 4), indexing='ij')
+    pos9 = np.stack([ys.ravel(), xs.ravel()], axis=1)
+    Z9 = np.zeros((K9, pos9.shape[0]))
+    for i in range(pos9.shape[0]):
+        sel = rs.choice(K9, 5, replace=False)
+        Z9[sel, i] = f32(rs.randn(5))
+
+    class fake_extractor(object):
+        patch_size = ps9
+
+        def extract(self, img):
+            return None, pos9
+
+    class fake_coder(object):
+        def encode(self, desc, dictionary):
+            return Z9
+
+    out = dict(pos=pos9.astype(np.int32), Z=Z9, H=H9, W=W9, patch_size=ps9)
+    img9 = np.zeros((H9, W9))
+    for tag, nrm in (("plain", None), ("l2", l2_normalizer())):
+        ex = sc_spm_extractor(feature_extractor=fake_extractor(), levels=(1, 2, 4), sparse_coder=fake_coder(),
+                              pooling_operator=sc_max_pooling(), normalizer=nrm)
+        out["feat_" + tag] = quiet(ex.encode, [img9], np.zeros((64, K9)))[:, 0]
+    np.savez_compressed(os.path.join(OUT, "F9.npz"), **out)
+    print("F9 feature length", out["feat_plain"].shape, "non-zero", int((out["feat_plain"] != 0).sum()))
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)
 

@@ -20,6 +20,7 @@ What it does:
          (legal on numpy 1.12, ValueError on numpy 2) -> take the scalars
        - ``if init_dict == 'data'`` with an ndarray argument -> isinstance guard
        - ``type(data) is np.core.memmap`` -> ``np.memmap`` (numpy 2 removed np.core alias warning)
+       - ``img[slices]`` with a LIST of slices (utils/img.py:462) -> ``img[tuple(slices)]`` (numpy >= 1.23)
      None of them changes the arithmetic of the hot path.
   4. points HOME at the temp dir (import-time side effects create ``~/lyssa_files``),
   5. imports the converted package and returns the module.
@@ -75,6 +76,9 @@ def load_reference():
             (r"'wa'", "'a'", True)])
     _patch(os.path.join(dst, "utils", "__init__.py"),
            [(r"'wa'", "'a'", False),
+            (r"np\.core\.memmap", "np.memmap", False)])
+    _patch(os.path.join(dst, "utils", "img.py"),
+           [(r"img\[slices\]", "img[tuple(slices)]", True),       # list-of-slices indexing: removed in numpy >= 1.23
             (r"np\.core\.memmap", "np.memmap", False)])
     _patch(os.path.join(dst, "sparse_coding.py"),
            [(r"^(\s+)w = g\n(\s+)v = w \* w\n",

@@ -664,3 +664,65 @@ def test_projected_gradient_step_vs_oracle(eng):
     se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
     D = projected_grad_desc(X, n_atoms=K, sparse_coder=se, batch_size=40, D_init=D0.copy(), eta=0.05, n_epochs=3)
     assert D.shape == (n, K) and np.max(np.abs(np.linalg.norm(D, axis=0) - 1)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8f ranks 2-3
+def test_grid_patches_and_preproc(eng):
+    """On-device producer of the signal matrix: bit-exact pixels, per-patch preprocessing within fp32."""
+    from lyssandra_amd.utils.img import grid_patches, grid_patches_device, extract_patches, compute_n_patches
+    from lyssandra_amd.feature_extract.preproc import preproc, preproc_device
+    from oracle import lyssa_oracle as orc
+    g = load_golden("F8")
+    for key, im, ps, st in (("u8_p8_s3", g["img_u8"], 8, 3), ("u8_p16_s7", g["img_u8"], 16, 7),
+                            ("rgb_p8_s5", g["img_rgb"], 8, 5)):
+        P = grid_patches(im, patch_size=ps, step_size=st)
+        assert P.dtype == im.dtype and np.array_equal(P, g[key])             # byte/pixel copies: bit-exact
+        Xs = grid_patches_device(im, ps, st)
+        assert tuple(Xs.shape) == (g[key].shape[1], g[key].shape[0])
+    base = g["u8_p8_s3"].astype(np.float64)
+    for name in ("scaling", "local_centering", "contrast_normalization", "normalization"):
+        ref = g["pre_" + name]
+        out = preproc(name)(base)
+        assert np.max(np.abs(out - ref)) < 1e-5 * max(1.0, np.abs(ref).max()), name
+    # fused producer == extraction followed by preproc
+    Xf = grid_patches_device(g["img_u8"], 8, 3, scale=1.0, center=True, normalize=True).cpu().numpy().T
+    assert np.max(np.abs(Xf - g["pre_contrast_normalization"])) < 1e-5
+    Xs = grid_patches_device(g["img_u8"], 8, 3)
+    preproc_device(Xs, 'scaling')
+    assert np.max(np.abs(Xs.cpu().numpy().T - g["pre_scaling"])) < 1e-6
+    with pytest.raises(NotImplementedError):
+        preproc('whitening')(base)
+    # list of images, consecutive column blocks (utils/img.py:300-376); random subset uses the global RNG
+    pats, numbers = extract_patches([g["img_u8"], g["img_u8"][:20, :30]], step_size=4, patch_size=8)
+    n1 = np.prod(compute_n_patches(37, 52, 8, 4))
+    n2 = np.prod(compute_n_patches(20, 30, 8, 4))
+    assert numbers.tolist() == [n1, n2] and pats.shape == (64, n1 + n2)
+    assert np.array_equal(pats[:, :n1], orc.grid_patches(g["img_u8"], 8, 4))
+    np.random.seed(5)
+    sub = grid_patches(g["img_u8"], patch_size=8, n_patches=20)
+    np.random.seed(5)
+    full = orc.grid_patches(g["img_u8"], 8, 1)
+    assert np.array_equal(sub, full[:, np.random.choice(np.arange(full.shape[1]), 20, replace=False)])
+    # full-size property: a 2048x2048 image, 8x8 patches step 2 -> 1M patches; every patch equals its window
+    import torch
+    big = (np.arange(2048 * 2048, dtype=np.int64) * 2654435761 % 251).astype(np.uint8).reshape(2048, 2048)
+    Xb = grid_patches_device(big, 8, 2)
+    n_ph, n_pw = compute_n_patches(2048, 2048, 8, 2)
+    assert Xb.shape[0] == n_ph * n_pw == 1021 * 1021
+    for p in (0, 12345, n_ph * n_pw - 1, 777777):
+        i, j = divmod(p, n_pw)
+        assert np.array_equal(Xb[p].cpu().numpy().reshape(8, 8), big[2 * i:2 * i + 8, 2 * j:2 * j + 8].astype(np.float32))
+
+
+def test_spatial_pyramid_pooling_from_triplets(eng):
+    from lyssandra_amd.feature_extract.pooling import spatial_pyramid_pool
+    g = load_golden("F9")
+    Z, pos = g["Z"], g["pos"]
+    idx, coef, nnz = eng.sparsify_host(Z, k=6)
+    for tag, l2 in (("plain", False), ("l2", True)):
+        f = spatial_pyramid_pool(idx, coef, nnz, Z.shape[0], pos, int(g["patch_size"]), (int(g["H"]), int(g["W"])),
+                                 levels=(1, 2, 4), normalize=l2)
+        ref = g["feat_" + tag]
+        assert f.shape == ref.shape
+        assert np.array_equal(f != 0, ref != 0)
+        assert np.max(np.abs(f - ref)) < 1e-6 * np.abs(ref).max()

@@ -179,3 +179,19 @@ def test_omp_and_thresh_match_reference():
     assert np.array_equal(orc.thresh_encode(X, D, nonzero_percentage=0.4), g["thresh_p40_Z"])
     # on a unit-norm dictionary plain OMP and Batch-OMP are the same algorithm
     assert np.max(np.abs(orc.omp_encode(X, D, 6) - orc.bomp_encode(X, D, 6))) < 1e-6   # D is float32-rounded: diag = 1 +- 6e-8
+
+
+def test_patches_preproc_pooling_match_reference():
+    """grid_patches (utils/img.py:420-477), per-patch preproc (feature_extract/preproc.py:46-80)
+    and the ScSPM pooling loop (feature_extract/spatial_pyramid.py:57-97) against the reference's outputs."""
+    g = load_golden("F8")
+    assert np.array_equal(orc.grid_patches(g["img_u8"], 8, 3), g["u8_p8_s3"])
+    assert np.array_equal(orc.grid_patches(g["img_u8"], 16, 7), g["u8_p16_s7"])
+    assert np.array_equal(orc.grid_patches(g["img_rgb"], 8, 5), g["rgb_p8_s5"])
+    base = g["u8_p8_s3"].astype(np.float64)
+    for name in ("scaling", "local_centering", "contrast_normalization", "normalization"):
+        assert np.max(np.abs(orc.preproc(name, base) - g["pre_" + name])) <= 1e-13
+    g9 = load_golden("F9")
+    for tag, l2 in (("plain", False), ("l2", True)):
+        f = orc.spm_pool(g9["Z"], g9["pos"], int(g9["patch_size"]), (int(g9["H"]), int(g9["W"])), l2=l2)
+        assert np.max(np.abs(f - g9["feat_" + tag])) <= 1e-14
