@@ -29,6 +29,11 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _ld(t):
+    """Leading dimension of a row-major 2-D tensor (a single-row tensor reports an arbitrary stride)."""
+    return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.shape[1]), 1)
+
+
 def _stream():
     return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
 
@@ -143,7 +148,9 @@ def bomp_encode(Xs, dd, k, out=None, algorithm='bomp'):
     k = int(k)
     if k < 1:
         raise ValueError("n_nonzero_coefs must be >= 1")
-    assert Xs.dtype == torch.float32 and Xs.stride(1) == 1
+    assert Xs.dtype == torch.float32
+    if N > 0 and Xs.shape[1] > 1 and Xs.stride(1) != 1:
+        Xs = Xs.contiguous()
     if out is None:
         idx = torch.empty((N, k), dtype=torch.int32, device=dd.device)
         coef = torch.empty((N, k), dtype=torch.float32, device=dd.device)
@@ -155,13 +162,13 @@ def bomp_encode(Xs, dd, k, out=None, algorithm='bomp'):
     ws_bytes = lib.lys_bomp_workspace_bytes(dd.n, dd.K, min(k, 64), N)
     ws = _workspace(ws_bytes, dd.device, "bomp")
     if algorithm == 'thresh':
-        _lib.check(lib.lys_thresh_encode(_ptr(Xs), Xs.stride(0), _ptr(dd.D), dd.n, dd.K, k, N,
+        _lib.check(lib.lys_thresh_encode(_ptr(Xs), _ld(Xs), _ptr(dd.D), dd.n, dd.K, k, N,
                                          _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(ws), ws.numel(), _stream()),
                    "lys_thresh_encode")
         return idx, coef, nnz
     G = dd.gram()
     fn = lib.lys_bomp_encode if algorithm == 'bomp' else lib.lys_omp_encode
-    _lib.check(fn(_ptr(Xs), Xs.stride(0), _ptr(dd.D), _ptr(G), dd.n, dd.K, k, N,
+    _lib.check(fn(_ptr(Xs), _ld(Xs), _ptr(dd.D), _ptr(G), dd.n, dd.K, k, N,
                   _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(ws), ws.numel(), _stream()),
                "lys_%s_encode" % algorithm)
     return idx, coef, nnz
@@ -228,7 +235,7 @@ def residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=True, out=None):
     else:
         R = None
     err = torch.zeros((1,), dtype=torch.float64, device=dd.device) if want_err else None
-    _lib.check(lib.lys_residual(_ptr(Xs), Xs.stride(0), _ptr(dd.D), dd.n, dd.K, k, N, _ptr(idx), _ptr(coef), _ptr(nnz),
+    _lib.check(lib.lys_residual(_ptr(Xs), _ld(Xs), _ptr(dd.D), dd.n, dd.K, k, N, _ptr(idx), _ptr(coef), _ptr(nnz),
                                 _ptr(R), dd.ldd, _ptr(err), _stream()), "lys_residual")
     return R, (float(err.item()) if want_err else None)
 
@@ -284,7 +291,7 @@ class HipKsvdOps(object):
         return (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
 
     def accumulate(self, a):
-        _lib.check(self.lib.lys_ksvd_atom_accumulate(a, _ptr(self.R), self.R.stride(0), self.dd.n, self.k,
+        _lib.check(self.lib.lys_ksvd_atom_accumulate(a, _ptr(self.R), _ld(self.R), self.dd.n, self.k,
                                                      _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.coef),
                                                      _ptr(self.sbuf), _stream()), "lys_ksvd_atom_accumulate")
 
@@ -292,14 +299,14 @@ class HipKsvdOps(object):
         return self.sbuf[a]
 
     def apply(self, a):
-        _lib.check(self.lib.lys_ksvd_atom_apply(a, _ptr(self.R), self.R.stride(0), self.dd.n, self.k,
+        _lib.check(self.lib.lys_ksvd_atom_apply(a, _ptr(self.R), _ld(self.R), self.dd.n, self.k,
                                                 _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.coef),
                                                 _ptr(self.sbuf), _ptr(self.dd.D), _ptr(self.Dnext), _stream()),
                    "lys_ksvd_atom_apply")
 
     def fused_step(self, a):
         """[pending update of atom a-1] + [accumulation for atom a] in one launch (a = K: only the last update)."""
-        _lib.check(self.lib.lys_ksvd_fused_step(a, self.dd.K, _ptr(self.R), self.R.stride(0), self.dd.n, self.k,
+        _lib.check(self.lib.lys_ksvd_fused_step(a, self.dd.K, _ptr(self.R), _ld(self.R), self.dd.n, self.k,
                                                 _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.idx), _ptr(self.coef),
                                                 _ptr(self.sbuf), _ptr(self.dd.D), _ptr(self.Dnext), _stream()),
                    "lys_ksvd_fused_step")
@@ -316,12 +323,12 @@ class HipKsvdOps(object):
         """All atoms of one cycle in one C call (no per-atom Python / collective), fused K+1-launch form."""
         import os
         if os.environ.get("LYS_KSVD_FUSED", "1") != "0":
-            _lib.check(self.lib.lys_ksvd_sweep_fused(_ptr(self.R), self.R.stride(0), self.dd.n, self.dd.K, self.k,
+            _lib.check(self.lib.lys_ksvd_sweep_fused(_ptr(self.R), _ld(self.R), self.dd.n, self.dd.K, self.k,
                                                      _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.idx),
                                                      _ptr(self.coef), _ptr(self.sbuf), _ptr(self.dd.D),
                                                      _ptr(self.Dnext), _stream()), "lys_ksvd_sweep_fused")
         else:
-            _lib.check(self.lib.lys_ksvd_sweep(_ptr(self.R), self.R.stride(0), self.dd.n, self.dd.K, self.k,
+            _lib.check(self.lib.lys_ksvd_sweep(_ptr(self.R), _ld(self.R), self.dd.n, self.dd.K, self.k,
                                                _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.coef), _ptr(self.sbuf),
                                                _ptr(self.dd.D), _ptr(self.Dnext), _stream()), "lys_ksvd_sweep")
         self.dd.invalidate()
@@ -376,7 +383,7 @@ class OdlState(object):
         Xs, idx, coef, nnz = self._batch
         k = int(idx.shape[1])
         row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
-        _lib.check(lib.lys_odl_increments(_ptr(Xs), Xs.stride(0), dd.n, dd.K, k, _ptr(idx), _ptr(coef), _ptr(nnz),
+        _lib.check(lib.lys_odl_increments(_ptr(Xs), _ld(Xs), dd.n, dd.K, k, _ptr(idx), _ptr(coef), _ptr(nnz),
                                           _ptr(row_ptr), _ptr(entry), _ptr(self.dA), _ptr(self.dB), _stream()),
                    "lys_odl_increments")
         return self.dA, self.dB

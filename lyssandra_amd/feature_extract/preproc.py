@@ -26,7 +26,7 @@ def preproc_device(Xs, name):
     torch = engine.require_gpu()
     lib = _lib.load()
     scale, center, norm = _FLAGS[name]
-    _lib.check(lib.lys_preproc_signals(ctypes.c_void_p(Xs.data_ptr()), Xs.stride(0), int(Xs.shape[1]), int(Xs.shape[0]),
+    _lib.check(lib.lys_preproc_signals(ctypes.c_void_p(Xs.data_ptr()), engine._ld(Xs), int(Xs.shape[1]), int(Xs.shape[0]),
                                        float(scale), int(center), int(norm),
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "lys_preproc_signals")
     return Xs

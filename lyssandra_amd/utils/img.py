@@ -40,7 +40,7 @@ def grid_patches_device(img, patch_size, step_size, scale=1.0, center=False, nor
     Xs = torch.empty((n_ph * n_pw, dim), dtype=torch.float32, device=dev)
     _lib.check(lib.lys_grid_patches(ctypes.c_void_p(t.data_ptr()), dtype, H, W, C, patch_size, step_size, float(scale),
                                     int(bool(center)), int(bool(normalize)), ctypes.c_void_p(Xs.data_ptr()),
-                                    Xs.stride(0), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                    engine._ld(Xs), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                "lys_grid_patches")
     return Xs
 

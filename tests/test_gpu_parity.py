@@ -726,3 +726,44 @@ def test_spatial_pyramid_pooling_from_triplets(eng):
         assert f.shape == ref.shape
         assert np.array_equal(f != 0, ref != 0)
         assert np.max(np.abs(f - ref)) < 1e-6 * np.abs(ref).max()
+
+
+# ------------------------------------------------------------------------------------------------ empty / ragged inputs
+def test_empty_and_ragged_batches(eng):
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    from oracle import lyssa_oracle as orc
+    rs = np.random.RandomState(12)
+    D = rs.randn(12, 70)
+    D /= np.linalg.norm(D, axis=0, keepdims=True)
+    D = D.astype(np.float32).astype(np.float64)
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 3}, verbose=False)
+    Z0 = se.encode(np.zeros((12, 0)), D)                         # no signals at all
+    assert Z0.shape == (70, 0) and Z0.dtype == np.float64
+    for N in (1, 2, 3, 5, 63, 65, 129):                          # not multiples of the 4-wave workgroup / 128-row tile
+        X = rs.randn(12, N).astype(np.float32).astype(np.float64)
+        Z = se.encode(X, D)
+        _, _, _, gap = orc.bomp_encode_sparse(X, D, 3)
+        Zo = orc.bomp_encode(X, D, 3)
+        ok = gap >= TIE_GAP
+        assert Z.shape == (70, N) and np.array_equal((Z != 0)[:, ok], (Zo != 0)[:, ok])
+        assert np.max(np.abs(Z - Zo)[:, ok]) < 1e-5 * np.abs(Zo).max()
+    # single atom, single feature: the smallest dictionary there is
+    Z = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 1}).encode(np.array([[2.0, -3.0, 0.0]]), np.array([[1.0]]))
+    assert Z.shape == (1, 3) and np.allclose(Z, [[2.0, -3.0, 0.0]])
+    # a strided / non-contiguous view and an integer-valued matrix are accepted like numpy arrays in the reference
+    Xbig = rs.randn(24, 40)
+    Zs = se.encode(Xbig[::2, ::2], D)
+    assert np.array_equal(Zs, se.encode(np.ascontiguousarray(Xbig[::2, ::2]), D))
+    # n_nonzero_coefs larger than the number of atoms is clamped by the greedy loop itself (re-selection stop)
+    Dsmall = np.eye(4)[:, :3]
+    Zc = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 5}).encode(rs.randn(4, 6), Dsmall)
+    assert Zc.shape == (3, 6) and np.all((Zc != 0).sum(0) <= 3)
+    # K-SVD on a batch where some signals are all-zero and one atom is never used
+    from lyssandra_amd.dict_learning.ksvd import approx_ksvd
+    X = rs.randn(12, 50)
+    X[:, 7] = 0
+    Zk = orc.bomp_encode(X, D, 3)
+    Dr, Zr, ur = orc.approx_ksvd(X, D.copy(), Zk.copy())
+    Dg, Zg = D.copy(), Zk.copy()
+    _, _, ug = approx_ksvd(X, Dg, Zg, verbose=False)
+    assert list(ug) == list(ur) and _atom_err(Dg, Dr) < 1e-5 and np.max(np.abs(Zg - Zr)) < 1e-5 * np.abs(Zr).max()
