@@ -153,3 +153,22 @@ def batch_omp(X, Alpha, D, Gram, n_nonzero_coefs=None, tol=None):
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                "lys_bomp_from_alpha0")
     return engine.densify(idx, coef, nnz, K)
+
+
+def _thresh_from_alpha(Alpha, nonzero_percentage=None, n_nonzero_coefs=None):
+    """`thresholding` / `soft_thresholding` (sparse_coding.py:416-425, feature_encoding.py:26-37) on a precomputed
+    Alpha: the correlations are uploaded as the alpha0 tile and go through `thresh_wave_kernel` with an identity
+    "dictionary" (alpha0 = Alpha'), i.e. the engine's own GEMM is bypassed, not the kernel."""
+    Alpha = np.asarray(Alpha)
+    K, N = Alpha.shape
+    k = n_nonzero_coefs
+    if nonzero_percentage is not None:
+        k = int(np.floor(nonzero_percentage * K))
+    # X := Alpha (features = atoms), D := I_K  =>  alpha0 = X D = Alpha'
+    se = sparse_encoder(algorithm='thresh', params={'n_nonzero_coefs': int(k)}, verbose=False)
+    return se.encode(Alpha, np.eye(K))
+
+
+def thresholding(Alpha, nonzero_percentage=None, n_nonzero_coefs=None):
+    """Function form of lyssa/sparse_coding.py:416-425."""
+    return _thresh_from_alpha(Alpha, nonzero_percentage, n_nonzero_coefs)
