@@ -57,7 +57,7 @@ int ksvd_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, f
 int ksvd_sweep_fused(float*, int64_t, int, int, int, const int32_t*, const int32_t*, const int32_t*, float*, double*,
                      float*, float*, hipStream_t);
 int ksvd_fused_step(int, int, float*, int64_t, int, int, const int32_t*, const int32_t*, const int32_t*, float*, double*,
-                    const float*, float*, hipStream_t);
+                    const float*, float*, hipStream_t, const int32_t* row_ptr_host = nullptr);
 int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const float*, const int32_t*, const int32_t*,
                    const int32_t*, float*, float*, hipStream_t);
 int axpby(float*, float, const float*, int64_t, hipStream_t);

@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256) void ksvd_apply_kernel(int atom, float* __rest
 // omega_{a-1} skips it.  Membership is decided from the signal's own k-entry support row, no merged list needed.
 // ---------------------------------------------------------------------------------------------
 template <int FB>
-__global__ __launch_bounds__(256) void ksvd_fused_kernel(int atom, int K, float* __restrict__ R, int64_t ldr, int n, int k,
+__global__ __launch_bounds__(256) void ksvd_fused_kernel(int atom, int K, int4 hb, int2 hn, float* __restrict__ R,
+                                                         int64_t ldr, int n, int k,
                                                          const int32_t* __restrict__ row_ptr,
                                                          const int32_t* __restrict__ entry,
                                                          const int32_t* __restrict__ idx, float* __restrict__ coef,
@@ -458,15 +459,18 @@ __global__ __launch_bounds__(256) void ksvd_fused_kernel(int atom, int K, float*
     __shared__ float s_acc[16][FB * 64 + 1];
     const int prev = atom - 1;
     const bool have_prev = prev >= 0, have_cur = atom < K;
-    const int pbeg = have_prev ? row_ptr[prev] : 0, pend = have_prev ? row_ptr[prev + 1] : 0;
-    const int cbeg = have_cur ? row_ptr[atom] : 0, cend = have_cur ? row_ptr[atom + 1] : 0;
+    // segment bounds: passed by value when the host knows row_ptr (hb.x >= 0), which removes one dependent load from
+    // the head of every launch; read from row_ptr otherwise (multi-GPU stepping)
+    const bool byval = hb.x >= 0;
+    const int pbeg = !have_prev ? 0 : byval ? hb.x : row_ptr[prev], pend = !have_prev ? 0 : byval ? hb.y : row_ptr[prev + 1];
+    const int cbeg = !have_cur ? 0 : byval ? hb.z : row_ptr[atom], cend = !have_cur ? 0 : byval ? hb.w : row_ptr[atom + 1];
     const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
     // ---- extra workgroups: warm L2 for the NEXT launch (atom+1): its entry list, coefficients, support rows and
     // residual rows are touched now, so that the next kernel's dependent loads hit L2 instead of HBM
     if ((int)blockIdx.x >= KSVD_BLOCKS) {
         const int nxt = atom + 1;
         if (nxt >= K) return;
-        const int nb = row_ptr[nxt], ne = row_ptr[nxt + 1];
+        const int nb = byval ? hn.x : row_ptr[nxt], ne = byval ? hn.y : row_ptr[nxt + 1];
         const int pteam = ((int)blockIdx.x - KSVD_BLOCKS) * 16 + team, pteams = ((int)gridDim.x - KSVD_BLOCKS) * 16;
         for (int e = nb + pteam; e < ne; e += pteams) {
             const int ss = entry[e];
@@ -646,7 +650,17 @@ __global__ __launch_bounds__(256) void ksvd_fused_kernel(int atom, int K, float*
 }
 
 int ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,
-                    const int32_t* idx, float* coef, double* sbuf, const float* D, float* Dnext, hipStream_t stream) {
+                    const int32_t* idx, float* coef, double* sbuf, const float* D, float* Dnext, hipStream_t stream,
+                    const int32_t* row_ptr_host) {
+    int4 hb = make_int4(-1, -1, -1, -1);
+    int2 hn = make_int2(0, 0);
+    if (row_ptr_host) {
+        hb.x = (atom >= 1) ? row_ptr_host[atom - 1] : 0;
+        hb.y = (atom >= 1) ? row_ptr_host[atom] : 0;
+        hb.z = (atom < K) ? row_ptr_host[atom] : 0;
+        hb.w = (atom < K) ? row_ptr_host[atom + 1] : 0;
+        if (atom + 1 < K) hn = make_int2(row_ptr_host[atom + 1], row_ptr_host[atom + 2]);
+    }
     const int ldd = padded_features(n);
     const int fb = (n <= 64) ? 1 : (n <= 128) ? 2 : (n <= 256) ? 4 : 0;
     static int pf = -1;  // workgroups that warm L2 for the next atom (LYS_KSVD_PREFETCH_BLOCKS, default 256: 13.1 -> 12.0 ms/sweep at config 2)
@@ -656,9 +670,9 @@ int ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, const 
         if (pf < 0) pf = 0;
     }
     switch (fb) {
-        case 1: hipLaunchKernelGGL(ksvd_fused_kernel<1>, dim3(KSVD_BLOCKS + pf), dim3(256), 0, stream, atom, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
-        case 2: hipLaunchKernelGGL(ksvd_fused_kernel<2>, dim3(KSVD_BLOCKS + pf), dim3(256), 0, stream, atom, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
-        case 4: hipLaunchKernelGGL(ksvd_fused_kernel<4>, dim3(KSVD_BLOCKS + pf), dim3(256), 0, stream, atom, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
+        case 1: hipLaunchKernelGGL(ksvd_fused_kernel<1>, dim3(KSVD_BLOCKS + pf), dim3(256), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
+        case 2: hipLaunchKernelGGL(ksvd_fused_kernel<2>, dim3(KSVD_BLOCKS + pf), dim3(256), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
+        case 4: hipLaunchKernelGGL(ksvd_fused_kernel<4>, dim3(KSVD_BLOCKS + pf), dim3(256), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
         default: set_error("ksvd: n = %d > 256 not supported", n); return LYS_ENOSUP;
     }
     LYS_LAUNCH_CHECK();
@@ -731,8 +745,28 @@ static SweepGraphCache g_sweep_cache[64];
 int ksvd_sweep_fused(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
                      const int32_t* idx, float* coef, double* sbuf, float* D, float* Dnext, hipStream_t stream) {
     LYS_CHECK_HIP(hipMemsetAsync(sbuf, 0, (size_t)K * (n + 1) * sizeof(double), stream));
+    // optional (LYS_KSVD_BOUNDS_BY_VALUE=1): one small D2H copy per cycle gives every launch its segment bounds by
+    // value.  Measured: no gain (11.59 vs 11.55 ms/sweep) -- the row_ptr load is not on the critical path -- so off.
+    static int byval = -1;
+    if (byval < 0) {
+        const char* e = getenv("LYS_KSVD_BOUNDS_BY_VALUE");
+        byval = (e && e[0] == '1') ? 1 : 0;
+    }
+    static thread_local int32_t* host_rp = nullptr;
+    static thread_local int host_cap = 0;
+    const int32_t* rp_host = nullptr;
+    if (byval) {
+        if (host_cap < K + 1) {
+            if (host_rp) hipHostFree(host_rp);
+            LYS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&host_rp), (size_t)(K + 1) * sizeof(int32_t), 0));
+            host_cap = K + 1;
+        }
+        LYS_CHECK_HIP(hipMemcpyAsync(host_rp, row_ptr, (size_t)(K + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        LYS_CHECK_HIP(hipStreamSynchronize(stream));
+        rp_host = host_rp;
+    }
     for (int a = 0; a <= K; ++a) {
-        const int rc = ksvd_fused_step(a, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, Dnext, stream);
+        const int rc = ksvd_fused_step(a, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, Dnext, stream, rp_host);
         if (rc) return rc;
     }
     return ksvd_commit(n, K, row_ptr, Dnext, D, stream);
