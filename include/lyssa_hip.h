@@ -205,6 +205,8 @@ int lys_pool_max_abs(const int32_t* idx, const float* coef, const int32_t* nnz, 
                      void* stream);
 
 /* ---- small utilities --------------------------------------------------------------------------- */
+/* *out_dev = sum of |G[a][b]|, a != b < K -- numerator of average_mutual_coherence (dict_learning/utils.py:7-11). */
+int lys_offdiag_abs_sum(const float* G, int K, double* out_dev, void* stream);
 /* Column normalisation of the packed dictionary, x/(||x||+eps) (utils/math.py:65-71). */
 int lys_norm_atoms(float* D_packed, int n, int K, void* stream);
 /* Sparse triplet -> dense fp64 Z (K x N, row-major, the reference's return type, sparse_coding.py:365). */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "lys_grid_patches": (_I, [_P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _L, _P]),
     "lys_preproc_signals": (_I, [_P, _L, _I, _L, _F, _I, _I, _P]),
     "lys_pool_max_abs": (_I, [_P, _P, _P, _I, _L, _P, _I, _I, _I, _P, _I, _P]),
+    "lys_offdiag_abs_sum": (_I, [_P, _I, _P, _P]),
     "lys_norm_atoms": (_I, [_P, _I, _I, _P]),
     "lys_densify_f64": (_I, [_P, _P, _P, _I, _I, _L, _P, _P]),
     "lys_debug_bomp_variant": (_I, [_P, _P, _L, _I, _P, _P, _P, _I, _I, _P]),

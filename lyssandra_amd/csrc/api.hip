@@ -63,6 +63,7 @@ int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const f
 int axpby(float*, float, const float*, int64_t, hipStream_t);
 int odl_update(float*, const float*, const float*, int, int, int, float*, hipStream_t);
 int norm_atoms(float*, int, int, hipStream_t);
+int offdiag_abs_sum(const float*, int, double*, hipStream_t);
 int grid_patches(const void*, int, int, int, int, int, int, float, int, int, float*, int64_t, hipStream_t);
 int preproc_signals(float*, int64_t, int, int64_t, float, int, int, hipStream_t);
 int pool_max_abs(const int32_t*, const float*, const int32_t*, int, int64_t, const int32_t*, int, int, int, float*, int,
@@ -426,6 +427,11 @@ int lys_pool_max_abs(const int32_t* idx, const float* coef, const int32_t* nnz, 
                      int n_levels, int K, int n_cells, float* out, int l2_normalize, void* stream) {
     LYS_REQUIRE(idx && coef && nnz && cell && out && n_levels >= 1 && K > 0 && n_cells > 0, "pool_max_abs: bad arguments");
     return pool_max_abs(idx, coef, nnz, k, N, cell, n_levels, K, n_cells, out, l2_normalize, STREAM(stream));
+}
+
+int lys_offdiag_abs_sum(const float* G, int K, double* out_dev, void* stream) {
+    LYS_REQUIRE(G && out_dev && K > 0, "offdiag_abs_sum: bad arguments");
+    return offdiag_abs_sum(G, K, out_dev, STREAM(stream));
 }
 
 int lys_norm_atoms(float* D_packed, int n, int K, void* stream) {

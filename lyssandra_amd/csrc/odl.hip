@@ -178,6 +178,35 @@ int norm_atoms(float* D, int n, int K, hipStream_t stream) {
     return LYS_OK;
 }
 
+// sum of |G[a][b]| over a != b, a,b < K  (average_mutual_coherence, lyssa/dict_learning/utils.py:7-11)
+__global__ __launch_bounds__(256) void offdiag_abs_sum_kernel(const float* __restrict__ G, int K, int Kp,
+                                                              double* __restrict__ out) {
+    __shared__ double s_part[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int a = blockIdx.x; a < K; a += gridDim.x) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < K; b += 256)
+            if (b != a) s += fabsf(G[(int64_t)a * Kp + b]);
+        acc += (double)s;
+    }
+    // block reduction: per-wave DPP sum of the float parts is not enough (acc is per thread): go through LDS
+    float f = (float)acc;
+    const float w = wave_sum_f(f);
+    if (lane == 0) s_part[wid] = (double)w;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+}
+
+int offdiag_abs_sum(const float* G, int K, double* out, hipStream_t stream) {
+    const int Kp = padded_atoms(K);
+    LYS_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
+    const int grid = K < 1024 ? K : 1024;
+    hipLaunchKernelGGL(offdiag_abs_sum_kernel, dim3(grid), dim3(256), 0, stream, G, K, Kp, out);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 __global__ void densify_kernel(const int32_t* __restrict__ idx, const float* __restrict__ coef,
                                const int32_t* __restrict__ nnz, int k, int64_t N, double* __restrict__ Z) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -42,10 +42,16 @@ def approx_error(D, Z, X, n_jobs=1):
 
 
 def average_mutual_coherence(D):
-    """lyssa/dict_learning/utils.py:7-11 -- mean off-diagonal |D'D| (Gram from the device MFMA GEMM)."""
+    """lyssa/dict_learning/utils.py:7-11 -- mean off-diagonal |D'D| (Gram from the MFMA GEMM, reduction on the device)."""
+    import ctypes
+    from .. import _lib
+    torch = engine.require_gpu()
+    lib = _lib.load()
     D = np.asarray(D)
     dd = engine.DeviceDictionary.from_host(D)
     K = dd.K
-    G = dd.gram()[:K, :K].abs()
-    tot = float(G.double().sum().item() - G.double().diagonal().sum().item())
-    return tot / float(K * (K - 1))
+    G = dd.gram()
+    out = torch.zeros((1,), dtype=torch.float64, device=dd.device)
+    _lib.check(lib.lys_offdiag_abs_sum(ctypes.c_void_p(G.data_ptr()), K, ctypes.c_void_p(out.data_ptr()),
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "lys_offdiag_abs_sum")
+    return float(out.item()) / float(K * (K - 1))

@@ -252,6 +252,12 @@ def test_sparse_encoder_dropin(eng):
 def test_residual_error_and_csr(eng):
     import torch
     from oracle import lyssa_oracle as orc
+    from lyssandra_amd.dict_learning.utils import average_mutual_coherence, approx_error
+    Dc = np.random.RandomState(1).randn(20, 37)
+    Dc /= np.linalg.norm(Dc, axis=0, keepdims=True)
+    assert abs(average_mutual_coherence(Dc) - orc.average_mutual_coherence(Dc)) < 1e-6
+    Zc = orc.bomp_encode(Dc[:, :5] * 2.0 + 0.1, Dc, 3)
+    assert abs(approx_error(Dc, Zc, Dc[:, :5] * 2.0 + 0.1) - orc.approx_error(Dc, Zc, Dc[:, :5] * 2.0 + 0.1)) < 1e-4
     g = load_golden("F5")
     X, D0, k = g["X"].astype(np.float64), g["D0"].astype(np.float64), int(g["k"])
     Xs = eng.signals_to_device(X)
