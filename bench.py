@@ -281,6 +281,19 @@ def cpu_baseline(Xs, Dt, k, sample, pool_workers=-1):
                                           % (done, len(jobs), dtp)}
         except Exception as e:  # the baseline must never take the bench line down
             out["all_cores"] = {"error": repr(e)}
+    # informative: the plain-C restatement (oracle/bomp_oracle.c, OpenMP over signals) -- what a tuned CPU port does
+    try:
+        from oracle import c_oracle
+        n_c = min(Xs.shape[0], 200000)
+        Xc = Xs[:n_c].t().contiguous().double().cpu().numpy()
+        c_oracle.bomp_encode_sparse(Xc[:, :256], D, k)
+        t0 = time.perf_counter()
+        c_oracle.bomp_encode_sparse(Xc, D, k)
+        dtc = time.perf_counter() - t0
+        out["c_port_all_cores"] = {"value": n_c / dtc, "unit": "patches/s", "cores": os.cpu_count(),
+                                   "sample": "%d patches, float64 C restatement with OpenMP, %.1f s" % (n_c, dtc)}
+    except Exception as e:
+        out["c_port_all_cores"] = {"error": repr(e)}
     return out
 
 

@@ -781,3 +781,32 @@ def test_empty_and_ragged_batches(eng):
     Dg, Zg = D.copy(), Zk.copy()
     _, _, ug = approx_ksvd(X, Dg, Zg, verbose=False)
     assert list(ug) == list(ur) and _atom_err(Dg, Dr) < 1e-5 and np.max(np.abs(Zg - Zr)) < 1e-5 * np.abs(Zr).max()
+
+
+# ------------------------------------------------------------------------------------------------ large direct parity
+def test_bomp_direct_parity_262144_signals(eng):
+    """SURVEY 8(d) parity protocol at scale: 2^18 seeded Gaussian patches at the metric shape, GPU supports / order /
+    coefficients against the float64 C restatement of the oracle (oracle/bomp_oracle.c, pinned to the reference)."""
+    import torch
+    from oracle import c_oracle
+    n, K, k, N = 64, 1024, 10, 1 << 18
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    Dt = torch.randn((n, K), device="cuda", generator=gen)
+    Dt = Dt / Dt.norm(dim=0, keepdim=True)
+    Xs = torch.randn((N, n), device="cuda", generator=gen)
+    dd = eng.DeviceDictionary(n, K)
+    dd.set(Dt)
+    idx, coef, nnz = _host_triplet(eng.bomp_encode(Xs, dd, k))
+    D = dd.D[:K, :n].t().contiguous().double().cpu().numpy()      # the fp32 values the engine really used
+    X = Xs.t().contiguous().double().cpu().numpy()
+    oi, oc, on, gap = c_oracle.bomp_encode_sparse(X, D, k)
+    ok = gap >= TIE_GAP
+    n_tie = int((~ok).sum())
+    n_tie_diff = int((idx[~ok] != oi[~ok]).any(axis=1).sum())
+    print("N=%d tie signals (gap < 1e-5): %d, of which selected differently: %d" % (N, n_tie, n_tie_diff))
+    assert n_tie < 0.01 * N
+    assert np.array_equal(idx[ok], oi[ok]) and np.array_equal(nnz[ok], on[ok])       # identical supports AND order
+    scale = np.abs(oc).max(axis=1, keepdims=True)
+    worst = np.max((np.abs(coef - oc) / scale)[ok])
+    print("worst coefficient error relative to max|z|: %.3g" % worst)
+    assert worst < COEF_TOL

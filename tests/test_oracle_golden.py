@@ -195,3 +195,24 @@ def test_patches_preproc_pooling_match_reference():
     for tag, l2 in (("plain", False), ("l2", True)):
         f = orc.spm_pool(g9["Z"], g9["pos"], int(g9["patch_size"]), (int(g9["H"]), int(g9["W"])), l2=l2)
         assert np.max(np.abs(f - g9["feat_" + tag])) <= 1e-14
+
+
+def test_c_oracle_matches_numpy_oracle_and_reference():
+    """oracle/bomp_oracle.c (fast float64 C restatement used for the large GPU parity runs) against the numpy oracle
+    and the reference-generated golden vectors, edge cases included."""
+    from oracle import c_oracle
+    for name in ("F1", "F2", "F3"):
+        g = load_golden(name)
+        X, D, k = g["X"].astype(np.float64), g["D"].astype(np.float64), int(g["k"])
+        idx, coef, nnz, gap = c_oracle.bomp_encode_sparse(X, D, k)
+        oi, oc, on, og = orc.bomp_encode_sparse(X, D, k)
+        assert np.array_equal(idx, oi) and np.array_equal(nnz, on)
+        assert np.max(np.abs(coef - oc)) <= 1e-12 and np.max(np.abs(gap - og)) <= 1e-9
+        Z = orc.densify(idx, coef, nnz, D.shape[1])
+        gi, gc, gn = _triplet_sorted(Z, k)
+        assert np.array_equal(gi, g["idx"]) and np.max(np.abs(gc - g["coef"])) <= 1e-12
+    g = load_golden("F4")
+    for case in ("dup", "k1", "k4K4", "pool37", "nonunit", "ragged"):
+        X, D, k = g[case + "_X"].astype(np.float64), g[case + "_D"].astype(np.float64), int(g[case + "_k"])
+        Z = orc.densify(*c_oracle.bomp_encode_sparse(X, D, k)[:3], D.shape[1])
+        assert np.array_equal(Z != 0, g[case + "_Z"] != 0) and np.max(np.abs(Z - g[case + "_Z"])) <= 1e-12, case
