@@ -810,3 +810,26 @@ def test_bomp_direct_parity_262144_signals(eng):
     worst = np.max((np.abs(coef - oc) / scale)[ok])
     print("worst coefficient error relative to max|z|: %.3g" % worst)
     assert worst < COEF_TOL
+
+
+@pytest.mark.parametrize("n,K,k,N", [(256, 4096, 20, 6000), (64, 2048, 10, 30000), (64, 256, 5, 100000),
+                                     (128, 1024, 10, 40000)])
+def test_bomp_direct_parity_other_shapes(eng, n, K, k, N):
+    """Config-3 (n=256, K=4096, k=20) and config-1 (K=256, k=5) shapes at sizes the C oracle finishes in seconds."""
+    import torch
+    from oracle import c_oracle
+    gen = torch.Generator(device="cuda").manual_seed(K + k)
+    Dt = torch.randn((n, K), device="cuda", generator=gen)
+    Dt = Dt / Dt.norm(dim=0, keepdim=True)
+    Xs = torch.randn((N, n), device="cuda", generator=gen)
+    dd = eng.DeviceDictionary(n, K)
+    dd.set(Dt)
+    idx, coef, nnz = _host_triplet(eng.bomp_encode(Xs, dd, k))
+    D = dd.D[:K, :n].t().contiguous().double().cpu().numpy()
+    X = Xs.t().contiguous().double().cpu().numpy()
+    oi, oc, on, gap = c_oracle.bomp_encode_sparse(X, D, k)
+    ok = gap >= TIE_GAP
+    assert ok.mean() > 0.98
+    assert np.array_equal(idx[ok], oi[ok]) and np.array_equal(nnz[ok], on[ok])
+    scale = np.abs(oc).max(axis=1, keepdims=True)
+    assert np.max((np.abs(coef - oc) / scale)[ok]) < COEF_TOL
