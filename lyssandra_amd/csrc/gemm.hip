@@ -10,6 +10,8 @@
 // 36 floats: a lane reads its operand as ONE ds_read_b128 (4 consecutive k) which feeds 4 MFMAs, and
 // 36 = 4 (mod 32) makes the 16-lane ds_read_b128 groups conflict-free (MI355X_MICROARCH.md, LDS).
 // The k-pairing inside an MFMA is (8q+e, 8q+4+e): any pairing is valid because the sum runs over all k.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace lys {
@@ -155,12 +157,14 @@ int gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, 
 // ------------------------------------------------------------------------------------------------
 constexpr int A0_LD = 68;  // 64 + 4: conflict-free ds_read_b128 (68 = 4 mod 32)
 
-__global__ __launch_bounds__(256, 2) void alpha0_n64_kernel(const float* __restrict__ X, int64_t ldx,
+template <int NJ>  // atom sub-tiles per wave: workgroup tile = 128 signals x 64*NJ atoms
+__global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void alpha0_n64_kernel(const float* __restrict__ X, int64_t ldx,
                                                             const float* __restrict__ D, int ldd,
                                                             float* __restrict__ C, int Kp, int64_t N, int n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [128][68] signals
-    float* Bs = smem + 128 * A0_LD;   // [128][68] atoms
+    float* Bs = smem + 128 * A0_LD;   // [64*NJ][68] atoms
+    constexpr int BN = 64 * NJ;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wsig = wid >> 1, watom = wid & 1;
     const int64_t bm = (int64_t)blockIdx.x * 128;
@@ -187,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_kernel(const float* __restr
         *reinterpret_cast<float4*>(&As[r * A0_LD + lc4]) = v;
     }
     // ---- first atom tile into registers (D is packed: ldd is a multiple of 8 and columns >= n are zero)
-    float4 pre[8];
+    float4 pre[4 * NJ];
     auto fetch = [&](int bn) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4 * NJ; ++i) {
             const int r = lrow + 16 * i;
             pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (lc4 < ldd) pre[i] = *reinterpret_cast<const float4*>(D + (int64_t)(bn + r) * ldd + lc4);
@@ -198,31 +202,32 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_kernel(const float* __restr
     };
     fetch(0);
     const int h = lane >> 5, l31 = lane & 31;
-    for (int bn = 0; bn < Kp; bn += 128) {
+    for (int bn = 0; bn < Kp; bn += BN) {
         __syncthreads();  // previous tile's LDS reads are done (and As is visible on the first pass)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 16 * i) * A0_LD + lc4]) = pre[i];
+        for (int i = 0; i < 4 * NJ; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 16 * i) * A0_LD + lc4]) = pre[i];
         __syncthreads();
-        if (bn + 128 < Kp) fetch(bn + 128);  // prefetch behind the MFMAs
-        f32x16 acc[2][2];
+        if (bn + BN < Kp) fetch(bn + BN);  // prefetch behind the MFMAs
+        f32x16 acc[2][NJ];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            float4 a[2], b[2];
+            float4 a[2], b[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 2; ++i)
                 a[i] = *reinterpret_cast<const float4*>(&As[(wsig * 64 + i * 32 + l31) * A0_LD + q * 8 + h * 4]);   // signals
-                b[i] = *reinterpret_cast<const float4*>(&Bs[(watom * 64 + i * 32 + l31) * A0_LD + q * 8 + h * 4]);  // atoms
-            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                b[j] = *reinterpret_cast<const float4*>(&Bs[(watom * 32 * NJ + j * 32 + l31) * A0_LD + q * 8 + h * 4]);  // atoms
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
@@ -233,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = bn + watom * 64 + j * 32 + l31;
+            for (int j = 0; j < NJ; ++j) {
+                const int col = bn + watom * 32 * NJ + j * 32 + l31;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t row = bm + wsig * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -249,13 +254,22 @@ bool alpha0_fast_path(int n, int Kp) { return n <= 64 && (Kp % 128) == 0; }
 int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, int Kp, int64_t N, int n,
                hipStream_t stream) {
     if (N <= 0) return LYS_OK;
-    const size_t lds = 2 * 128 * A0_LD * sizeof(float);
+    // LYS_ALPHA0_BN = 64 | 128 atoms per workgroup tile.  Measured: 128 (2 workgroups/CU) 80.7 TFLOP/s, 64 (3/CU)
+    // 77.7 -- occupancy is not the limiter, the 1 GiB/tile of alpha0 stores is (about 2.6 TB/s).
+    static int nj = -1;
+    if (nj < 0) {
+        const char* e = getenv("LYS_ALPHA0_BN");
+        nj = (e && atoi(e) == 64) ? 1 : 2;
+    }
+    const size_t lds = (size_t)(128 + 64 * nj) * A0_LD * sizeof(float);
     static bool attr_set[64] = {false};
     int dev = 0;
     LYS_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * A0_LD * (int)sizeof(float)));
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 192 * A0_LD * (int)sizeof(float)));
         attr_set[dev] = true;
     }
     const int64_t blocks = (N + 127) / 128;
@@ -263,7 +277,10 @@ int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, i
         set_error("alpha0: grid too large");
         return LYS_ENOSUP;
     }
-    hipLaunchKernelGGL(alpha0_n64_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
+    if (nj == 2)
+        hipLaunchKernelGGL(alpha0_n64_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
+    else
+        hipLaunchKernelGGL(alpha0_n64_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
