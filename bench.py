@@ -173,7 +173,7 @@ def main():
                 "patches_per_launch": sig_per_launch,
                 "avg_launch_ms": omp_avg_ms,
                 "launches_timed": launches.value,
-                "gemm_stage": {"kernel": "gemm_nt_f32_kernel (alpha0 = X D, v_mfma_f32_32x32x2_f32)",
+                "gemm_stage": {"kernel": "alpha0_n64_kernel (alpha0 = X D, v_mfma_f32_32x32x2_f32, software-pipelined buffer stores)",
                                "achieved": gemm_tf, "frac": gemm_tf / PEAK_FP32_TFLOPS, "flop_per_patch": f_gemm,
                                "avg_launch_ms": gemm_avg_ms},
                 "whole_step": {"achieved": step_tf, "frac": step_tf / PEAK_FP32_TFLOPS,

@@ -157,7 +157,12 @@ int gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, 
 // ------------------------------------------------------------------------------------------------
 constexpr int A0_LD = 68;  // 64 + 4: conflict-free ds_read_b128 (68 = 4 mod 32)
 
-template <int NJ>  // atom sub-tiles per wave: workgroup tile = 128 signals x 64*NJ atoms
+// MODE 0: direct epilogue (dword stores, 128-B row segments).
+// MODE 2: software-pipelined stores -- two accumulator sets; tile t's 64 stores are issued 8 at a time between the MFMA
+//         groups of tile t+1, so the store queue drains at a steady rate under the matrix pipe instead of in bursts.
+// MODE 1: the epilogue goes through LDS (the atom tile's buffer is free by then) so that every store instruction writes
+// two full 512-byte row segments (dwordx4 per lane) instead of two 128-byte segments (dword per lane).
+template <int NJ, int MODE>  // NJ atom sub-tiles per wave: workgroup tile = 128 signals x 64*NJ atoms
 __global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void alpha0_n64_kernel(const float* __restrict__ X, int64_t ldx,
                                                             const float* __restrict__ D, int ldd,
                                                             float* __restrict__ C, int Kp, int64_t N, int n) {
@@ -202,6 +207,81 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void alpha0_n64_kernel(cons
     };
     fetch(0);
     const int h = lane >> 5, l31 = lane & 31;
+    if constexpr (MODE == 2) {
+        f32x16 accA[2][NJ], accB[2][NJ];
+        // MODE 2 is launched on whole 128-signal tiles only (no row checks).  Addresses are a wave-uniform 64-bit
+        // base (SALU) plus one 32-bit lane offset, so the 64 stores of a tile cost no address VGPRs.
+        const int wsig_u = __builtin_amdgcn_readfirstlane(wsig), watom_u = __builtin_amdgcn_readfirstlane(watom);
+        // buffer stores: descriptor = this workgroup's 128 rows of C (SGPRs), one VGPR lane offset, SALU row/column offset
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(C + bm * Kp, 0, 128 * Kp * (int)sizeof(float), 0x00020000);
+        const int lane_off = ((4 * h) * Kp + l31) * (int)sizeof(float);
+        auto store_part = [&](f32x16 (&acc)[2][NJ], int bn, int part) {   // 8 parts of 4*NJ stores
+            const int i = part >> 2;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = (part & 3) * 4 + rr;
+                    const int soff = ((wsig_u * 64 + i * 32 + (r & 3) + 8 * (r >> 2)) * Kp + bn + watom_u * 32 * NJ + j * 32) *
+                                     (int)sizeof(float);
+                    const float val = acc[i][j][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrc, lane_off, soff, 2 /* nt */);
+                }
+            }
+        };
+        auto tile = [&](f32x16 (&cur)[2][NJ], f32x16 (&prev)[2][NJ], int bn, bool have_prev) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4 * NJ; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 16 * i) * A0_LD + lc4]) = pre[i];
+            __syncthreads();
+            if (bn + BN < Kp) fetch(bn + BN);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[i][j][r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float4 a[2], b[NJ];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i] = *reinterpret_cast<const float4*>(&As[(wsig * 64 + i * 32 + l31) * A0_LD + q * 8 + h * 4]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    b[j] = *reinterpret_cast<const float4*>(&Bs[(watom * 32 * NJ + j * 32 + l31) * A0_LD + q * 8 + h * 4]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, cur[i][j], 0, 0, 0);
+                        cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, cur[i][j], 0, 0, 0);
+                        cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, cur[i][j], 0, 0, 0);
+                        cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, cur[i][j], 0, 0, 0);
+                    }
+                if (have_prev) store_part(prev, bn - BN, q);
+            }
+        };
+        // at the loop back edge the pending (not yet stored) tile is always in accB
+        bool pending_b = false;
+        for (int bn = 0; bn < Kp; bn += 2 * BN) {
+            tile(accA, accB, bn, bn > 0);
+            if (bn + BN < Kp) {
+                tile(accB, accA, bn + BN, true);
+                pending_b = true;
+            } else {
+                pending_b = false;
+#pragma unroll
+                for (int part = 0; part < 8; ++part) store_part(accA, bn, part);
+            }
+        }
+        if (pending_b) {
+#pragma unroll
+            for (int part = 0; part < 8; ++part) store_part(accB, Kp - BN, part);
+        }
+        return;
+    }
     for (int bn = 0; bn < Kp; bn += BN) {
         __syncthreads();  // previous tile's LDS reads are done (and As is visible on the first pass)
 #pragma unroll
@@ -234,18 +314,51 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void alpha0_n64_kernel(cons
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        // ---- epilogue (rows = signals): acc[i][j][r] = C[signal = wsig*64 + i*32 + (r&3) + 8(r>>2) + 4h][atom = .. + l31]
+        if constexpr (MODE == 1 && NJ == 2) {
+            constexpr int SLD = 132;  // staging row stride (floats): 64 rows x 132 x 4 B = 33 792 B <= the Bs region
+            float* Stg = Bs;
+            __syncthreads();          // every wave is done reading this atom tile
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int half = 0; half < 2; ++half) {
+                if (wsig == half) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int col = bn + watom * 32 * NJ + j * 32 + l31;
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = bm + wsig * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < N) __builtin_nontemporal_store(acc[i][j][r], &C[row * Kp + col]);
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                Stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * SLD + watom * 64 + j * 32 + l31] =
+                                    acc[i][j][r];
                 }
+                __syncthreads();
+                // 64 rows x 128 floats = 2048 float4: 8 per thread; a wave stores 2 rows x 512 B per instruction
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int v = tid + 256 * t;
+                    const int row = v >> 5, c4 = (v & 31) * 4;
+                    const int64_t grow = bm + half * 64 + row;
+                    if (grow < N) {
+                        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                        const f32x4_ val = *reinterpret_cast<const f32x4_*>(&Stg[row * SLD + c4]);
+                        __builtin_nontemporal_store(val, reinterpret_cast<f32x4_*>(C + grow * Kp + bn + c4));
+                    }
+                }
+                __syncthreads();
             }
+        } else {
+            // ---- epilogue (rows = signals): acc[i][j][r] = C[signal = wsig*64 + i*32 + (r&3) + 8(r>>2) + 4h][atom = .. + l31]
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = bn + watom * 32 * NJ + j * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = bm + wsig * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < N) __builtin_nontemporal_store(acc[i][j][r], &C[row * Kp + col]);
+                    }
+                }
+        }
     }
 }
 
@@ -256,19 +369,25 @@ int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, i
     if (N <= 0) return LYS_OK;
     // LYS_ALPHA0_BN = 64 | 128 atoms per workgroup tile.  Measured: 128 (2 workgroups/CU) 80.7 TFLOP/s, 64 (3/CU)
     // 77.7 -- occupancy is not the limiter, the 1 GiB/tile of alpha0 stores is (about 2.6 TB/s).
-    static int nj = -1;
+    static int nj = -1, xpose = 2;
     if (nj < 0) {
         const char* e = getenv("LYS_ALPHA0_BN");
         nj = (e && atoi(e) == 64) ? 1 : 2;
+        const char* x = getenv("LYS_ALPHA0_XPOSE");
+        xpose = x ? atoi(x) : 2;   // LYS_ALPHA0_XPOSE = 0 direct | 1 LDS transpose | 2 pipelined stores (default)
     }
     const size_t lds = (size_t)(128 + 64 * nj) * A0_LD * sizeof(float);
     static bool attr_set[64] = {false};
     int dev = 0;
     LYS_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<2>),
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<2, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * A0_LD * (int)sizeof(float)));
-        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<1>),
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<2, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * A0_LD * (int)sizeof(float)));
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<2, 0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * A0_LD * (int)sizeof(float)));
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<1, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 192 * A0_LD * (int)sizeof(float)));
         attr_set[dev] = true;
     }
@@ -277,10 +396,20 @@ int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, i
         set_error("alpha0: grid too large");
         return LYS_ENOSUP;
     }
-    if (nj == 2)
-        hipLaunchKernelGGL(alpha0_n64_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
+    if (nj == 2 && xpose == 2) {
+        const int64_t whole = N / 128, tail = N - whole * 128;
+        if (whole)
+            hipLaunchKernelGGL((alpha0_n64_kernel<2, 2>), dim3((unsigned)whole), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp,
+                               whole * 128, n);
+        if (tail)
+            hipLaunchKernelGGL((alpha0_n64_kernel<2, 0>), dim3(1), dim3(256), lds, stream, X + whole * 128 * ldx, ldx, D, ldd,
+                               C + whole * 128 * Kp, Kp, tail, n);
+    } else if (nj == 2 && xpose == 1)
+        hipLaunchKernelGGL((alpha0_n64_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
+    else if (nj == 2)
+        hipLaunchKernelGGL((alpha0_n64_kernel<2, 0>), dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
     else
-        hipLaunchKernelGGL(alpha0_n64_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
+        hipLaunchKernelGGL((alpha0_n64_kernel<1, 0>), dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
