@@ -130,6 +130,20 @@ int lys_ksvd_atom_accumulate(int atom, const float* R, int64_t ldr, int n, int k
 int lys_ksvd_atom_apply(int atom, float* R, int64_t ldr, int n, int k,
                         const int32_t* row_ptr, const int32_t* entry, float* coef,
                         const double* sbuf, const float* D_packed, float* D_next, void* stream);
+/*
+ * Exact rank-1 K-SVD cycle, lyssa/dict_learning/ksvd.py:19-43 (`ksvd`): for atoms 0..K-1 in order, the leading
+ * singular triplet (u, sigma, v) of Rk = R[:, omega] + d_old x_omega replaces (d, x_omega) and R[:, omega] = Rk - u sigma v'.
+ * The reference calls sklearn's randomized_svd(n_iter=10, flip_sign=False) (random sign, not bit-reproducible);
+ * here, per atom: C = Rk Rk' (n x n, fp64), its leading eigenvector u by Lanczos with full re-orthogonalisation
+ * (<= 32 steps, started at d_old) + Rayleigh-Ritz, then x_omega = Rk'u; sign u . d_old >= 0.
+ * work: lys_ksvd_exact_workspace_bytes(n).  max_support >= max_a |omega_a| (N is always valid).  Unused atoms keep
+ * their column.  Single GPU.
+ */
+size_t lys_ksvd_exact_workspace_bytes(int n);
+int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k,
+                         const int32_t* row_ptr, const int32_t* entry, float* coef,
+                         double* work, size_t work_bytes, float* D_packed, float* D_next,
+                         int64_t max_support, void* stream);
 /* Whole cycle on one GPU (atoms 0..K-1 in order, both phases, then commit); sbuf is zeroed inside. */
 int lys_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k,
                    const int32_t* row_ptr, const int32_t* entry, float* coef,

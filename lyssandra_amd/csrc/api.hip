@@ -52,6 +52,9 @@ int ksvd_atom_accumulate(int, const float*, int64_t, int, int, const int32_t*, c
 int ksvd_atom_apply(int, float*, int64_t, int, int, const int32_t*, const int32_t*, float*, const double*,
                     const float*, float*, hipStream_t);
 int ksvd_commit(int, int, const int32_t*, const float*, float*, hipStream_t);
+int ksvd_exact_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
+                     int64_t, hipStream_t);
+size_t ksvd_exact_work_doubles(int);
 int ksvd_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
                hipStream_t);
 int ksvd_sweep_fused(float*, int64_t, int, int, int, const int32_t*, const int32_t*, const int32_t*, float*, double*,
@@ -380,6 +383,17 @@ int lys_ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, co
                     atom <= K,
                 "ksvd_fused_step: bad arguments");
     return ksvd_fused_step(atom, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D_packed, D_next, STREAM(stream));
+}
+
+size_t lys_ksvd_exact_workspace_bytes(int n) { return ksvd_exact_work_doubles(n) * sizeof(double); }
+
+int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
+                         float* coef, double* work, size_t work_bytes, float* D_packed, float* D_next,
+                         int64_t max_support, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && coef && work && D_packed && D_next && (ldr % 4) == 0 && max_support >= 0,
+                "ksvd_exact_sweep: bad arguments");
+    LYS_REQUIRE(work_bytes >= ksvd_exact_work_doubles(n) * sizeof(double), "ksvd_exact_sweep: work buffer too small");
+    return ksvd_exact_sweep(R, ldr, n, K, k, row_ptr, entry, coef, work, D_packed, D_next, max_support, STREAM(stream));
 }
 
 int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, float* D_packed, void* stream) {

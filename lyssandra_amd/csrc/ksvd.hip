@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <algorithm>
 
 namespace lys {
 
@@ -717,6 +718,299 @@ int ksvd_commit(int n, int K, const int32_t* row_ptr, const float* Dnext, float*
     hipLaunchKernelGGL(ksvd_commit_kernel, dim3(K), dim3(64), 0, stream, padded_features(n), K, row_ptr, Dnext, D);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact rank-1 K-SVD atom update (lyssa/dict_learning/ksvd.py:19-43).  The reference takes the leading singular
+// triplet of Rk = R[:, omega] + d_old x_omega with sklearn's randomized_svd(n_components=1, n_iter=10).  Here, per atom:
+//   1. ksvd_gram_kernel   C = Rk Rk' (n x n, fp64 atomics of fp32 64x64 register tiles; one pass over the atom's rows)
+//   2. ksvd_eig_kernel    leading eigenvector u of C: Lanczos with full re-orthogonalisation (<= 32 steps, one
+//                         workgroup, basis in LDS, C read from L2) + Rayleigh-Ritz on the small projected matrix
+//   3. ksvd_exact_apply_kernel   x_i = rk_i . u (= sigma v_i), R_i = rk_i - u x_i
+// Sign convention: u . d_old >= 0 (the reference's sign is arbitrary, flip_sign=False).
+// ---------------------------------------------------------------------------------------------
+constexpr int GRAM_TS = 32;   // signals staged per LDS tile
+constexpr int GRAM_SPB = 256; // signals per workgroup (bounds the number of fp64 atomics per atom)
+
+__global__ __launch_bounds__(256) void ksvd_gram_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                                        const int32_t* __restrict__ row_ptr,
+                                                        const int32_t* __restrict__ entry,
+                                                        const float* __restrict__ coef, const float* __restrict__ D,
+                                                        int ldd, double* __restrict__ C) {
+    __shared__ __attribute__((aligned(16))) float As[GRAM_TS][68];
+    __shared__ __attribute__((aligned(16))) float Bs[GRAM_TS][68];
+    const int beg = row_ptr[atom], end = row_ptr[atom + 1];
+    const int s0 = beg + blockIdx.x * GRAM_SPB;
+    if (s0 >= end) return;
+    const int s1 = min(end, s0 + GRAM_SPB);
+    // blockIdx.y enumerates the upper-triangular 64x64 blocks (bi <= bj) of C
+    int bi = 0, bj = blockIdx.y;
+    const int nb = (n + 63) >> 6;
+    while (bj >= nb - bi) {
+        bj -= nb - bi;
+        ++bi;
+    }
+    bj += bi;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int lsig = tid >> 3, lf = (tid & 7) * 8;  // loader: signal lsig of the tile, features lf..lf+7 of the block
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+    for (int t0 = s0; t0 < s1; t0 += GRAM_TS) {
+        const int e = t0 + lsig;
+        float va[8], vb[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) va[c] = vb[c] = 0.f;
+        if (e < s1) {
+            const int ss = entry[e];
+            const int64_t sig = ss / k;
+            const float x = coef[ss];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int fa = bi * 64 + lf + c, fb = bj * 64 + lf + c;
+                if (fa < n) va[c] = fmaf(D[(int64_t)atom * ldd + fa], x, R[sig * ldr + fa]);
+                if (fb < n) vb[c] = fmaf(D[(int64_t)atom * ldd + fb], x, R[sig * ldr + fb]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            As[lsig][lf + c] = va[c];
+            Bs[lsig][lf + c] = vb[c];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int sgl = 0; sgl < GRAM_TS; ++sgl) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[sgl][4 * ty]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[sgl][4 * tx]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = fmaf(av[a], bv[c], acc[a][c]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int r = bi * 64 + 4 * ty + a, cc = bj * 64 + 4 * tx + c;
+            if (r < n && cc < n) {
+                atomicAdd(C + (int64_t)r * n + cc, (double)acc[a][c]);
+                if (bi != bj) atomicAdd(C + (int64_t)cc * n + r, (double)acc[a][c]);
+            }
+        }
+}
+
+constexpr int EIG_M = 32;  // Lanczos steps (Krylov dimension)
+
+__device__ __forceinline__ double block_sum_d(double x, double* red /* [4] in LDS */) {
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// One workgroup (256 threads).  Dynamic LDS: Q[(EIG_M + 1) * n] doubles.
+__global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const int32_t* __restrict__ row_ptr,
+                                                       const double* __restrict__ C, const float* __restrict__ D,
+                                                       int ldd, float* __restrict__ Dnext) {
+    extern __shared__ __attribute__((aligned(16))) double Q[];  // [EIG_M + 1][n]
+    __shared__ double H[EIG_M][EIG_M], T[EIG_M][EIG_M];
+    __shared__ double hh[EIG_M + 1], red[4], wv[256], cvec[EIG_M];
+    __shared__ int m_used;
+    if (row_ptr[atom] >= row_ptr[atom + 1]) return;
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    // n <= 256: thread tid owns component tid of every n-vector
+    const double d0 = (tid < n) ? (double)D[(int64_t)atom * ldd + tid] : 0.0;
+    for (int i = tid; i < EIG_M * EIG_M; i += 256) (&H[0][0])[i] = 0.0;
+    double nrm2 = block_sum_d(d0 * d0, red);
+    {
+        double q0 = (nrm2 > 0.0) ? d0 / sqrt(nrm2) : (tid == 0 ? 1.0 : 0.0);
+        if (tid < n) Q[tid] = q0;
+    }
+    if (tid == 0) m_used = EIG_M;
+    __syncthreads();
+    double scale0 = 0.0;
+    int m = 0;
+    for (int j = 0; j < EIG_M; ++j) {
+        // w = C q_j (C symmetric: column access is coalesced)
+        double w = 0.0;
+        if (tid < n) {
+            const double* qj = Q + (int64_t)j * n;
+            for (int c = 0; c < n; ++c) w = fma(C[(int64_t)c * n + tid], qj[c], w);
+        }
+        // classical Gram-Schmidt, twice, against q_0..q_j; the first round's coefficients are column j of H
+        for (int round = 0; round < 2; ++round) {
+            wv[tid] = w;
+            __syncthreads();
+            for (int i = wid; i <= j; i += 4) {
+                double d = 0.0;
+                for (int c = lane; c < n; c += 64) d = fma(Q[(int64_t)i * n + c], wv[c], d);
+                for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+                if (lane == 0) hh[i] = d;
+            }
+            __syncthreads();
+            if (tid < n)
+                for (int i = 0; i <= j; ++i) w = fma(-hh[i], Q[(int64_t)i * n + tid], w);
+            if (tid <= j) {
+                if (round == 0) H[tid][j] = hh[tid];
+                else H[tid][j] += hh[tid];
+            }
+            __syncthreads();
+        }
+        const double beta2 = block_sum_d(w * w, red);
+        const double beta = sqrt(beta2);
+        m = j + 1;
+        if (j == 0) scale0 = fabs(H[0][0]) + beta;
+        if (!(beta > 1e-13 * scale0) || j == EIG_M - 1 || j + 1 >= n) break;  // Krylov space exhausted
+        if (tid < n) Q[(int64_t)(j + 1) * n + tid] = w / beta;
+        __syncthreads();
+    }
+    // Rayleigh-Ritz: leading eigenvector of the m x m projected matrix Q'CQ by repeated squaring (2^14 power steps)
+    __syncthreads();
+    for (int i = tid; i < EIG_M * EIG_M; i += 256) {
+        const int r = i / EIG_M, c = i % EIG_M;
+        T[r][c] = (r < m && c < m) ? H[min(r, c)][max(r, c)] : 0.0;  // H holds q_i . C q_j for i <= j
+    }
+    __syncthreads();
+    for (int it = 0; it < 14; ++it) {
+        double mx = 0.0;
+        for (int i = tid; i < EIG_M * EIG_M; i += 256) mx = fmax(mx, fabs((&T[0][0])[i]));
+        for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+        __syncthreads();
+        if (lane == 0) red[wid] = mx;
+        __syncthreads();
+        mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        if (!(mx > 0.0)) break;
+        const double inv = 1.0 / mx;
+        double tnew[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = tid + 256 * e, r = i / EIG_M, c = i % EIG_M;
+            double t = 0.0;
+            for (int l = 0; l < EIG_M; ++l) t = fma(T[r][l] * inv, T[l][c] * inv, t);
+            tnew[e] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) (&T[0][0])[tid + 256 * e] = tnew[e];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int jb = 0;
+        for (int j = 1; j < m; ++j)
+            if (T[j][j] > T[jb][jb]) jb = j;
+        const bool ok = T[jb][jb] > 0.0;
+        for (int i = 0; i < EIG_M; ++i) cvec[i] = ok ? T[i][jb] : (i == 0 ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    double u = 0.0;
+    if (tid < n)
+        for (int j = 0; j < m; ++j) u = fma(cvec[j], Q[(int64_t)j * n + tid], u);
+    const double un2 = block_sum_d(u * u, red);
+    const double sg = block_sum_d(u * d0, red);
+    if (un2 > 0.0) u *= (sg < 0.0 ? -1.0 : 1.0) / sqrt(un2);
+    else u = d0;
+    if (tid < n) Dnext[(int64_t)atom * ldd + tid] = (float)u;
+}
+
+// x_i = rk_i . u (= sigma v_i), R_i = rk_i - u x_i with u = D_next[atom] (ksvd.py:36-40)
+template <int FB>
+__global__ __launch_bounds__(256) void ksvd_exact_apply_kernel(int atom, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                               const int32_t* __restrict__ row_ptr,
+                                                               const int32_t* __restrict__ entry,
+                                                               float* __restrict__ coef, const float* __restrict__ D,
+                                                               int ldd, const float* __restrict__ Dnext) {
+    const int beg = row_ptr[atom], end = row_ptr[atom + 1];
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int gteam = blockIdx.x * 16 + team, nteams = gridDim.x * 16;
+    if (beg + blockIdx.x * 16 >= end) return;
+    float4 dold[FB], u[FB];
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        const int f = 64 * b + 4 * q;
+        dold[b] = u[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < n) {
+            dold[b] = *reinterpret_cast<const float4*>(D + (int64_t)atom * ldd + f);
+            u[b] = *reinterpret_cast<const float4*>(Dnext + (int64_t)atom * ldd + f);
+        }
+    }
+    for (int e = beg + gteam; e < end; e += nteams) {
+        const int ss = entry[e];
+        const int64_t sig = ss / k;
+        const float xo = coef[ss];
+        float4 rk[FB];
+        float dot = 0.f;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < n) r = *reinterpret_cast<const float4*>(R + sig * ldr + f);
+            rk[b].x = fmaf(dold[b].x, xo, r.x);
+            rk[b].y = fmaf(dold[b].y, xo, r.y);
+            rk[b].z = fmaf(dold[b].z, xo, r.z);
+            rk[b].w = fmaf(dold[b].w, xo, r.w);
+            dot = fmaf(rk[b].x, u[b].x, dot);
+            dot = fmaf(rk[b].y, u[b].y, dot);
+            dot = fmaf(rk[b].z, u[b].z, dot);
+            dot = fmaf(rk[b].w, u[b].w, dot);
+        }
+        const float xn = row16_sum(dot);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (f < n) {
+                float4 o;
+                o.x = fmaf(-u[b].x, xn, rk[b].x);
+                o.y = fmaf(-u[b].y, xn, rk[b].y);
+                o.z = fmaf(-u[b].z, xn, rk[b].z);
+                o.w = fmaf(-u[b].w, xn, rk[b].w);
+                *reinterpret_cast<float4*>(R + sig * ldr + f) = o;
+            }
+        }
+        if (q == 0) coef[ss] = xn;
+    }
+}
+
+size_t ksvd_exact_work_doubles(int n) { return (size_t)n * n; }
+
+// One exact cycle on one GPU.  max_support: upper bound of |omega_a| over the atoms (sizes the Gram grid).
+int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
+                     float* coef, double* work, float* D, float* Dnext, int64_t max_support, hipStream_t stream) {
+    const int ldd = padded_features(n);
+    const int fb = fb_of(n);
+    if (!fb) {
+        set_error("ksvd: n = %d > 256 not supported", n);
+        return LYS_ENOSUP;
+    }
+    static bool attr_set[64] = {};
+    int dev = 0;
+    LYS_CHECK_HIP(hipGetDevice(&dev));
+    const size_t eig_lds = (size_t)(EIG_M + 1) * n * sizeof(double);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ksvd_eig_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (EIG_M + 1) * 256 * (int)sizeof(double)));
+        attr_set[dev] = true;
+    }
+    const int nb = (n + 63) / 64;
+    const unsigned gx = (unsigned)std::max<int64_t>(1, (max_support + GRAM_SPB - 1) / GRAM_SPB);
+    for (int a = 0; a < K; ++a) {
+        LYS_CHECK_HIP(hipMemsetAsync(work, 0, (size_t)n * n * sizeof(double), stream));
+        hipLaunchKernelGGL(ksvd_gram_kernel, dim3(gx, nb * (nb + 1) / 2), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
+                           entry, coef, D, ldd, work);
+        hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, a, n, row_ptr, work, D, ldd, Dnext);
+        switch (fb) {
+            case 1: hipLaunchKernelGGL(ksvd_exact_apply_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
+            case 2: hipLaunchKernelGGL(ksvd_exact_apply_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
+            default: hipLaunchKernelGGL(ksvd_exact_apply_kernel<4>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
+        }
+        LYS_LAUNCH_CHECK();
+    }
+    return ksvd_commit(n, K, row_ptr, Dnext, D, stream);
 }
 
 // The 2K+2 dependent launches of one cycle are captured once into a hipGraph and replayed while the buffer

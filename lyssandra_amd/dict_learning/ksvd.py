@@ -36,6 +36,26 @@ def approx_ksvd(Y, D, X, n_cycles=1, verbose=True):
     return D, X, unused_atoms
 
 
+def ksvd(Y, D, X, n_cycles=1, verbose=True):
+    """lyssa/dict_learning/ksvd.py:19-43 -- the exact K-SVD update (rank-1 SVD of every atom's restricted residual).
+
+    Same in-place contract as ``approx_ksvd``.  The reference's ``randomized_svd(n_iter=10, flip_sign=False)`` is
+    replaced by a deterministic device eigen-solve (Gram matrix + Lanczos started from the old atom), so atoms agree with the
+    reference up to the sign of (d_k, x_k) and the accuracy of the randomized solver; D X is sign-invariant.
+    """
+    Ys = engine.signals_to_device(Y)
+    dd = engine.DeviceDictionary.from_host(D)
+    idx, coef, nnz = engine.sparsify_host(X)
+    R, _ = engine.residual(Ys, dd, idx, coef, nnz, want_R=True, want_err=False)
+    unused_atoms = []
+    buffers = {}
+    for _ in range(n_cycles):
+        unused_atoms += engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=buffers)
+    D[:] = dd.to_host()
+    _scatter_codes(X, idx, coef, nnz)
+    return D, X, unused_atoms
+
+
 def _scatter_codes(X, idx, coef, nnz):
     """Write the (updated) coefficients back into the dense host matrix, support unchanged."""
     hi, hc, hn = idx.cpu().numpy(), coef.cpu().numpy(), nnz.cpu().numpy()
@@ -49,7 +69,7 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
                     max_iter=20, non_neg=False, approx=False, eta=None,
                     n_cycles=1, n_jobs=1, mmap=False, verbose=True, return_codes=True, group=None, shard_span=None,
                     n_total=None):
-    """lyssa/dict_learning/ksvd.py:129-231 (``approx=True`` path).
+    """lyssa/dict_learning/ksvd.py:129-231 (``approx=True``: approximate update; ``approx=False``: exact rank-1 update).
 
     Returns ``(D, Z)`` with D float64 (n, K) and Z dense float64 (K, N) -- pass ``return_codes=False`` to skip
     the dense materialisation (then Z is the device triplet).  Reference behaviours kept on purpose:
@@ -62,9 +82,10 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
     are all-reduced, `init_dict='data'` and the unused-atom replacement work on GLOBAL signal indices (every rank
     must hold the same numpy RNG state).  The returned codes are the local shard's.
     """
-    if not approx or non_neg:
-        raise NotImplementedError("only approx=True, non_neg=False is on the accelerated path "
-                                  "(exact rank-1 K-SVD / nn-K-SVD are out of scope)")
+    if non_neg and not approx:
+        raise NotImplementedError("nn_ksvd (non_neg=True with approx=False) is outside the accelerated path")
+    if not approx and group is not None:
+        raise NotImplementedError("the exact K-SVD update runs on one GPU (approx=True shards over a group)")
     if eta is not None:
         raise NotImplementedError("eta (force_mi) is outside the accelerated path")
     X = np.asarray(X)
@@ -111,7 +132,10 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
                                out=R if (R is not None and R.shape[0] == idx.shape[0]) else None)
         unused_atoms = []
         for _ in range(n_cycles):
-            unused_atoms += engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group, buffers=buffers)
+            if approx:
+                unused_atoms += engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group, buffers=buffers)
+            else:  # ksvd.py:189-190: exact rank-1 update
+                unused_atoms += engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=buffers)
         # ---- replace unused atoms (host RNG, ksvd.py:199-207)
         for j in range(len(unused_atoms)):
             if len(unused_data) == 0:

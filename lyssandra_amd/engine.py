@@ -352,6 +352,35 @@ def ksvd_cycle(R, dd, idx, coef, nnz, group=None, buffers=None):
     return _d.ksvd_cycle_sharded(ops, dd.K, group)
 
 
+def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None):
+    """One cycle of the EXACT rank-1 K-SVD update (lyssa/dict_learning/ksvd.py:19-43), in place on R, coef, dd.D.
+
+    Per atom: Gram matrix of the restricted residual, its leading eigenvector (Lanczos + Rayleigh-Ritz in one
+    workgroup), coefficient / residual update (the reference: sklearn ``randomized_svd(n_iter=10)``, random sign).
+    Returns the unused atoms.  Single GPU.
+    """
+    torch = _torch()
+    lib = _lib.load()
+    k = int(idx.shape[1])
+    if buffers is None:
+        buffers = {}
+    row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
+    need = int(lib.lys_ksvd_exact_workspace_bytes(dd.n)) // 8
+    work = buffers.get("exact_work")
+    if work is None or work.numel() < need:
+        work = buffers["exact_work"] = torch.zeros((need,), dtype=torch.float64, device=dd.device)
+    Dnext = buffers.get("exact_Dnext")
+    if Dnext is None or Dnext.shape != dd.D.shape:
+        Dnext = buffers["exact_Dnext"] = torch.zeros_like(dd.D)
+    counts = row_ptr[1:] - row_ptr[:-1]
+    max_support = int(counts.max().item()) if counts.numel() else 0
+    _lib.check(lib.lys_ksvd_exact_sweep(_ptr(R), _ld(R), dd.n, dd.K, k, _ptr(row_ptr), _ptr(entry), _ptr(coef),
+                                        _ptr(work), work.numel() * 8, _ptr(dd.D), _ptr(Dnext), max_support,
+                                        _stream()), "lys_ksvd_exact_sweep")
+    dd.invalidate()
+    return torch.nonzero(counts == 0).flatten().cpu().numpy().tolist()
+
+
 # --------------------------------------------------------------------------------------------- online DL
 class OdlState(object):
     """Device-resident A (K x K) and B (n x K, stored atom-major) of online dictionary learning."""

@@ -299,6 +299,34 @@ def approx_ksvd(Y, D, X, n_cycles=1):
     return D, X, unused
 
 
+def ksvd_exact(Y, D, X, n_cycles=1):
+    """lyssa/dict_learning/ksvd.py:19-43 (`ksvd`).  Mutates D and X in place; returns (D, X, unused_atoms).
+
+    The reference takes U,S,V = randomized_svd(Rk, n_components=1, n_iter=10, flip_sign=False) :35 -- a randomized
+    range finder whose sign is arbitrary and whose accuracy depends on the spectrum.  The restatement uses the EXACT
+    leading singular triplet (numpy SVD), sign chosen so that u . d_old >= 0; parity with the reference is therefore
+    up to the sign of (d_k, x_k) and the randomized solver's accuracy (tests/test_oracle_golden.py, F10).
+    """
+    n_atoms = D.shape[1]
+    unused = []
+    R = Y - fast_dot(D, X)
+    for _ in range(n_cycles):
+        for k in range(n_atoms):
+            omega = X[k, :] != 0
+            if not np.any(omega):
+                unused.append(k)
+                continue
+            Rk = R[:, omega] + np.outer(D[:, k], X[k, omega])
+            U, S, Vt = np.linalg.svd(Rk, full_matrices=False)
+            u, sv = U[:, 0], S[0] * Vt[0, :]
+            if np.dot(u, D[:, k]) < 0:
+                u, sv = -u, -sv
+            D[:, k] = u
+            X[k, omega] = sv
+            R[:, omega] = Rk - np.outer(u, sv)
+    return D, X, unused
+
+
 def ksvd_dict_learn(X, n_atoms, init_dict='data', encode=None, max_iter=20, n_cycles=1, verbose=True,
                     trace=None):
     """lyssa/dict_learning/ksvd.py:129-231, approx=True, eta=None path.

@@ -16,6 +16,7 @@ Fixtures:
       hand-driven iterations + one full ksvd_dict_learn(max_iter=50) run (patience quirk, RNG use)
   F6  online DL, same data, batch 500, 1 and 2 epochs, beta=None and beta=0.9: D at every encode
       call, final D, A, B
+  F10 exact K-SVD (`ksvd`, randomized_svd seeded): F5's data (first 1200 signals), D / codes / error after 2 iterations
 """
 import contextlib
 import io
@@ -298,6 +299,30 @@ def main():
         out["feat_" + tag] = quiet(ex.encode, [img9], np.zeros((64, K9)))[:, 0]
     np.savez_compressed(os.path.join(OUT, "F9.npz"), **out)
     print("F9 feature length", out["feat_plain"].shape, "non-zero", int((out["feat_plain"] != 0).sum()))
+
+    # ---------------- F10: exact K-SVD (ksvd.py:19-43).  randomized_svd draws from the GLOBAL RNG and
+    # leaves the sign of (d_k, x_k) arbitrary: the fixture stores the reference's result for a seeded run; parity is
+    # checked up to sign and to the randomized solver's accuracy.
+    f5 = np.load(os.path.join(OUT, "F5.npz"))
+    X10, D10, k10 = f5["X"].astype(np.float64)[:, :1200], f5["D0"].astype(np.float64), int(f5["k"])
+    out = dict(n_signals=1200, k=k10)
+    D = D10.copy()
+    for it in range(2):
+        Z = ref_bomp(X10, D, k10)
+        i0, c0, z0 = dense_to_triplet(Z, k10)
+        np.random.seed(1000 + it)
+        D, Z, unused = quiet(ref_ksvd.ksvd, X10, D, Z, n_cycles=1, verbose=False)
+        i1, c1, z1 = dense_to_triplet(Z, k10)
+        assert np.array_equal(i0, i1)
+        out["it%d_D" % it] = D.copy()
+        out["it%d_idx" % it] = i1
+        out["it%d_coef_in" % it] = c0
+        out["it%d_coef" % it] = c1
+        out["it%d_nnz" % it] = z1
+        out["it%d_err" % it] = ref_approx_error(D, Z, X10, n_jobs=1)
+        out["it%d_unused" % it] = np.array(unused, dtype=np.int32)
+        print("F10 it", it, "err", out["it%d_err" % it], "unused", unused)
+    np.savez_compressed(os.path.join(OUT, "F10.npz"), **out)
 
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)

@@ -327,6 +327,71 @@ def test_approx_ksvd_golden(eng):
     assert _atom_err(D, g["cyc2_D"]) < 1e-5
 
 
+def test_exact_ksvd_golden(eng):
+    """ksvd.py:19-43 (exact rank-1 update) on F10: device power iteration vs the reference's randomized SVD run
+    (atoms up to sign) and vs the oracle's exact SVD (same sign convention: u . d_old >= 0)."""
+    from oracle import lyssa_oracle as orc
+    from lyssandra_amd.dict_learning.ksvd import ksvd, ksvd_dict_learn
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    g5, g = load_golden("F5"), load_golden("F10")
+    N, k = int(g["n_signals"]), int(g["k"])
+    X = g5["X"].astype(np.float64)[:, :N]
+    D = g5["D0"].astype(np.float64).copy()
+    K = D.shape[1]
+    for it in range(2):
+        Zin = orc.densify(g["it%d_idx" % it], g["it%d_coef_in" % it], g["it%d_nnz" % it], K)
+        Do, Zo, _ = orc.ksvd_exact(X, D.copy(), Zin.copy())
+        Dh, Zh = D.copy(), Zin.copy()
+        Dr, Zr, unused = ksvd(X, Dh, Zh, n_cycles=1, verbose=False)
+        assert Dr is Dh and Zr is Zh
+        assert np.array_equal(Zh != 0, Zo != 0)
+        assert _atom_err(Dh, Do) < 2e-5, (it, _atom_err(Dh, Do))
+        assert np.max(np.abs(Zh - Zo)) < 2e-5 * np.abs(Zo).max()
+        Dref = g["it%d_D" % it]
+        sgn = np.sign((Dh * Dref).sum(0))
+        assert _atom_err(Dh, Dref * sgn) < 2e-5
+        err = np.sum((X - Dh @ Zh) ** 2)
+        assert abs(err - float(g["it%d_err" % it])) < 1e-5 * float(g["it%d_err" % it]), (it, err)
+        assert list(unused) == list(g["it%d_unused" % it])
+        D = Dref.copy()
+    # the learner with approx=False drives the same update; the error must fall monotonically on this data
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    errs = []
+    Dl = g5["D0"].astype(np.float64)
+    for _ in range(3):
+        Dl, Zl = ksvd_dict_learn(X, K, init_dict=Dl, sparse_coder=se, max_iter=1, approx=False, verbose=False)
+        errs.append(np.sum((X - Dl @ Zl) ** 2))
+    assert errs[2] < errs[1] < errs[0]
+
+
+@pytest.mark.parametrize("n,K,k,N", [(200, 48, 4, 700), (100, 40, 3, 300), (16, 24, 2, 30)])
+def test_exact_ksvd_other_shapes(eng, n, K, k, N):
+    """exact K-SVD at n = 100/200 (2 and 4 feature blocks per lane), ragged n, tiny omega (rank-deficient Rk) and
+    an unused atom, against the oracle's exact SVD."""
+    from oracle import lyssa_oracle as orc
+    from lyssandra_amd.dict_learning.ksvd import ksvd
+    rs = np.random.RandomState(n + K)
+    Dt = rs.randn(n, K)
+    Dt /= np.linalg.norm(Dt, axis=0)
+    X = np.zeros((n, N))
+    for i in range(N):
+        sel = rs.choice(K - 1, k, replace=False)          # atom K-1 never used by the codes below
+        X[:, i] = Dt[:, sel] @ rs.randn(k)
+    X += 0.05 * rs.randn(n, N)
+    X = X.astype(np.float32).astype(np.float64)
+    D0 = (Dt + 0.3 * rs.randn(n, K))
+    D0 = (D0 / np.linalg.norm(D0, axis=0)).astype(np.float32).astype(np.float64)
+    Z = orc.bomp_encode(X, D0, k)
+    Z[K - 1, :] = 0
+    Do, Zo, uo = orc.ksvd_exact(X, D0.copy(), Z.copy())
+    Dh, Zh = D0.copy(), Z.copy()
+    _, _, uh = ksvd(X, Dh, Zh, verbose=False)
+    assert list(uh) == list(uo) and (K - 1) in uh
+    assert np.array_equal(Dh[:, K - 1], D0[:, K - 1])
+    assert _atom_err(Dh, Do) < 5e-5, _atom_err(Dh, Do)
+    assert np.max(np.abs(Zh - Zo)) < 5e-5 * np.abs(Zo).max()
+
+
 def test_ksvd_coder_dropin(eng):
     """ksvd_dict_learn host control flow: patience quirk (11 encode calls), global-RNG use, ndarray init_dict."""
     from lyssandra_amd.dict_learning.ksvd import ksvd_dict_learn, ksvd_coder

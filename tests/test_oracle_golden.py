@@ -82,6 +82,27 @@ def test_approx_ksvd_matches_reference():
     assert np.max(np.abs(D - g["cyc2_D"])) <= 1e-10
 
 
+def test_exact_ksvd_matches_reference():
+    """ksvd.py:19-43 on F10 (reference run with randomized_svd seeded): the oracle's exact SVD reproduces the
+    reference's atoms and codes up to the arbitrary sign of (d_k, x_k), and its error."""
+    g5, g = load_golden("F5"), load_golden("F10")
+    N, k = int(g["n_signals"]), int(g["k"])
+    X = g5["X"].astype(np.float64)[:, :N]
+    D = g5["D0"].astype(np.float64).copy()
+    K = D.shape[1]
+    for it in range(2):
+        Z = orc.densify(g["it%d_idx" % it], g["it%d_coef_in" % it], g["it%d_nnz" % it], K)
+        D1, Z1, unused = orc.ksvd_exact(X, D.copy(), Z.copy())
+        Dr = g["it%d_D" % it]
+        sgn = np.sign((D1 * Dr).sum(0))
+        assert np.max(np.abs(D1 - Dr * sgn)) <= 1e-6
+        Zr = orc.densify(g["it%d_idx" % it], g["it%d_coef" % it], g["it%d_nnz" % it], K)
+        assert np.max(np.abs(Z1 - Zr * sgn[:, None])) <= 1e-6
+        assert list(unused) == list(g["it%d_unused" % it])
+        assert abs(orc.approx_error(D1, Z1, X) - float(g["it%d_err" % it])) <= 1e-8 * float(g["it%d_err" % it])
+        D = Dr.copy()
+
+
 @pytest.mark.parametrize("verbose", [True, False])
 def test_ksvd_driver_matches_reference(verbose):
     """Host control flow: patience quirk (11 encode calls for max_iter=50) and global-RNG consumption."""

@@ -9,6 +9,7 @@ from lyssandra_amd import engine
 n, K, k = 64, 1024, 10
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+exact = len(sys.argv) > 3 and sys.argv[3] == "exact"   # exact rank-1 update (ksvd.py:19-43) instead of the approximate one
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(3)
 Xs = torch.randn((N, n), device=dev, generator=g)
@@ -29,7 +30,8 @@ for it in range(iters):
     out, t_enc = timed(lambda: engine.bomp_encode(Xs, dd, k, out=out))
     idx, coef, nnz = out
     (R, _), t_res = timed(lambda: engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False, out=R))
-    unused, t_sweep = timed(lambda: engine.ksvd_cycle(R, dd, idx, coef, nnz, buffers=buffers))
+    cycle = engine.ksvd_exact_cycle if exact else engine.ksvd_cycle
+    unused, t_sweep = timed(lambda: cycle(R, dd, idx, coef, nnz, buffers=buffers))
     err, t_err = timed(lambda: engine.approx_error(Xs, dd, idx, coef, nnz))
     nnz_tot = int(nnz.sum().item())
     gbs = 3 * 4 * n * nnz_tot / (t_sweep * 1e-3) / 1e9
