@@ -93,6 +93,19 @@ int lys_bomp_from_alpha0(const float* alpha0, const float* G, int K, int k, int6
 
 /* ---- residual / error -------------------------------------------------------------------------- */
 /*
+ * l1-penalised coding, lyssa/sparse_coding.py:487-509 + :697-698 (`lasso`: spams.lasso(X, D, lambda1=lambda, lambda2=0,
+ * mode=2), i.e. min_a 0.5||x - D a||^2 + lambda ||a||_1 per signal; SPAMS -- not vendored -- solves it by LARS).
+ * Here: greedy coordinate descent on c = D'x - G a (one Gram row per step), stopped when the largest coordinate
+ * change is <= tol * max|D'x| or after max_steps steps.  Output like the other encoders: idx/coef [N][kcap]
+ * (unused slots -1/0, unordered), nnz[N]; steps[N] (optional) = steps taken, negative when more than kcap
+ * coefficients were non-zero (only the first kcap are returned).  G = true Gram matrix (its diagonal is used).
+ */
+size_t lys_lasso_workspace_bytes(int n, int K, int64_t N);
+int lys_lasso_encode(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K,
+                     float lambda, int kcap, int max_steps, float tol, int64_t N,
+                     int32_t* idx, float* coef, int32_t* nnz, int32_t* steps,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/*
  * R = X - D Z (signal-major [N][ldr]) and err = ||X - D Z||_F^2 accumulated in fp64 into *err_dev
  * (which the caller zeroes).  Replaces `R = Y - fast_dot(D, X)` lyssa/dict_learning/ksvd.py:103 and
  * `approx_error` lyssa/dict_learning/utils.py:14-19.  R may be NULL (error only); err_dev may be NULL.

@@ -1051,7 +1051,7 @@ int ksvd_sweep_fused(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     const int32_t* rp_host = nullptr;
     if (byval) {
         if (host_cap < K + 1) {
-            if (host_rp) hipHostFree(host_rp);
+            if (host_rp) (void)hipHostFree(host_rp);
             LYS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&host_rp), (size_t)(K + 1) * sizeof(int32_t), 0));
             host_cap = K + 1;
         }
@@ -1098,7 +1098,7 @@ int ksvd_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_pt
     const SweepGraphKey key{R, (void*)row_ptr, (void*)entry, coef, sbuf, D, Dnext, ldr, n, K, k};
     if (!(c.valid && c.key == key)) {
         if (c.exec) {
-            hipGraphExecDestroy(c.exec);
+            (void)hipGraphExecDestroy(c.exec);
             c.exec = nullptr;
         }
         c.valid = false;
@@ -1107,12 +1107,12 @@ int ksvd_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_pt
         const int rc = ksvd_sweep_eager(R, ldr, n, K, k, row_ptr, entry, coef, sbuf, D, Dnext, c.stream);
         const hipError_t e2 = hipStreamEndCapture(c.stream, &graph);
         if (rc) {
-            if (graph) hipGraphDestroy(graph);
+            if (graph) (void)hipGraphDestroy(graph);
             return rc;
         }
         LYS_CHECK_HIP(e2);
         const hipError_t e3 = hipGraphInstantiate(&c.exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
+        (void)hipGraphDestroy(graph);
         LYS_CHECK_HIP(e3);
         c.key = key;
         c.valid = true;

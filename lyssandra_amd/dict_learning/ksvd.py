@@ -15,7 +15,7 @@ from ..utils.math import normalize
 
 
 def _is_device_coder(sc):
-    return isinstance(sc, sparse_encoder) and sc.algorithm in ('bomp', 'omp', 'thresh')
+    return isinstance(sc, sparse_encoder) and sc.algorithm in ('bomp', 'omp', 'thresh', 'lasso')
 
 
 def approx_ksvd(Y, D, X, n_cycles=1, verbose=True):

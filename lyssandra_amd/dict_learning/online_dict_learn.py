@@ -12,7 +12,7 @@ from ..utils import gen_batches
 
 
 def _is_device_coder(sc):
-    return isinstance(sc, sparse_encoder) and sc.algorithm in ('bomp', 'omp', 'thresh')
+    return isinstance(sc, sparse_encoder) and sc.algorithm in ('bomp', 'omp', 'thresh', 'lasso')
 
 
 def online_dict_learn(X, n_atoms, sparse_coder=None, batch_size=None, A=None, B=None, D_init=None,

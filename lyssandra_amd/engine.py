@@ -174,6 +174,38 @@ def bomp_encode(Xs, dd, k, out=None, algorithm='bomp'):
     return idx, coef, nnz
 
 
+def lasso_encode(Xs, dd, lam, kcap=None, max_steps=None, tol=1e-6, out=None, return_steps=False):
+    """min_a 0.5||x - D a||^2 + lam ||a||_1 for every row of ``Xs`` (sparse_coding.py:487-509, spams.lasso mode 2).
+
+    Greedy coordinate descent on the Gram matrix in liblyssa_hip.so.  Returns the triplet (idx, coef, nnz) with
+    ``kcap`` slots per signal (default min(n, K): a lasso minimiser has at most that many non-zeros), entries
+    unordered.  ``return_steps`` adds the per-signal step counts (negative: support truncated to kcap,
+    == max_steps: not converged to ``tol * max|D'x|``)."""
+    torch = _torch()
+    lib = _lib.load()
+    N = int(Xs.shape[0])
+    kcap = int(kcap) if kcap is not None else min(dd.n, dd.K)
+    max_steps = int(max_steps) if max_steps is not None else 50 * kcap
+    assert Xs.dtype == torch.float32
+    if N > 0 and Xs.shape[1] > 1 and Xs.stride(1) != 1:
+        Xs = Xs.contiguous()
+    if out is None:
+        idx = torch.empty((N, kcap), dtype=torch.int32, device=dd.device)
+        coef = torch.empty((N, kcap), dtype=torch.float32, device=dd.device)
+        nnz = torch.empty((N,), dtype=torch.int32, device=dd.device)
+    else:
+        idx, coef, nnz = out
+    steps = torch.zeros((N,), dtype=torch.int32, device=dd.device)
+    if N > 0:
+        ws = _workspace(lib.lys_lasso_workspace_bytes(dd.n, dd.K, N), dd.device, "bomp")
+        _lib.check(lib.lys_lasso_encode(_ptr(Xs), _ld(Xs), _ptr(dd.D), _ptr(dd.gram()), dd.n, dd.K, float(lam), kcap,
+                                        max_steps, float(tol), N, _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(steps),
+                                        _ptr(ws), ws.numel(), _stream()), "lys_lasso_encode")
+    if return_steps:
+        return idx, coef, nnz, steps
+    return idx, coef, nnz
+
+
 def densify(idx, coef, nnz, K, out=None):
     """Sparse triplet -> dense float64 (K, N) host array (the reference's return type, sparse_coding.py:365)."""
     torch = _torch()

@@ -8,7 +8,8 @@ Same constructor, attributes and call contract as the reference class:
 
 ``'bomp'`` runs entirely in liblyssa_hip.so (fp32 MFMA GEMMs for G = D'D and alpha0 = D'X, wave-per-signal
 greedy/Cholesky kernel); ``'omp'`` (fixed ``n_nonzero_coefs``) and ``'thresh'`` ride on the same engine (SURVEY 8f
-rank 1).  There is NO CPU fallback: without the library or without a GPU the call raises.
+rank 1), and so does ``'lasso'`` (``params['lambda']``; Gram-based coordinate descent instead of SPAMS' LARS, same
+minimiser -- SURVEY 8f rank 4).  There is NO CPU fallback: without the library or without a GPU the call raises.
 Unknown algorithms raise ``ValueError("Sparse optimizer not found.")`` exactly like sparse_coding.py:705-706;
 the reference's other algorithms are outside the accelerated path and raise NotImplementedError.
 
@@ -69,12 +70,24 @@ class sparse_encoder(object):
         self._check_algorithm()
         Xs = engine.signals_to_device(X, self.device)
         dd = self._dictionary(D)
-        return engine.bomp_encode(Xs, dd, self._k(dd.K), algorithm=self.algorithm)
+        return self.encode_device(Xs, dd)
 
     def encode_device(self, Xs, dd, out=None):
         """Device-resident form: ``Xs`` signal-major fp32 cuda tensor [N, n], ``dd`` an engine.DeviceDictionary;
         ``out`` = a previously returned triplet to overwrite (stable buffers for iterative learners)."""
         self._check_algorithm()
+        if self.algorithm == 'lasso':
+            # sparse_coding.py:697-698: lasso(params['lambda'], n_jobs)(X, D); extra knobs: kcap / max_steps / tol
+            lam = self.params.get('lambda')
+            if lam is None:
+                raise ValueError("params['lambda'] is required for algorithm='lasso'")
+            idx, coef, nnz, steps = engine.lasso_encode(Xs, dd, lam, kcap=self.params.get('kcap'),
+                                                        max_steps=self.params.get('max_steps'),
+                                                        tol=self.params.get('tol', 1e-6), out=out, return_steps=True)
+            if int(steps.min().item()) < 0 if steps.numel() else False:
+                raise RuntimeError("lasso: more than kcap=%d non-zero coefficients for some signal; raise "
+                                   "params['kcap'] or lambda" % idx.shape[1])
+            return idx, coef, nnz
         return engine.bomp_encode(Xs, dd, self._k(dd.K), out=out, algorithm=self.algorithm)
 
     # -- helpers ---------------------------------------------------------------------------------------
@@ -91,11 +104,11 @@ class sparse_encoder(object):
         return int(k)
 
     def _check_algorithm(self):
-        if self.algorithm in ('bomp', 'omp', 'thresh'):
+        if self.algorithm in ('bomp', 'omp', 'thresh', 'lasso'):
             return
         if self.algorithm in _REFERENCE_ALGORITHMS:
             raise NotImplementedError(
-                "algorithm=%r is outside the MI355X-accelerated path ('bomp', 'omp', 'thresh' are implemented; "
+                "algorithm=%r is outside the MI355X-accelerated path ('bomp', 'omp', 'thresh', 'lasso' are implemented; "
                 "there is deliberately no CPU fallback in this package)" % (self.algorithm,))
         raise ValueError("Sparse optimizer not found.")  # sparse_coding.py:705-706
 

@@ -238,6 +238,50 @@ def thresh_encode(X, D, n_nonzero_coefs=None, nonzero_percentage=None):
 
 
 # --------------------------------------------------------------------------- dictionary helpers
+def lasso_signal(a0, G, lam, tol=1e-13, max_steps=100000):
+    """argmin_a 0.5||x - D a||^2 + lam ||a||_1 given a0 = D'x and G = D'D: greedy coordinate descent, float64.
+
+    The reference delegates to spams.lasso(mode=2, lambda2=0) (sparse_coding.py:487-509); SPAMS is absent, so this
+    restates the PROBLEM, not SPAMS' LARS code ("lasso parity unpinned") -- it is pinned against sklearn's
+    independent solvers and the KKT conditions in tests/test_oracle_golden.py."""
+    K = a0.shape[0]
+    a = np.zeros(K)
+    c = a0.astype(np.float64).copy()
+    gd = np.diag(G).astype(np.float64)
+    ginv = np.where(gd > 0, 1.0 / np.where(gd > 0, gd, 1.0), 0.0)
+    scale = np.max(np.abs(a0)) if K else 0.0
+    for _ in range(max_steps):
+        v = c + gd * a
+        s = np.sign(v) * np.maximum(np.abs(v) - lam, 0.0) * ginv
+        d = s - a
+        j = int(np.argmax(np.abs(d)))
+        if not (abs(d[j]) > tol * scale):
+            break
+        a[j] += d[j]
+        c -= d[j] * G[:, j]
+    return a
+
+
+def lasso_encode(X, D, lam, tol=1e-13):
+    """Dense (K, N) lasso codes, one column per signal (sparse_coding.py:697-698)."""
+    G = fast_dot(D.T, D)
+    A0 = fast_dot(D.T, X)
+    Z = np.zeros((D.shape[1], X.shape[1]))
+    for i in range(X.shape[1]):
+        Z[:, i] = lasso_signal(A0[:, i], G, lam, tol=tol)
+    return Z
+
+
+def lasso_kkt_violation(X, D, Z, lam):
+    """max over signals/atoms of the KKT residual of min 0.5||x-Da||^2 + lam||a||_1, relative to max|D'x|:
+    |d_j'(x - D a)| <= lam where a_j = 0, and d_j'(x - D a) = lam sign(a_j) where a_j != 0."""
+    C = fast_dot(D.T, X - fast_dot(D, Z))
+    scale = np.maximum(np.max(np.abs(fast_dot(D.T, X)), axis=0), 1e-300)
+    zero = Z == 0
+    v = np.where(zero, np.maximum(np.abs(C) - lam, 0.0), np.abs(C - lam * np.sign(Z)))
+    return float(np.max(v / scale[None, :]))
+
+
 def approx_error(D, Z, X):
     """lyssa/dict_learning/utils.py:14-19 -- ||X - DZ||_F^2."""
     return frobenius_squared(X - fast_dot(D, Z))

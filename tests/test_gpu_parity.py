@@ -392,6 +392,71 @@ def test_exact_ksvd_other_shapes(eng, n, K, k, N):
     assert np.max(np.abs(Zh - Zo)) < 5e-5 * np.abs(Zo).max()
 
 
+def _lasso_problem(seed, n, K, N, active=6, noise=0.05):
+    rs = np.random.RandomState(seed)
+    D = rs.randn(n, K)
+    D /= np.linalg.norm(D, axis=0)
+    X = np.zeros((n, N))
+    for i in range(N):
+        sel = rs.choice(K, active, replace=False)
+        X[:, i] = D[:, sel] @ rs.randn(active)
+    X += noise * rs.randn(n, N)
+    X /= np.linalg.norm(X, axis=0)
+    return (D.astype(np.float32).astype(np.float64), X.astype(np.float32).astype(np.float64))
+
+
+@pytest.mark.parametrize("n,K,N,lam", [(64, 256, 300, 0.15), (64, 1024, 200, 0.2), (128, 2048, 64, 0.15),
+                                       (20, 40, 50, 0.1), (100, 6000, 16, 0.2)])
+def test_lasso_matches_oracle_and_kkt(eng, n, K, N, lam):
+    """'lasso' (sparse_coding.py:487-509, spams.lasso mode 2): device coordinate descent vs the float64 oracle, and the
+    KKT conditions of min 0.5||x-Da||^2 + lam||a||_1 evaluated in float64 on the returned codes."""
+    from oracle import lyssa_oracle as orc
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    D, X = _lasso_problem(n + K, n, K, N)
+    se = sparse_encoder(algorithm='lasso', params={'lambda': lam}, verbose=False)
+    Z = se.encode(X, D)
+    assert Z.shape == (K, N) and Z.dtype == np.float64
+    Zo = orc.lasso_encode(X, D, lam)
+    scale = np.abs(Zo).max()
+    # the stopping rule bounds the KKT residual (1e-6 of max|D'x|); the distance to the minimiser is that times the
+    # conditioning of the active Gram block, hence the looser coefficient tolerance
+    assert np.max(np.abs(Z - Zo)) < 1e-4 * scale, np.max(np.abs(Z - Zo)) / scale
+    big = np.abs(Zo) > 1e-3 * scale
+    assert np.array_equal((Z != 0) & big, big)                # every significant oracle coefficient is present
+    assert orc.lasso_kkt_violation(X, D, Z, lam) < 1e-5
+    # step counts: converged well inside the default budget; lam >= max|D'x| gives the zero code in 0 steps
+    Xs = eng.signals_to_device(X)
+    dd = eng.DeviceDictionary.from_host(D)
+    idx, coef, nnz, steps = eng.lasso_encode(Xs, dd, lam, return_steps=True)
+    st = steps.cpu().numpy()
+    assert st.min() >= 0 and st.max() < 50 * min(n, K)
+    assert np.array_equal(nnz.cpu().numpy(), (Z != 0).sum(0))
+    idx, coef, nnz, steps = eng.lasso_encode(Xs, dd, 1.5, return_steps=True)
+    assert int(nnz.sum().item()) == 0 and int(steps.abs().sum().item()) == 0 and bool((idx == -1).all())
+    # a too small kcap is reported, not silently truncated
+    idx, coef, nnz, steps = eng.lasso_encode(Xs, dd, lam, kcap=1, return_steps=True)
+    assert int(steps.min().item()) < 0 and int(nnz.max().item()) == 1
+
+
+def test_online_dict_learn_with_lasso_coder(eng):
+    """config-4 style: online DL driven by the l1 coder (device path end to end); the objective falls."""
+    from lyssandra_amd.dict_learning import online_dictionary_coder
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    D, X = _lasso_problem(5, 32, 64, 1500, active=4)
+    lam = 0.15
+    se = sparse_encoder(algorithm='lasso', params={'lambda': lam}, verbose=False)
+    D0 = _lasso_problem(6, 32, 64, 1)[0]
+
+    def objective(Dm):
+        Z = se.encode(X, Dm)
+        return 0.5 * np.sum((X - Dm @ Z) ** 2) + lam * np.abs(Z).sum()
+
+    oc = online_dictionary_coder(n_atoms=64, sparse_coder=se, batch_size=250, D_init=D0.copy(), n_epochs=2)
+    oc.fit(X)
+    assert np.allclose(np.linalg.norm(oc.D, axis=0), 1.0, atol=1e-5)
+    assert objective(oc.D) < 0.9 * objective(D0)
+
+
 def test_ksvd_coder_dropin(eng):
     """ksvd_dict_learn host control flow: patience quirk (11 encode calls), global-RNG use, ndarray init_dict."""
     from lyssandra_amd.dict_learning.ksvd import ksvd_dict_learn, ksvd_coder

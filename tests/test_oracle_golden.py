@@ -82,6 +82,30 @@ def test_approx_ksvd_matches_reference():
     assert np.max(np.abs(D - g["cyc2_D"])) <= 1e-10
 
 
+def test_lasso_oracle_against_independent_solvers():
+    """'lasso' (sparse_coding.py:487-509) delegates to SPAMS, which is not available: the oracle restates the problem
+    min 0.5||x-Da||^2 + lam||a||_1 and is pinned here against sklearn's coordinate-descent Lasso, sklearn's LARS path
+    (SPAMS' own algorithm family) and the KKT conditions."""
+    from sklearn.linear_model import Lasso, lars_path
+    rs = np.random.RandomState(7)
+    n, K, N = 32, 96, 12
+    D = rs.randn(n, K)
+    D /= np.linalg.norm(D, axis=0)
+    X = rs.randn(n, N)
+    X /= np.linalg.norm(X, axis=0)
+    for lam in (0.4, 0.25):
+        Z = orc.lasso_encode(X, D, lam)
+        assert orc.lasso_kkt_violation(X, D, Z, lam) < 1e-10
+        assert 0 < (Z != 0).sum(0).max() < n
+        m = Lasso(alpha=lam / n, fit_intercept=False, tol=1e-14, max_iter=100000)
+        for i in range(N):
+            m.fit(D, X[:, i])
+            assert np.max(np.abs(m.coef_ - Z[:, i])) < 1e-8
+            _, _, coefs = lars_path(D, X[:, i], method='lasso', alpha_min=lam / n)
+            assert np.max(np.abs(coefs[:, -1] - Z[:, i])) < 1e-8
+    assert np.all(orc.lasso_encode(X, D, 1.0) == 0)          # lam >= max|D'x|: the zero code
+
+
 def test_exact_ksvd_matches_reference():
     """ksvd.py:19-43 on F10 (reference run with randomized_svd seeded): the oracle's exact SVD reproduces the
     reference's atoms and codes up to the arbitrary sign of (d_k, x_k), and its error."""
