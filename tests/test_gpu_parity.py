@@ -241,7 +241,9 @@ def test_sparse_encoder_dropin(eng):
     with pytest.raises(Exception):
         sparse_encoder(algorithm='se', params={'n_nonzero_coefs': 4}).encode(X, D)
     with pytest.raises(NotImplementedError):
-        sparse_encoder(algorithm='lasso', params={'lambda': 1}).encode(X, D)
+        sparse_encoder(algorithm='llc', params={'knn': 5}).encode(X, D)
+    with pytest.raises(ValueError):
+        sparse_encoder(algorithm='lasso', params={}).encode(X, D)      # 'lambda' is required
     Xr = np.random.RandomState(0).rand(10, 100)
     Dr = np.random.RandomState(1).rand(10, 4)
     Zr = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 4}).encode(Xr, Dr)
