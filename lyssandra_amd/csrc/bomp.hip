@@ -76,13 +76,50 @@ __device__ __forceinline__ void extract_case(const float (&p)[(KMAX - 1 - NLDS) 
     }
 }
 
+// registers 4c..4c+3 of lane Lo, c only known at run time (wave-uniform): static if-chain like extract_case
+template <int R, int C>
+__device__ __forceinline__ void argmax_group_case(const float (&a)[R], int csel, int Lo, unsigned mbits, int& rsel,
+                                                  unsigned& vsel) {
+    if constexpr (4 * C < R) {
+        if (csel == C) {
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                const unsigned sv = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, a[4 * C + q]), Lo);
+                const bool hit = (sv & 0x7fffffffu) == mbits;
+                rsel = hit ? 4 * C + q : rsel;
+                vsel = hit ? sv : vsel;
+            }
+        } else {
+            argmax_group_case<R, C + 1>(a, csel, Lo, mbits, rsel, vsel);
+        }
+    }
+}
+
 template <int R>
 __device__ __forceinline__ bool wave_argmax(const float (&a)[R], int lane, int& kk, float& akk, int& Lown, int& rown,
                                             float& mabs) {
     using L = Lay<R>;
-    float best = fabsf(a[0]);
+    constexpr bool GROUPED = (R >= 8) && (R % 4 == 0);  // resolve the owner's register in two rounds of 4 readlanes
+    constexpr int NG = GROUPED ? R / 4 : 1;
+    float m4[NG];
+    float best;
+    if constexpr (GROUPED) {
+        // max |.| of each 4-register group: v_max3_f32 + v_max_f32 with |.| source modifiers (written as asm: the
+        // compiler canonicalises every fabsf() operand of fmaxf with an extra v_max |x|,|x|)
 #pragma unroll
-    for (int r = 1; r < R; ++r) best = fmaxf(best, fabsf(a[r]));
+        for (int c = 0; c < NG; ++c) {
+            float t3;
+            asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t3) : "v"(a[4 * c]), "v"(a[4 * c + 1]), "v"(a[4 * c + 2]));
+            asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(m4[c]) : "v"(t3), "v"(a[4 * c + 3]));
+        }
+        best = m4[0];
+#pragma unroll
+        for (int c = 1; c < NG; ++c) best = fmaxf(best, m4[c]);
+    } else {
+        best = fabsf(a[0]);
+#pragma unroll
+        for (int r = 1; r < R; ++r) best = fmaxf(best, fabsf(a[r]));
+    }
     const float m = wave_max_f(best);
     mabs = m;
     const unsigned long long bal = __ballot(best == m);
@@ -93,12 +130,22 @@ __device__ __forceinline__ bool wave_argmax(const float (&a)[R], int lane, int& 
         const int Lo = __builtin_ctzll(bal);
         int rsel = 0;
         unsigned vsel = 0;
+        if constexpr (GROUPED) {
+            int csel = 0;
 #pragma unroll
-        for (int r = R - 1; r >= 0; --r) {
-            const unsigned sv = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, a[r]), Lo);
-            const bool hit = (sv & 0x7fffffffu) == mbits;
-            rsel = hit ? r : rsel;
-            vsel = hit ? sv : vsel;
+            for (int c = NG - 1; c >= 0; --c) {
+                const unsigned sv = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, m4[c]), Lo);
+                csel = (sv == mbits) ? c : csel;  // first (lowest) group that holds the maximum
+            }
+            argmax_group_case<R, 0>(a, csel, Lo, mbits, rsel, vsel);
+        } else {
+#pragma unroll
+            for (int r = R - 1; r >= 0; --r) {
+                const unsigned sv = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, a[r]), Lo);
+                const bool hit = (sv & 0x7fffffffu) == mbits;
+                rsel = hit ? r : rsel;
+                vsel = hit ? sv : vsel;
+            }
         }
         Lown = Lo;
         rown = rsel;
@@ -172,6 +219,11 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
         const bool more = (J + 1 < KMAX) && (J + 1 < k);
         // Gram row of the new atom (G is symmetric: row kk == column kk), issued before the scalar work
         float g[R];
+        if (!more) {
+            // g is never read on this path: give the registers a "definition" so that the compiler does not zero them
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "=v"(g[r]));
+        }
         if (more)
             load_row<R>(G + (int64_t)(VAR == 1 ? (kk & 7) : VAR == 4 ? (kk & 255) : VAR == 5 ? (kk & 63)
                                       : VAR == 6 ? (kk % 768) : VAR == 7 ? (kk & 511) : VAR == 8 ? (kk % 896) : kk) * L::Kp,
@@ -254,7 +306,7 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
         }
         float lr = 0.f;
 #pragma unroll
-        for (int i = 0; i < J; ++i) lr = writelane_f(w[i], i, lr, lane);
+        for (int i = 0; i < J; ++i) lr = writelane_sgpr(lr, w[i], i);  // w[i] came from readlane: already scalar
         s.Lrow[J] = lr;
         s.tv = writelane_f(t, J, s.tv, lane);
         s.rinv = writelane_f(inv, J, s.rinv, lane);

@@ -108,6 +108,14 @@ __device__ __forceinline__ float readlane_f(float x, int lane) {
 }
 // vec with lane `lane` replaced by the (wave-uniform) value `val`; needs the caller's lane id.
 // (clang has no writelane builtin; a compare+select is one v_cndmask once `my_lane == lane` is hoisted.)
+// vec[lane] = val for a wave-uniform val that already lives in an SGPR (a readlane / readfirstlane result) and a
+// compile-time-constant lane: one v_writelane_b32 (clang has no builtin for it) instead of compare + select
+__device__ __forceinline__ float writelane_sgpr(float vec, float val_sgpr, int lane_const) {
+    const int sv = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, val_sgpr));  // folds away when already scalar
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(sv), "i"(lane_const));
+    return vec;
+}
+
 __device__ __forceinline__ float writelane_f(float val, int lane, float vec, int my_lane) {
     return (my_lane == lane) ? val : vec;
 }
