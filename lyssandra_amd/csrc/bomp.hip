@@ -97,9 +97,13 @@ __device__ __forceinline__ bool wave_argmax(const float (&a)[R], int lane, int& 
             asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t3) : "v"(a[4 * c]), "v"(a[4 * c + 1]), "v"(a[4 * c + 2]));
             asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(m4[c]) : "v"(t3), "v"(a[4 * c + 3]));
         }
-        best = m4[0];
+        if constexpr (NG == 4) {
+            best = fmaxf(fmaxf(fmaxf(m4[0], m4[1]), m4[2]), m4[3]);  // v_max3 + v_max (operands are already canonical)
+        } else {
+            best = m4[0];
 #pragma unroll
-        for (int c = 1; c < NG; ++c) best = fmaxf(best, m4[c]);
+            for (int c = 1; c < NG; ++c) best = fmaxf(best, m4[c]);
+        }
     } else {
         best = fabsf(a[0]);
 #pragma unroll
@@ -246,8 +250,9 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
         if constexpr (VAR == 3) {
             inv = 1.f / sqrtf(vs);
         } else {
+            // hardware rsq: 1 ulp, i.e. the rounding level of every other fp32 operation of the step (a Newton step
+            // on top was measured to change no support and no coefficient beyond 2e-7; it cost 4 VALU ops per step)
             inv = __builtin_amdgcn_rsqf(vs);
-            inv = inv * fmaf(-0.5f * vs, inv * inv, 1.5f);
         }
         const float t = akk * inv;
 
