@@ -61,6 +61,22 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, int lane
     }
 }
 
+// Uniform extraction  w[i] = p[i][rr](lane L)  for NLDS <= i < J, with rr only known at run time (wave-uniform), as
+// an if-chain over rr: every register index static, one v_readlane per vector.  Used for k > 10 (many vectors per
+// step); for k <= 10 the VGPR index mode (below) is faster.
+template <int R, int KMAX, int NLDS, int J, int RR, class PV>
+__device__ __forceinline__ void extract_case(const PV (&p)[(KMAX - 1 - NLDS) > 0 ? (KMAX - 1 - NLDS) : 1], int rr, int L,
+                                             float (&w)[KMAX]) {
+    if constexpr (RR < R) {
+        if (rr == RR) {
+#pragma unroll
+            for (int i = NLDS; i < J; ++i) w[i] = readlane_f(p[i - NLDS][RR], L);
+        } else {
+            extract_case<R, KMAX, NLDS, J, RR + 1, PV>(p, rr, L, w);
+        }
+    }
+}
+
 // registers 4c..4c+3 of lane Lo, c only known at run time (wave-uniform): static if-chain keeps every register index static
 template <int R, int C>
 __device__ __forceinline__ void argmax_group_case(const float (&a)[R], int csel, int Lo, unsigned mbits, int& rsel,
@@ -232,11 +248,15 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
             }
         }
         if constexpr (J > NLDS) {
-            // w[i] = p_i[rown](lane Lown): indexed v_mov + v_readlane per vector, no branch tree (measured 0.970 ->
-            // 0.945 ms against the static if-chain; the same trick on the argmax's second round did not pay)
-            const int rr = __builtin_amdgcn_readfirstlane(rown);
+            if constexpr (KMAX <= 10) {
+                // w[i] = p_i[rown](lane Lown): indexed v_mov + v_readlane per vector, no branch tree (0.970 -> 0.945 ms
+                // at K=1024, k=10 against the static if-chain; at k=20 the if-chain wins: one VALU op per vector)
+                const int rr = __builtin_amdgcn_readfirstlane(rown);
 #pragma unroll
-            for (int i = NLDS; i < J; ++i) w[i] = readlane_f(s.p[i - NLDS][rr], Lown);
+                for (int i = NLDS; i < J; ++i) w[i] = readlane_f(s.p[i - NLDS][rr], Lown);
+            } else {
+                extract_case<R, KMAX, NLDS, J, 0>(s.p, rown, Lown, w);
+            }
         }
         // Cholesky pivot: batch_omp hard-codes a unit Gram diagonal (:333-349); 'omp' (`_omp`, :44-52) inverts the
         // true G[Dx,Dx], i.e. uses G[kk][kk] (wave-uniform scalar load, only taken on the 'omp' path)
