@@ -24,7 +24,7 @@ _lib.check(lib.lys_alpha0(P(Xs), Xs.stride(0), P(dd.D), n, K, N, P(a0), st))
 idx = torch.empty((N, k), dtype=torch.int32, device=dev)
 coef = torch.empty((N, k), dtype=torch.float32, device=dev)
 nnz = torch.empty((N,), dtype=torch.int32, device=dev)
-configs = [("v0 regs-only 2w/SIMD", 0, 0, 10), ("v4 NLDS=3 3w/SIMD", 4, 0, 10), ("v15 NLDS=3 alpha0 rows L2-hot (64 rows)", 15, 0, 10), ("v5 NLDS=2 3w/SIMD", 5, 0, 10),
+configs = [("v0 regs-only 2w/SIMD", 0, 0, 10), ("v4 NLDS=3 3w/SIMD", 4, 0, 10), ("v15 NLDS=3 alpha0 rows L2-hot (64 rows)", 15, 0, 10), ("v5 NLDS=2 3w/SIMD (product)", 5, 0, 10),
            ("v6 NLDS=3 hot G (8 rows)", 6, 0, 10), ("v8 NLDS=3 G rows & 255 (1MB)", 8, 0, 10),
            ("v9 NLDS=3 G rows & 63 (256KB)", 9, 0, 10), ("v11 G rows & 511 (2MB)", 11, 0, 10),
            ("v10 G rows % 768 (3MB)", 10, 0, 10), ("v12 G rows % 896 (3.5MB)", 12, 0, 10), ("v1 hot G rows", 1, 0, 10), ("v2 no orth FMAs", 2, 0, 10),
@@ -43,9 +43,9 @@ for name, *_ in configs:
     t = sorted(times[name])
     med = t[len(t) // 2]
     print("%-34s median %.4f ms  min %.4f ms  -> %.1f M sig/s" % (name, med, t[0], N / med / 1e3))
-# v4 must reproduce v0 bit for bit
+# v4 / v5 must reproduce v0 bit for bit
 outs = []
-for var in (0, 4):
+for var in (0, 4, 5):
     _lib.check(lib.lys_debug_bomp_variant(P(a0), P(G), N, 10, P(idx), P(coef), P(nnz), var, 0, st))
     torch.cuda.synchronize()
     outs.append((idx.clone(), coef.clone(), nnz.clone()))
