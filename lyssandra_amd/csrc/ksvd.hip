@@ -806,12 +806,22 @@ __global__ __launch_bounds__(256) void ksvd_gram_kernel(int atom, const float* _
 
 constexpr int EIG_M = 32;  // Lanczos steps (Krylov dimension)
 
-__device__ __forceinline__ double block_sum_d(double x, double* red /* [4] in LDS */) {
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+// sum over the 256 threads of the workgroup through LDS (two levels of 16; no cross-lane fp64 shuffles)
+__device__ __forceinline__ double block_sum_d(double x, double* pr /* [256] */, double* red /* [16] */) {
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    pr[threadIdx.x] = x;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x < 16) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += pr[threadIdx.x * 16 + q];
+        red[threadIdx.x] = t;
+    }
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q];
+    return tot;
 }
 
 // One workgroup (256 threads).  Dynamic LDS: Q[(EIG_M + 1) * n] doubles.
@@ -820,14 +830,14 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
                                                        int ldd, float* __restrict__ Dnext) {
     extern __shared__ __attribute__((aligned(16))) double Q[];  // [EIG_M + 1][n]
     __shared__ double H[EIG_M][EIG_M], T[EIG_M][EIG_M];
-    __shared__ double hh[EIG_M + 1], red[4], wv[256], cvec[EIG_M];
+    __shared__ double hh[EIG_M + 1], red[16], wv[256], pr[256], cvec[EIG_M];
     __shared__ int m_used;
     if (row_ptr[atom] >= row_ptr[atom + 1]) return;
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     // n <= 256: thread tid owns component tid of every n-vector
     const double d0 = (tid < n) ? (double)D[(int64_t)atom * ldd + tid] : 0.0;
     for (int i = tid; i < EIG_M * EIG_M; i += 256) (&H[0][0])[i] = 0.0;
-    double nrm2 = block_sum_d(d0 * d0, red);
+    double nrm2 = block_sum_d(d0 * d0, pr, red);
     {
         double q0 = (nrm2 > 0.0) ? d0 / sqrt(nrm2) : (tid == 0 ? 1.0 : 0.0);
         if (tid < n) Q[tid] = q0;
@@ -837,32 +847,59 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
     double scale0 = 0.0;
     int m = 0;
     for (int j = 0; j < EIG_M; ++j) {
-        // w = C q_j (C symmetric: column access is coalesced)
+        // w = C q_j (C symmetric: column access is coalesced).  The 256 threads split the sum over c into 256/npad
+        // parts (npad = n rounded up to 64/128/256), independent loads unrolled 8-deep: the matvec is L2-latency bound
         double w = 0.0;
-        if (tid < n) {
+        {
+            const int npad = (n <= 64) ? 64 : (n <= 128) ? 128 : 256;
+            const int parts = 256 / npad, part = tid / npad, r = tid & (npad - 1);
+            const int c0 = (n * part) / parts, c1 = (n * (part + 1)) / parts;
             const double* qj = Q + (int64_t)j * n;
-            for (int c = 0; c < n; ++c) w = fma(C[(int64_t)c * n + tid], qj[c], w);
+            double acc = 0.0;
+            if (r < n) {
+#pragma unroll 8
+                for (int c = c0; c < c1; ++c) acc = fma(C[(int64_t)c * n + r], qj[c], acc);
+            }
+            __syncthreads();  // wv is free again (read by the previous step's Gram-Schmidt)
+            wv[tid] = acc;
+            __syncthreads();
+            if (tid < n)
+                for (int pp = 0; pp < parts; ++pp) w += wv[pp * npad + tid];
+            __syncthreads();
         }
-        // classical Gram-Schmidt, twice, against q_0..q_j; the first round's coefficients are column j of H
+        // classical Gram-Schmidt, twice, against q_0..q_j; the first round's coefficients are column j of H.
+        // Dot products: thread (i = tid/8, part = tid%8) sums one eighth of q_i . w, the 8 partials meet in LDS
+        // (wave-wide fp64 shuffles through ds_bpermute made this the slowest part of the kernel).
         for (int round = 0; round < 2; ++round) {
             wv[tid] = w;
             __syncthreads();
-            for (int i = wid; i <= j; i += 4) {
+            {
+                const int i = tid >> 3, part = tid & 7;
                 double d = 0.0;
-                for (int c = lane; c < n; c += 64) d = fma(Q[(int64_t)i * n + c], wv[c], d);
-                for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
-                if (lane == 0) hh[i] = d;
+                if (i <= j) {
+                    const int c0 = (n * part) >> 3, c1 = (n * (part + 1)) >> 3;
+                    const double* qi = Q + (int64_t)i * n;
+#pragma unroll 4
+                    for (int c = c0; c < c1; ++c) d = fma(qi[c], wv[c], d);
+                }
+                pr[tid] = d;
             }
             __syncthreads();
-            if (tid < n)
-                for (int i = 0; i <= j; ++i) w = fma(-hh[i], Q[(int64_t)i * n + tid], w);
             if (tid <= j) {
-                if (round == 0) H[tid][j] = hh[tid];
-                else H[tid][j] += hh[tid];
+                double d = 0.0;
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) d += pr[tid * 8 + q8];
+                hh[tid] = d;
+                if (round == 0) H[tid][j] = d;
+                else H[tid][j] += d;
             }
             __syncthreads();
+            if (tid < n) {
+#pragma unroll 4
+                for (int i = 0; i <= j; ++i) w = fma(-hh[i], Q[(int64_t)i * n + tid], w);
+            }
         }
-        const double beta2 = block_sum_d(w * w, red);
+        const double beta2 = block_sum_d(w * w, pr, red);
         const double beta = sqrt(beta2);
         m = j + 1;
         if (j == 0) scale0 = fabs(H[0][0]) + beta;
@@ -870,14 +907,14 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
         if (tid < n) Q[(int64_t)(j + 1) * n + tid] = w / beta;
         __syncthreads();
     }
-    // Rayleigh-Ritz: leading eigenvector of the m x m projected matrix Q'CQ by repeated squaring (2^14 power steps)
+    // Rayleigh-Ritz: leading eigenvector of the m x m projected matrix Q'CQ by repeated squaring (2^10 power steps)
     __syncthreads();
     for (int i = tid; i < EIG_M * EIG_M; i += 256) {
         const int r = i / EIG_M, c = i % EIG_M;
         T[r][c] = (r < m && c < m) ? H[min(r, c)][max(r, c)] : 0.0;  // H holds q_i . C q_j for i <= j
     }
     __syncthreads();
-    for (int it = 0; it < 14; ++it) {
+    for (int it = 0; it < 10; ++it) {
         double mx = 0.0;
         for (int i = tid; i < EIG_M * EIG_M; i += 256) mx = fmax(mx, fabs((&T[0][0])[i]));
         for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
@@ -911,8 +948,8 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
     double u = 0.0;
     if (tid < n)
         for (int j = 0; j < m; ++j) u = fma(cvec[j], Q[(int64_t)j * n + tid], u);
-    const double un2 = block_sum_d(u * u, red);
-    const double sg = block_sum_d(u * d0, red);
+    const double un2 = block_sum_d(u * u, pr, red);
+    const double sg = block_sum_d(u * d0, pr, red);
     if (un2 > 0.0) u *= (sg < 0.0 ? -1.0 : 1.0) / sqrt(un2);
     else u = d0;
     if (tid < n) Dnext[(int64_t)atom * ldd + tid] = (float)u;
