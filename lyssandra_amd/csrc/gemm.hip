@@ -389,6 +389,8 @@ int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, i
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * A0_LD * (int)sizeof(float)));
         LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<1, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 192 * A0_LD * (int)sizeof(float)));
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<1, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 192 * A0_LD * (int)sizeof(float)));
         attr_set[dev] = true;
     }
     const int64_t blocks = (N + 127) / 128;
@@ -403,6 +405,14 @@ int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, i
                                whole * 128, n);
         if (tail)
             hipLaunchKernelGGL((alpha0_n64_kernel<2, 0>), dim3(1), dim3(256), lds, stream, X + whole * 128 * ldx, ldx, D, ldd,
+                               C + whole * 128 * Kp, Kp, tail, n);
+    } else if (nj == 1 && xpose == 2) {
+        const int64_t whole = N / 128, tail = N - whole * 128;
+        if (whole)
+            hipLaunchKernelGGL((alpha0_n64_kernel<1, 2>), dim3((unsigned)whole), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp,
+                               whole * 128, n);
+        if (tail)
+            hipLaunchKernelGGL((alpha0_n64_kernel<1, 0>), dim3(1), dim3(256), lds, stream, X + whole * 128 * ldx, ldx, D, ldd,
                                C + whole * 128 * Kp, Kp, tail, n);
     } else if (nj == 2 && xpose == 1)
         hipLaunchKernelGGL((alpha0_n64_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
