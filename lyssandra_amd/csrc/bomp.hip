@@ -188,7 +188,7 @@ struct OmpState {
     float Lrow[KMAX];                                               // Lrow[j] lane i (<j) = L[j][i]
     float tv;                                                       // lane j = t_j
     float rinv;                                                     // lane j = 1/rho_j
-    float m0;                                                       // max |alpha0| (noise-floor reference)
+    float m0;                                                       // NOISE_REL * max |alpha0| (noise floor)
     int dxv;                                                        // lane j = Dx[j]
     int nsel;
 };
@@ -218,13 +218,15 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
         int kk, Lown, rown;
         float akk, mabs;
         if (!wave_argmax<R>(s.a, lane, kk, akk, Lown, rown, mabs)) return;
+        // noise floor: both sides are non-negative wave-uniform floats, so the comparison runs on their bit patterns in
+        // the scalar unit (s.m0 holds the bits of NOISE_REL * max|alpha0|, computed once)
         if constexpr (J == 0) {
-            s.m0 = mabs;
+            s.m0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, NOISE_REL * mabs)));
         } else {
-            if (!FAKE_G && mabs < NOISE_REL * s.m0) return;
+            if (!FAKE_G && __builtin_bit_cast(unsigned, mabs) < __builtin_bit_cast(unsigned, s.m0)) return;
         }
-        // re-selection => stop (sparse_coding.py:323-325)
-        if (!FAKE_G && __ballot(lane < J && s.dxv == kk) != 0ull) return;
+        // re-selection => stop (sparse_coding.py:323-325); lanes >= J still hold dxv = -1, which never equals kk
+        if (!FAKE_G && __ballot(s.dxv == kk) != 0ull) return;
         // The vector update is only needed if another selection follows: the reference's last
         // `a = a0 - G[:,Dx] z` (:359) is never read.  (J + 1 < k is wave-uniform; for J == KMAX-1 it is
         // statically false, so p[KMAX-1] never exists.)
