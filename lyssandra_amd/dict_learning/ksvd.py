@@ -86,8 +86,8 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
         raise NotImplementedError("nn_ksvd (non_neg=True with approx=False) is outside the accelerated path")
     if not approx and group is not None:
         raise NotImplementedError("the exact K-SVD update runs on one GPU (approx=True shards over a group)")
-    if eta is not None:
-        raise NotImplementedError("eta (force_mi) is outside the accelerated path")
+    if eta is not None and group is not None:
+        raise NotImplementedError("eta (force_mi) is not available in group (sharded) mode")
     X = np.asarray(X)
     n_features, n_samples = X.shape
     unused_data = []
@@ -145,6 +145,12 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
             col = X[:, i_] if group is None else _dist.fetch_global_column(X, shard_span, int(i_), group)
             dd.set_atom(unused_atoms[j], normalize(np.asarray(col, dtype=np.float64)))
             unused_data.remove(i_)
+        # ---- force mutual incoherence, not in the last iteration (ksvd.py:209-213)
+        if eta is not None and it < max_iter - 1:
+            from .utils import force_mi
+            Dh = dd.to_host()
+            Dh, unused_data = force_mi(Dh, X, (idx, coef, nnz), unused_data, eta)
+            dd.set(Dh)
         # ---- error with the updated codes (ksvd.py:220)
         error_curr = engine.approx_error(Xs, dd, idx, coef, nnz)
         if group is not None:

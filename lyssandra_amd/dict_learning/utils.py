@@ -2,7 +2,7 @@
 import numpy as np
 
 from .. import engine
-from ..utils.math import norm_cols
+from ..utils.math import norm_cols, normalize as _normalize
 
 
 def init_dictionary(X, n_atoms, method='data', return_unused_data=False, normalize=True):
@@ -55,3 +55,65 @@ def average_mutual_coherence(D):
     _lib.check(lib.lys_offdiag_abs_sum(ctypes.c_void_p(G.data_ptr()), K, ctypes.c_void_p(out.data_ptr()),
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "lys_offdiag_abs_sum")
     return float(out.item()) / float(K * (K - 1))
+
+
+def _code_row_norms(Z, n_atoms):
+    """||Z[k, :]|| for every atom, from a dense host matrix or from the device triplet (idx, coef, nnz)."""
+    if isinstance(Z, tuple):
+        torch = engine.require_gpu()
+        idx, coef, nnz = Z
+        k = idx.shape[1]
+        valid = torch.arange(k, device=idx.device)[None, :] < nnz[:, None]
+        sq = torch.zeros((n_atoms,), dtype=torch.float64, device=idx.device)
+        sq.index_add_(0, idx[valid].long(), coef[valid].double() ** 2)
+        return np.sqrt(sq.cpu().numpy())
+    Z = np.asarray(Z)
+    return np.sqrt(np.einsum('ij,ij->i', Z, Z))
+
+
+def force_mi(D, X, Z, unused_data, eta, max_tries=100):
+    """lyssa/dict_learning/utils.py:86-139 -- replace atoms whose mutual coherence exceeds ``eta`` by datapoints.
+
+    Host control flow with the GLOBAL numpy RNG like the reference: the coherence matrix |D'D| is computed ONCE (:89)
+    and not refreshed after a replacement; for atom i the most coherent partner j is looked up in that matrix, the one
+    of the two with the SMALLER code-row norm is replaced (:100-103: ``norm(Z[i]) > norm(Z[j])`` selects i ... the
+    reference's comment asks "the one least used?", its code picks the more used one -- reproduced as written); up to
+    ``max_tries`` + 1 random unused datapoints are tried and the least coherent one is taken.  Returns
+    ``(D, unused_data)``; D is modified in place.  Deviations, both on paths where the reference raises: when no
+    candidate lowers the coherence (``min_idx is None`` at :134) the atom is left alone, and when the candidate list
+    runs dry (:119-120, the reference returns a bare ``D`` that its caller cannot unpack) ``(D, unused_data)`` is
+    returned.
+    """
+    D = np.asarray(D)
+    n_atoms = D.shape[1]
+    G = np.abs(np.dot(D.T, D))
+    np.fill_diagonal(G, 0)
+    row_norm = _code_row_norms(Z, n_atoms)
+    for atom_idx1 in range(n_atoms):
+        atom_idx2 = int(np.argmax(G[atom_idx1, :]))
+        mcoh = G[atom_idx1, atom_idx2]
+        if mcoh < eta:
+            continue
+        c_atom = atom_idx1 if row_norm[atom_idx1] > row_norm[atom_idx2] else atom_idx2
+        cnt = 0
+        available_data = unused_data[:]
+        min_idx = None
+        min_coh = mcoh
+        while mcoh > eta:
+            if cnt > max_tries:
+                break
+            if len(available_data) == 0:
+                return D, unused_data
+            idx = np.random.choice(available_data, size=1)[0]
+            new_atom = _normalize(np.asarray(X[:, idx], dtype=np.float64))
+            available_data.remove(idx)
+            mcoh = np.max(np.abs(np.dot(D.T, new_atom)))
+            if mcoh < min_coh:
+                min_coh = mcoh
+                min_idx = idx
+            cnt += 1
+        if min_idx is None:
+            continue
+        D[:, c_atom] = _normalize(np.asarray(X[:, min_idx], dtype=np.float64))
+        unused_data.remove(min_idx)
+    return D, unused_data

@@ -295,6 +295,48 @@ def average_mutual_coherence(D):
     return float(np.sum(G) / float(K * (K - 1)))
 
 
+def force_mi(D, X, Z, unused_data, eta, max_tries=100):
+    """lyssa/dict_learning/utils.py:86-139, statement by statement (same global-RNG draws).  The two paths on which the
+    reference itself fails are made explicit: `min_idx is None` at :134 (no candidate lowered the coherence; the
+    reference would index X[:, None]) leaves the atom alone, and an exhausted candidate list (:119-120, bare `return D`)
+    returns (D, unused_data)."""
+    n_atoms = D.shape[1]
+    G = np.abs(np.dot(D.T, D))                                   # :88 (computed once, never refreshed)
+    np.fill_diagonal(G, 0)                                       # :89
+    for atom_idx1 in range(n_atoms):                             # :91
+        atom_idx2 = np.argmax(G[atom_idx1, :])                   # :93
+        mcoh = G[atom_idx1, atom_idx2]                           # :95
+        if mcoh < eta:                                           # :96
+            continue
+        if norm(Z[atom_idx1, :]) > norm(Z[atom_idx2, :]):        # :101
+            c_atom = atom_idx1
+        else:
+            c_atom = atom_idx2
+        cnt = 0
+        available_data = unused_data[:]                          # :108
+        min_idx = None
+        min_coh = mcoh
+        while mcoh > eta:                                        # :112
+            if cnt > max_tries:                                  # :114
+                break
+            if len(available_data) == 0:                         # :117
+                return D, unused_data
+            idx = np.random.choice(available_data, size=1)[0]    # :119,122
+            new_atom = normalize(X[:, idx])                      # :123-124
+            available_data.remove(idx)                           # :125
+            g = np.abs(np.dot(D.T, new_atom))                    # :126
+            mcoh = np.max(g)                                     # :127
+            if mcoh < min_coh:                                   # :128
+                min_coh = mcoh
+                min_idx = idx
+            cnt += 1
+        if min_idx is None:
+            continue
+        D[:, c_atom] = normalize(X[:, min_idx])                  # :134-135
+        unused_data.remove(min_idx)                              # :136
+    return D, unused_data
+
+
 def init_dictionary(X, n_atoms, method='data', return_unused_data=False, normalize=True):
     """lyssa/dict_learning/utils.py:49-70 ('data' method only).
 

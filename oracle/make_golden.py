@@ -16,6 +16,7 @@ Fixtures:
       hand-driven iterations + one full ksvd_dict_learn(max_iter=50) run (patience quirk, RNG use)
   F6  online DL, same data, batch 500, 1 and 2 epochs, beta=None and beta=0.9: D at every encode
       call, final D, A, B
+  F11 force_mi (mutual-incoherence step of ksvd_dict_learn, eta=0.9) on a dictionary with three coherent atom pairs
   F10 exact K-SVD (`ksvd`, randomized_svd seeded): F5's data (first 1200 signals), D / codes / error after 2 iterations
 """
 import contextlib
@@ -323,6 +324,29 @@ def main():
         out["it%d_unused" % it] = np.array(unused, dtype=np.int32)
         print("F10 it", it, "err", out["it%d_err" % it], "unused", unused)
     np.savez_compressed(os.path.join(OUT, "F10.npz"), **out)
+
+    # ---------------- F11: force_mi (dict_learning/utils.py:86-139; ksvd_dict_learn's optional `eta` step), seeded RNG
+    from lyssa.dict_learning.utils import force_mi as ref_force_mi
+    rs = np.random.RandomState(111)
+    n, K, N = 24, 40, 300
+    D = make_dict(rs, n, K)
+    for a_, b_ in ((3, 17), (8, 30), (21, 22)):       # three strongly coherent pairs
+        v = D[:, a_] + 0.05 * rs.randn(n)
+        D[:, b_] = v / np.linalg.norm(v)
+    D = f32(D)
+    X = f32(rs.randn(n, N))
+    Z = np.zeros((K, N))
+    for i in range(N):
+        Z[rs.choice(K, 3, replace=False), i] = rs.randn(3)
+    unused = list(range(40, 200))
+    out = dict(D=D.astype(np.float32), X=X.astype(np.float32), Z=Z, unused=np.array(unused), eta=0.9)
+    np.random.seed(4242)
+    D1, un1 = quiet(ref_force_mi, D.copy(), X, Z, list(unused), 0.9)
+    out["D_out"] = D1
+    out["unused_out"] = np.array(un1)
+    out["rng_after"] = np.random.randint(0, 2 ** 31 - 1)
+    print("F11 replaced atoms:", np.flatnonzero(np.abs(D1 - D).max(0) > 0), "unused left", len(un1))
+    np.savez_compressed(os.path.join(OUT, "F11.npz"), **out)
 
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)

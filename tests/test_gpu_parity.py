@@ -459,6 +459,31 @@ def test_online_dict_learn_with_lasso_coder(eng):
     assert objective(oc.D) < 0.9 * objective(D0)
 
 
+def test_ksvd_dict_learn_with_eta(eng):
+    """ksvd.py:209-213: the optional mutual-incoherence step (force_mi, golden F11) inside the learner."""
+    from lyssandra_amd.dict_learning.ksvd import ksvd_dict_learn
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    g = load_golden("F11")
+    D0, X = g["D"].astype(np.float64), g["X"].astype(np.float64)
+
+    def max_coh(Dm):
+        G = np.abs(Dm.T @ Dm)
+        np.fill_diagonal(G, 0)
+        return G.max()
+
+    assert max_coh(D0) > 0.95
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 3}, verbose=False)
+    np.random.seed(5)
+    D1, Z1 = ksvd_dict_learn(X, D0.shape[1], init_dict=D0, sparse_coder=se, max_iter=3, approx=True, eta=0.9,
+                             verbose=False)
+    assert D1.shape == D0.shape and Z1.shape == (D0.shape[1], X.shape[1])
+    assert np.allclose(np.linalg.norm(D1, axis=0), 1.0, atol=1e-5)
+    np.random.seed(5)
+    D2, _ = ksvd_dict_learn(X, D0.shape[1], init_dict=D0, sparse_coder=se, max_iter=3, approx=True, eta=None,
+                            verbose=False)
+    assert not np.allclose(D1, D2)                                  # the eta step changed the trajectory
+
+
 def test_ksvd_coder_dropin(eng):
     """ksvd_dict_learn host control flow: patience quirk (11 encode calls), global-RNG use, ndarray init_dict."""
     from lyssandra_amd.dict_learning.ksvd import ksvd_dict_learn, ksvd_coder

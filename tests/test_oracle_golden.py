@@ -82,6 +82,21 @@ def test_approx_ksvd_matches_reference():
     assert np.max(np.abs(D - g["cyc2_D"])) <= 1e-10
 
 
+def test_force_mi_matches_reference():
+    """dict_learning/utils.py:86-139 on F11: same atoms replaced, same datapoints drawn (global RNG), for the oracle
+    and for the product's host implementation (pure host control flow: no GPU needed)."""
+    from lyssandra_amd.dict_learning.utils import force_mi as product_force_mi
+    g = load_golden("F11")
+    D0, X, Z = g["D"].astype(np.float64), g["X"].astype(np.float64), g["Z"]
+    for fn in (orc.force_mi, product_force_mi):
+        np.random.seed(4242)
+        D1, un1 = fn(D0.copy(), X, Z, g["unused"].tolist(), float(g["eta"]))
+        assert np.max(np.abs(D1 - g["D_out"])) <= 1e-12
+        assert list(un1) == g["unused_out"].tolist()
+        assert np.random.randint(0, 2 ** 31 - 1) == int(g["rng_after"])
+    assert (np.abs(g["D_out"] - D0).max(0) > 0).sum() == 3          # the three coherent pairs each lost one atom
+
+
 def test_lasso_oracle_against_independent_solvers():
     """'lasso' (sparse_coding.py:487-509) delegates to SPAMS, which is not available: the oracle restates the problem
     min 0.5||x-Da||^2 + lam||a||_1 and is pinned here against sklearn's coordinate-descent Lasso, sklearn's LARS path
