@@ -473,15 +473,17 @@ def test_ksvd_dict_learn_with_eta(eng):
 
     assert max_coh(D0) > 0.95
     se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 3}, verbose=False)
-    np.random.seed(5)
-    D1, Z1 = ksvd_dict_learn(X, D0.shape[1], init_dict=D0, sparse_coder=se, max_iter=3, approx=True, eta=0.9,
-                             verbose=False)
-    assert D1.shape == D0.shape and Z1.shape == (D0.shape[1], X.shape[1])
-    assert np.allclose(np.linalg.norm(D1, axis=0), 1.0, atol=1e-5)
-    np.random.seed(5)
-    D2, _ = ksvd_dict_learn(X, D0.shape[1], init_dict=D0, sparse_coder=se, max_iter=3, approx=True, eta=None,
-                            verbose=False)
-    assert not np.allclose(D1, D2)                                  # the eta step changed the trajectory
+    # init_dict='data' so that unused datapoints exist to draw replacements from; eta low enough to trigger on the
+    # learned dictionary (after one sweep on random data no pair is 0.9-coherent any more)
+    res = {}
+    for eta in (0.3, None):
+        np.random.seed(5)
+        res[eta] = ksvd_dict_learn(X, 32, init_dict='data', sparse_coder=se, max_iter=3, approx=True, eta=eta,
+                                   verbose=False)
+        D1, Z1 = res[eta]
+        assert D1.shape == (X.shape[0], 32) and Z1.shape == (32, X.shape[1])
+        assert np.allclose(np.linalg.norm(D1, axis=0), 1.0, atol=1e-5)
+    assert not np.allclose(res[0.3][0], res[None][0])               # the eta step replaced atoms
 
 
 def test_ksvd_coder_dropin(eng):
