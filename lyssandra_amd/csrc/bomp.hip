@@ -208,13 +208,16 @@ constexpr float NOISE_REL = 4e-6f;
 // The Gram-row variants (1, 4..8) produce garbage correlations, so they also switch the data-dependent exits off and
 // keep the values bounded: every signal runs all k steps, like a real Gaussian signal does (otherwise the wrong rows
 // make the next argmax re-select the same atom and the kernel "speeds up" by stopping after two steps).
-template <int R, int KMAX, int NLDS, int J, int VAR = 0>
+// FAST: k == KMAX and the unit Gram diagonal are known at compile time (the 'bomp' headline launch): the per-step
+// `J >= k`, `J + 1 < k` and `unit_diag` tests and their scalar branches disappear.
+template <int R, int KMAX, int NLDS, int J, int VAR = 0, bool FAST = false>
 __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const float* __restrict__ G, int k, int lane,
-                                          f32x4* __restrict__ lds /* [NLDS][R/4][64] of this wave */, int unit_diag) {
+                                          f32x4* __restrict__ lds /* [NLDS][R/4][64] of this wave */, int unit_diag_rt) {
     using L = Lay<R>;
+    const bool unit_diag = FAST ? true : (unit_diag_rt != 0);
     constexpr bool FAKE_G = (VAR == 1) || (VAR >= 4 && VAR <= 8);
     if constexpr (J < KMAX) {
-        if (J >= k) return;
+        if (!FAST && J >= k) return;
         int kk, Lown, rown;
         float akk, mabs;
         if (!wave_argmax<R>(s.a, lane, kk, akk, Lown, rown, mabs)) return;
@@ -230,7 +233,7 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
         // The vector update is only needed if another selection follows: the reference's last
         // `a = a0 - G[:,Dx] z` (:359) is never read.  (J + 1 < k is wave-uniform; for J == KMAX-1 it is
         // statically false, so p[KMAX-1] never exists.)
-        const bool more = (J + 1 < KMAX) && (J + 1 < k);
+        const bool more = (J + 1 < KMAX) && (FAST || J + 1 < k);
         // Gram row of the new atom (G is symmetric: row kk == column kk), issued before the scalar work
         float g[R];
         if (!more) {
@@ -338,13 +341,13 @@ __device__ __forceinline__ void omp_steps(OmpState<R, KMAX, NLDS>& s, const floa
         s.rinv = writelane_f(inv, J, s.rinv, lane);
         s.dxv = writelane_i(kk, J, s.dxv, lane);
         s.nsel = J + 1;
-        omp_steps<R, KMAX, NLDS, J + 1, VAR>(s, G, k, lane, lds, unit_diag);
+        omp_steps<R, KMAX, NLDS, J + 1, VAR, FAST>(s, G, k, lane, lds, unit_diag_rt);
     }
 }
 
 // BW = waves per workgroup.  (A persistent variant that prefetches the next signal's alpha0 row into 16 more VGPRs
 // was tried and rejected: the loop-carried registers push the 3-waves/SIMD build into scratch, 4.5x slower.)
-template <int R, int KMAX, int WAVES_PER_SIMD, int NLDS = 0, int VAR = 0, int BW = 4>
+template <int R, int KMAX, int WAVES_PER_SIMD, int NLDS = 0, int VAR = 0, int BW = 4, bool FAST = false>
 __global__ __launch_bounds__(64 * BW, WAVES_PER_SIMD) void bomp_wave_kernel(const float* __restrict__ alpha0,
                                                                            const float* __restrict__ G, int64_t N,
                                                                            int k, int32_t* __restrict__ idx_out,
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(64 * BW, WAVES_PER_SIMD) void bomp_wave_kernel(cons
     s.m0 = 0.f;
     s.dxv = -1;
     s.nsel = 0;
-    omp_steps<R, KMAX, NLDS, 0, VAR>(s, G, k, lane, s_p + wid * (NLDS * L::C * 64), unit_diag);
+    omp_steps<R, KMAX, NLDS, 0, VAR, FAST>(s, G, k, lane, s_p + wid * (NLDS * L::C * 64), unit_diag);
     const int nsel = s.nsel;
 
     // z = L^-T t  (second triangular solve, sparse_coding.py:354), column-oriented over lanes
@@ -779,8 +782,12 @@ static int launch_wave(const float* alpha0, const float* G, int64_t N, int k, in
     if constexpr (R == 16 && KMAX == 10) {
         // headline shape: 2 vectors in LDS -> 163 VGPRs (<= 168) -> 3 waves/SIMD (32 KB LDS per 4-wave workgroup).
         // (3 vectors in LDS were needed while the kernel used more registers; now 2 is 2 % faster: less LDS traffic)
-        hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N,
-                           k, idx, coef, nnz, unit_diag);
+        if (k == 10 && unit_diag)
+            hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2, 0, 4, true>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                               alpha0, G, N, k, idx, coef, nnz, unit_diag);
+        else
+            hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N,
+                               k, idx, coef, nnz, unit_diag);
     } else {
         hipLaunchKernelGGL((bomp_wave_kernel<R, KMAX, W>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N,
                            k, idx, coef, nnz, unit_diag);
