@@ -375,15 +375,16 @@ __global__ __launch_bounds__(64 * BW, WAVES_PER_SIMD) void bomp_wave_kernel(cons
     const int nsel = s.nsel;
 
     // z = L^-T t  (second triangular solve, sparse_coding.py:354), column-oriented over lanes
-    float zv = s.tv, zout = 0.f;
+    // lane i of zv ends up as t_i - sum_{j>i} L[j][i] z_j (row j only touches lanes i < j), so z = zv * rinv at the end
+    float zv = s.tv;
 #pragma unroll
-    for (int i = KMAX - 1; i >= 0; --i) {
+    for (int i = KMAX - 1; i >= 1; --i) {
         if (i < nsel) {
-            const float zi = readlane_f(zv, i) * readlane_f(s.rinv, i);
-            zout = (lane == i) ? zi : zout;
+            const float zi = readlane_f(zv * s.rinv, i);
             zv = fmaf(-zi, s.Lrow[i], zv);
         }
     }
+    const float zout = zv * s.rinv;
     if (lane < k) {
         idx_out[sig * k + lane] = (lane < nsel) ? s.dxv : -1;
         coef_out[sig * k + lane] = (lane < nsel) ? zout : 0.f;
