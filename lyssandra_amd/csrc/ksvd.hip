@@ -449,15 +449,18 @@ __global__ __launch_bounds__(256) void ksvd_apply_kernel(int atom, float* __rest
 // the pending update of atom a-1 to its registers first, then accumulates for atom a); the team that meets it in
 // omega_{a-1} skips it.  Membership is decided from the signal's own k-entry support row, no merged list needed.
 // ---------------------------------------------------------------------------------------------
-template <int FB>
-__global__ __launch_bounds__(256) void ksvd_fused_kernel(int atom, int K, int4 hb, int2 hn, float* __restrict__ R,
+// TEAMS 16-lane teams per workgroup: every team walks its signals one after the other (three dependent memory round
+// trips per signal), so the kernel time is (signals per team) x latency -- 64 teams per workgroup instead of 16 keep
+// the number of fp64 atomics (one set per workgroup) and cut the chain from ~5 signals to 1-2.
+template <int FB, int TEAMS>
+__global__ __launch_bounds__(16 * TEAMS) void ksvd_fused_kernel(int atom, int K, int4 hb, int2 hn, float* __restrict__ R,
                                                          int64_t ldr, int n, int k,
                                                          const int32_t* __restrict__ row_ptr,
                                                          const int32_t* __restrict__ entry,
                                                          const int32_t* __restrict__ idx, float* __restrict__ coef,
                                                          double* __restrict__ sbuf, const float* __restrict__ D,
                                                          int ldd, float* __restrict__ Dnext) {
-    __shared__ float s_acc[16][FB * 64 + 1];
+    __shared__ float s_acc[TEAMS][FB * 64 + 1];
     const int prev = atom - 1;
     const bool have_prev = prev >= 0, have_cur = atom < K;
     // segment bounds: passed by value when the host knows row_ptr (hb.x >= 0), which removes one dependent load from
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(256) void ksvd_fused_kernel(int atom, int K, int4 h
         const int nxt = atom + 1;
         if (nxt >= K) return;
         const int nb = byval ? hn.x : row_ptr[nxt], ne = byval ? hn.y : row_ptr[nxt + 1];
-        const int pteam = ((int)blockIdx.x - KSVD_BLOCKS) * 16 + team, pteams = ((int)gridDim.x - KSVD_BLOCKS) * 16;
+        const int pteam = ((int)blockIdx.x - KSVD_BLOCKS) * TEAMS + team, pteams = ((int)gridDim.x - KSVD_BLOCKS) * TEAMS;
         for (int e = nb + pteam; e < ne; e += pteams) {
             const int ss = entry[e];
             const int64_t sig = ss / k;
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(256) void ksvd_fused_kernel(int atom, int K, int4 h
     const bool do_b = have_cur && (!both || (int)blockIdx.x >= half);
     const int blk = both ? ((int)blockIdx.x % half) : (int)blockIdx.x;
     const int nblk = both ? half : KSVD_BLOCKS;
-    const int gteam = blk * 16 + team, nteams = nblk * 16;
-    const bool blk_prev = do_a && (pbeg + blk * 16 < pend), blk_cur = do_b && (cbeg + blk * 16 < cend);
+    const int gteam = blk * TEAMS + team, nteams = nblk * TEAMS;
+    const bool blk_prev = do_a && (pbeg + blk * TEAMS < pend), blk_cur = do_b && (cbeg + blk * TEAMS < cend);
     if (!blk_prev && !blk_cur && !(blockIdx.x == 0 && have_prev)) return;  // uniform per block
 
     // ---- d_new of the previous atom (fp64, every team redundantly; block 0 / team 0 publishes it)
@@ -641,11 +644,11 @@ __global__ __launch_bounds__(256) void ksvd_fused_kernel(int atom, int K, int4 h
     if (q == 0) s_acc[team][FB * 64] = sq;
     __syncthreads();
     double* dst = sbuf + (int64_t)atom * (n + 1);
-    for (int f = threadIdx.x; f <= n; f += 256) {
+    for (int f = threadIdx.x; f <= n; f += 16 * TEAMS) {
         const int src = (f == n) ? FB * 64 : f;
         double tot = 0.0;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) tot += (double)s_acc[t][src];
+#pragma unroll 16
+        for (int t = 0; t < TEAMS; ++t) tot += (double)s_acc[t][src];
         atomicAdd(dst + f, tot);
     }
 }
@@ -671,9 +674,9 @@ int ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, const 
         if (pf < 0) pf = 0;
     }
     switch (fb) {
-        case 1: hipLaunchKernelGGL(ksvd_fused_kernel<1>, dim3(KSVD_BLOCKS + pf), dim3(256), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
-        case 2: hipLaunchKernelGGL(ksvd_fused_kernel<2>, dim3(KSVD_BLOCKS + pf), dim3(256), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
-        case 4: hipLaunchKernelGGL(ksvd_fused_kernel<4>, dim3(KSVD_BLOCKS + pf), dim3(256), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
+        case 1: hipLaunchKernelGGL((ksvd_fused_kernel<1, 64>), dim3(KSVD_BLOCKS + pf), dim3(1024), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
+        case 2: hipLaunchKernelGGL((ksvd_fused_kernel<2, 64>), dim3(KSVD_BLOCKS + pf), dim3(1024), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
+        case 4: hipLaunchKernelGGL((ksvd_fused_kernel<4, 32>), dim3(KSVD_BLOCKS + pf), dim3(512), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
         default: set_error("ksvd: n = %d > 256 not supported", n); return LYS_ENOSUP;
     }
     LYS_LAUNCH_CHECK();
