@@ -472,8 +472,8 @@ int thresh_from_alpha0(const float* alpha0, int K, int Kp, int k, int64_t N, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Workgroup-per-signal register kernel for K > 1024: 512 threads (8 waves) share one signal, thread t holds the
-// R = Kp/512 correlations  c*2048 + 4t + e  (dwordx4-coalesced rows) and the matching slices of the k-1
+// Workgroup-per-signal register kernel for K > 1024: T threads (T/64 waves) share one signal, thread t holds the
+// R = Kp/T correlations  c*4T + 4t + e  (dwordx4-coalesced rows) and the matching slices of the k-1
 // orthogonalised vectors in VGPRs.  Same arithmetic as bomp_wave_kernel; the argmax and the w_i = p_i[kk]
 // extraction go through LDS with two barriers per step.  K = 4096, k = 20 (config 3): 19*8 = 152 vector VGPRs,
 // one workgroup per CU.
@@ -506,7 +506,7 @@ __device__ __forceinline__ void blk_publish(const BlkState<R, KMAX>& s, int r, f
     }
 }
 
-template <int R, int KMAX, int J>
+template <int R, int KMAX, int J, int T>
 __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __restrict__ G, int Kp, int k, int tid,
                                           float* s_max, int* s_idx, float* s_w, float* s_akk, float* s_L, float* s_t,
                                           float* s_rinv, int* s_dx, int* s_nsel, float& m0, int unit_diag) {
@@ -520,10 +520,10 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
         const float mw = wave_max_f(best);
         int cand = 0x7fffffff;
 #pragma unroll
-        for (int r = R - 1; r >= 0; --r) cand = (fabsf(s.a[r]) == mw) ? ((r >> 2) * 2048 + tid * 4 + (r & 3)) : cand;
+        for (int r = R - 1; r >= 0; --r) cand = (fabsf(s.a[r]) == mw) ? ((r >> 2) * (4 * T) + tid * 4 + (r & 3)) : cand;
         const int cw = wave_min_i(cand);
-        float* smx = s_max + (J & 1) * 8;
-        int* six = s_idx + (J & 1) * 8;
+        float* smx = s_max + (J & 1) * (T / 64);
+        int* six = s_idx + (J & 1) * (T / 64);
         if (lane == 0) {
             smx[wid] = mw;
             six[wid] = cw;
@@ -532,7 +532,7 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
         float m = smx[0];
         int kk = six[0];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) {
+        for (int q = 1; q < T / 64; ++q) {
             const float v = smx[q];
             const int c = six[q];
             const bool better = (v > m) || (v == m && c < kk);
@@ -550,10 +550,14 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
             if (s_dx[i] == kk) return;  // re-selection => stop (sparse_coding.py:323-325)
         const bool more = (J + 1 < KMAX) && (J + 1 < k);
         float g[R];
+        if (!more) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "=v"(g[r]));  // never read: no zero-fill
+        }
         if (more) {
 #pragma unroll
             for (int c = 0; c < R / 4; ++c) {
-                const f32x4 t4 = *(reinterpret_cast<const f32x4*>(G + (int64_t)kk * Kp) + c * 512 + tid);
+                const f32x4 t4 = *(reinterpret_cast<const f32x4*>(G + (int64_t)kk * Kp) + c * T + tid);
                 g[4 * c] = t4.x;
                 g[4 * c + 1] = t4.y;
                 g[4 * c + 2] = t4.z;
@@ -561,7 +565,7 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
             }
         }
         // ---- owner publishes a[kk] and w_i = p_i[kk]
-        if (tid == ((kk & 2047) >> 2)) blk_publish<R, KMAX, J, 0>(s, (kk >> 11) * 4 + (kk & 3), s_w, s_akk);
+        if (tid == ((kk % (4 * T)) >> 2)) blk_publish<R, KMAX, J, 0>(s, (kk / (4 * T)) * 4 + (kk & 3), s_w, s_akk);
         __syncthreads();
         float w[KMAX];
         const float gkk = unit_diag ? 1.f : G[(int64_t)kk * Kp + kk];
@@ -572,8 +576,7 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
             vs = fmaf(-w[i], w[i], vs);
         }
         if ((J > 0 || !unit_diag) && vs < EPS32_F * gkk) return;
-        float inv = __builtin_amdgcn_rsqf(vs);
-        inv = inv * fmaf(-0.5f * vs, inv * inv, 1.5f);
+        const float inv = __builtin_amdgcn_rsqf(vs);  // 1 ulp, like the single-wave kernel
         const float t = (*s_akk) * inv;
         if constexpr (J + 1 < KMAX) {
             if (more) {
@@ -597,18 +600,18 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
             *s_nsel = J + 1;
         }
         // s_dx[J] is read by every thread in the next step only after that step's first barrier
-        blk_steps<R, KMAX, J + 1>(s, G, Kp, k, tid, s_max, s_idx, s_w, s_akk, s_L, s_t, s_rinv, s_dx, s_nsel, m0,
+        blk_steps<R, KMAX, J + 1, T>(s, G, Kp, k, tid, s_max, s_idx, s_w, s_akk, s_L, s_t, s_rinv, s_dx, s_nsel, m0,
                                   unit_diag);
     }
 }
 
-template <int R, int KMAX, int W>
-__global__ __launch_bounds__(512, W) void bomp_block_kernel(const float* __restrict__ alpha0,
+template <int R, int KMAX, int W, int T = 512>
+__global__ __launch_bounds__(T, W) void bomp_block_kernel(const float* __restrict__ alpha0,
                                                             const float* __restrict__ G, int64_t N, int k,
                                                             int32_t* __restrict__ idx_out,
                                                             float* __restrict__ coef_out,
                                                             int32_t* __restrict__ nnz_out, int unit_diag) {
-    constexpr int Kp = 512 * R;
+    constexpr int Kp = T * R;
     __shared__ float s_max[16];
     __shared__ int s_idx[16];
     __shared__ float s_w[KMAX];
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(512, W) void bomp_block_kernel(const float* __restr
     BlkState<R, KMAX> s;
 #pragma unroll
     for (int c = 0; c < R / 4; ++c) {
-        const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(alpha0 + sig * Kp) + c * 512 + tid);
+        const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(alpha0 + sig * Kp) + c * T + tid);
         s.a[4 * c] = t4.x;
         s.a[4 * c + 1] = t4.y;
         s.a[4 * c + 2] = t4.z;
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(512, W) void bomp_block_kernel(const float* __restr
     }
     __syncthreads();
     float m0 = 0.f;
-    blk_steps<R, KMAX, 0>(s, G, Kp, k, tid, s_max, s_idx, s_w, &s_akk, s_L, s_t, s_rinv, s_dx, &s_nsel, m0, unit_diag);
+    blk_steps<R, KMAX, 0, T>(s, G, Kp, k, tid, s_max, s_idx, s_w, &s_akk, s_L, s_t, s_rinv, s_dx, &s_nsel, m0, unit_diag);
     __syncthreads();
     const int nsel = s_nsel;
     if (tid == 0) {
@@ -838,14 +841,14 @@ int bomp_debug_variant(const float* alpha0, const float* G, int64_t N, int k, in
     return LYS_OK;
 }
 
-template <int R, int KMAX, int W>
+template <int R, int KMAX, int W, int T = 512>
 static int launch_block(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
                         hipStream_t stream, int unit_diag) {
     if (N > 0x7fffffffLL) {
         set_error("bomp: too many signals per launch (%lld)", (long long)N);
         return LYS_ENOSUP;
     }
-    hipLaunchKernelGGL((bomp_block_kernel<R, KMAX, W>), dim3((unsigned)N), dim3(512), 0, stream, alpha0, G, N, k, idx,
+    hipLaunchKernelGGL((bomp_block_kernel<R, KMAX, W, T>), dim3((unsigned)N), dim3(T), 0, stream, alpha0, G, N, k, idx,
                        coef, nnz, unit_diag);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
@@ -881,9 +884,13 @@ int bomp_from_alpha0(const float* alpha0, const float* G, int Kp, int k, int64_t
     }
     int rc = 1;
     if (Kp > 1024 && bomp_has_block_kernel(Kp, k)) {
-        if (Kp == 2048) return (k <= 10) ? launch_block<4, 10, 4>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
+        // k <= 10: 16 correlations per thread (2 / 4 / 8 waves per signal), like the single-wave kernel (K = 2048:
+        // 41 -> 62 M patches/s against the 512-thread split); k <= 20 needs the thinner split to hold 19 vectors.
+        // (Letting the winning wave resolve the argmax with readlanes and publish w itself was tried: slower, the other
+        // waves wait at the barrier for that serial chain.)
+        if (Kp == 2048) return (k <= 10) ? launch_block<16, 10, 2, 128>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
                                          : launch_block<4, 20, 3>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
-        if (Kp == 4096) return (k <= 10) ? launch_block<8, 10, 3>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
+        if (Kp == 4096) return (k <= 10) ? launch_block<16, 10, 2, 256>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
                                          : launch_block<8, 20, 2>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
         return launch_block<16, 10, 2>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
     }
