@@ -93,69 +93,104 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_cd_kernel(const fl
         __syncthreads();
     }
     const float tol_abs = tol_rel * amax;
-    int steps = 0;
-    while (steps < max_steps) {
-        Best b{-1.f, 0x7fffffff, 0.f};
+    int steps = 0, total = 0;
+    // Rounds of [coordinate descent to the stopping rule] + [compaction of the non-zeros] + [refresh of c from scratch].
+    // c -= delta * G[j,:] accumulates fp32 rounding over hundreds of steps; recomputing c = D'x - G a from the compacted
+    // code (one Gram row per non-zero) and resuming removes that drift.  The kernel returns when a round that started
+    // from fresh correlations needs no step at all (or at max_steps / after MAX_REFRESH rounds).
+    constexpr int MAX_REFRESH = 8;
+    for (int round = 0;; ++round) {
+        const int steps_before = steps;
+        while (steps < max_steps) {
+            Best b{-1.f, 0x7fffffff, 0.f};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float v = fmaf(gd[r], a[r], c[r]);
+                const float s = copysignf(fmaxf(fabsf(v) - lambda, 0.f), v) * ginv[r];
+                const float d = s - a[r];
+                const Best cand{fabsf(d), L::elem(r, t, T), d};
+                b = better(b, cand);
+            }
+            b = wave_best(b);
+            if (W > 1) {
+                if (lane == 0) {
+                    s_score[wid] = b.score;
+                    s_e[wid] = b.e;
+                    s_delta[wid] = b.delta;
+                }
+                __syncthreads();
+                b = Best{s_score[0], s_e[0], s_delta[0]};
+                for (int w = 1; w < W; ++w) b = better(b, Best{s_score[w], s_e[w], s_delta[w]});
+                __syncthreads();
+            }
+            if (!(b.score > tol_abs)) break;
+            float g[R];
+            load_vec<R>(G + (int64_t)b.e * Kp, t, T, g);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (L::elem(r, t, T) == b.e) a[r] += b.delta;
+                c[r] = fmaf(-b.delta, g[r], c[r]);
+            }
+            ++steps;
+        }
+        // ---- snap: a coefficient whose own update target is exactly zero (it sits below the stopping tolerance) is
+        // set to zero, so the returned support is the support of the minimiser and not "zero + 1e-7"
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float v = fmaf(gd[r], a[r], c[r]);
-            const float s = copysignf(fmaxf(fabsf(v) - lambda, 0.f), v) * ginv[r];
-            const float d = s - a[r];
-            const Best cand{fabsf(d), L::elem(r, t, T), d};
-            b = better(b, cand);
+            if (a[r] != 0.f && !(fabsf(v) > lambda)) {
+                c[r] = v;  // own-coordinate part of the correlation update (the other coordinates move by < tol)
+                a[r] = 0.f;
+            }
         }
-        b = wave_best(b);
+        // ---- compact the non-zeros: (thread, register) order, at most kcap entries
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) cnt += (a[r] != 0.f) ? 1 : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        int base = 0;
+        total = __shfl(incl, 63, 64);
         if (W > 1) {
-            if (lane == 0) {
-                s_score[wid] = b.score;
-                s_e[wid] = b.e;
-                s_delta[wid] = b.delta;
+            __syncthreads();
+            if (lane == 63) s_cnt[wid] = incl;
+            __syncthreads();
+            total = 0;
+            for (int w = 0; w < W; ++w) {
+                if (w < wid) base += s_cnt[w];
+                total += s_cnt[w];
             }
-            __syncthreads();
-            b = Best{s_score[0], s_e[0], s_delta[0]};
-            for (int w = 1; w < W; ++w) b = better(b, Best{s_score[w], s_e[w], s_delta[w]});
-            __syncthreads();
         }
-        if (!(b.score > tol_abs)) break;
-        float g[R];
-        load_vec<R>(G + (int64_t)b.e * Kp, t, T, g);
+        int pos = base + incl - cnt;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (L::elem(r, t, T) == b.e) a[r] += b.delta;
-            c[r] = fmaf(-b.delta, g[r], c[r]);
-        }
-        ++steps;
-    }
-    // ---- compact the non-zeros: (thread, register) order, at most kcap entries
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) cnt += (a[r] != 0.f) ? 1 : 0;
-    int incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    int base = 0, total = __shfl(incl, 63, 64);
-    if (W > 1) {
-        if (lane == 63) s_cnt[wid] = incl;
+        for (int r = 0; r < R; ++r)
+            if (a[r] != 0.f) {
+                if (pos < kcap) {
+                    idx[sig * kcap + pos] = L::elem(r, t, T);
+                    coef[sig * kcap + pos] = a[r];
+                }
+                ++pos;
+            }
+        const bool fresh_and_quiet = (round > 0) && (steps == steps_before);
+        if (fresh_and_quiet || steps >= max_steps || round >= MAX_REFRESH || total > kcap || total == 0) break;
+        // ---- refresh: c = alpha0 - sum_e coef_e * G[idx_e, :] from the list just written
+        __threadfence_block();
         __syncthreads();
-        total = 0;
-        for (int w = 0; w < W; ++w) {
-            if (w < wid) base += s_cnt[w];
-            total += s_cnt[w];
-        }
-    }
-    int pos = base + incl - cnt;
+        load_vec<R>(alpha0 + sig * Kp, t, T, c);
+        for (int e = 0; e < total; ++e) {
+            const int j = idx[sig * kcap + e];
+            const float aj = coef[sig * kcap + e];
+            float g[R];
+            load_vec<R>(G + (int64_t)j * Kp, t, T, g);
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (a[r] != 0.f) {
-            if (pos < kcap) {
-                idx[sig * kcap + pos] = L::elem(r, t, T);
-                coef[sig * kcap + pos] = a[r];
-            }
-            ++pos;
+            for (int r = 0; r < R; ++r) c[r] = fmaf(-aj, g[r], c[r]);
         }
+        __syncthreads();  // the list is overwritten by the next compaction
+    }
     for (int p = total + t; p < kcap; p += T) {  // unused slots: (-1, 0) like the other encoders
         idx[sig * kcap + p] = -1;
         coef[sig * kcap + p] = 0.f;

@@ -84,9 +84,17 @@ class sparse_encoder(object):
             idx, coef, nnz, steps = engine.lasso_encode(Xs, dd, lam, kcap=self.params.get('kcap'),
                                                         max_steps=self.params.get('max_steps'),
                                                         tol=self.params.get('tol', 1e-6), out=out, return_steps=True)
-            if int(steps.min().item()) < 0 if steps.numel() else False:
-                raise RuntimeError("lasso: more than kcap=%d non-zero coefficients for some signal; raise "
-                                   "params['kcap'] or lambda" % idx.shape[1])
+            if steps.numel():
+                if int(steps.min().item()) < 0:
+                    raise RuntimeError("lasso: more than kcap=%d non-zero coefficients for some signal; raise "
+                                       "params['kcap'] or lambda" % idx.shape[1])
+                budget = self.params.get('max_steps')
+                budget = int(budget) if budget is not None else 50 * int(idx.shape[1])
+                n_bad = int((steps >= budget).sum().item())
+                if n_bad:
+                    import warnings
+                    warnings.warn("lasso: %d of %d signals used the whole step budget (%d) without reaching tol; "
+                                  "raise params['max_steps'] or lambda" % (n_bad, steps.numel(), budget))
             return idx, coef, nnz
         return engine.bomp_encode(Xs, dd, self._k(dd.K), out=out, algorithm=self.algorithm)
 

@@ -440,6 +440,50 @@ def test_lasso_matches_oracle_and_kkt(eng, n, K, N, lam):
     assert int(steps.min().item()) < 0 and int(nnz.max().item()) == 1
 
 
+def test_lasso_non_unit_norm_and_ragged_shapes(eng):
+    """lasso on a dictionary whose atoms are NOT unit norm (the update divides by the true Gram diagonal) and on
+    ragged sizes (K = 1000 -> padded 1024, n = 37, N = 3): oracle agreement + KKT."""
+    from oracle import lyssa_oracle as orc
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    rs = np.random.RandomState(77)
+    for n, K, N, lam in [(37, 1000, 3, 0.2), (64, 300, 40, 0.3)]:
+        D = rs.randn(n, K)
+        D /= np.linalg.norm(D, axis=0)
+        D *= rs.uniform(0.5, 2.0, size=K)[None, :]            # atom norms in [0.5, 2]
+        X = D[:, rs.choice(K, 5, replace=False)] @ rs.randn(5, N) + 0.05 * rs.randn(n, N)
+        D = D.astype(np.float32).astype(np.float64)
+        X = X.astype(np.float32).astype(np.float64)
+        Z = sparse_encoder(algorithm='lasso', params={'lambda': lam, 'max_steps': 20000}, verbose=False).encode(X, D)
+        Zo = orc.lasso_encode(X, D, lam)
+        # n = 37 against K = 1000 is a very coherent dictionary: the fp32 KKT residual (~1e-5) is amplified by the
+        # conditioning of the active Gram block in the coefficients, so those get a looser bound than the residual
+        assert np.max(np.abs(Z - Zo)) < 2e-3 * np.abs(Zo).max()
+        assert orc.lasso_kkt_violation(X, D, Z, lam) < 5e-5
+
+
+def test_exact_ksvd_tiny_supports(eng):
+    """exact K-SVD when an atom is used by a single signal (rank-1 Rk: the eigen-solve's Krylov space is exhausted after
+    one step) and with n = 5 features."""
+    from oracle import lyssa_oracle as orc
+    from lyssandra_amd.dict_learning.ksvd import ksvd
+    rs = np.random.RandomState(9)
+    n, K, N = 5, 6, 12
+    D = rs.randn(n, K)
+    D = (D / np.linalg.norm(D, axis=0)).astype(np.float32).astype(np.float64)
+    X = rs.randn(n, N).astype(np.float32).astype(np.float64)
+    Z = np.zeros((K, N))
+    Z[0, 3] = 1.5                                              # atom 0: one signal
+    Z[1, [0, 1]] = [0.7, -0.2]                                 # atom 1: two signals
+    for i in range(N):
+        Z[2 + (i % 3), i] = rs.randn()                         # atoms 2..4: four signals each; atom 5 unused
+    Do, Zo, uo = orc.ksvd_exact(X, D.copy(), Z.copy())
+    Dh, Zh = D.copy(), Z.copy()
+    _, _, uh = ksvd(X, Dh, Zh, verbose=False)
+    assert list(uh) == list(uo) == [5]
+    assert _atom_err(Dh, Do) < 5e-5, _atom_err(Dh, Do)
+    assert np.max(np.abs(Zh - Zo)) < 5e-5 * np.abs(Zo).max()
+
+
 def test_online_dict_learn_with_lasso_coder(eng):
     """config-4 style: online DL driven by the l1 coder (device path end to end); the objective falls."""
     from lyssandra_amd.dict_learning import online_dictionary_coder
