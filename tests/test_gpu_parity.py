@@ -1069,3 +1069,23 @@ def test_bomp_template_sweep(eng, n, K, k):
     assert np.array_equal(idx[ok], oi[ok]) and np.array_equal(nnz[ok], on[ok])
     scale = np.abs(oc).max(axis=1, keepdims=True)
     assert np.max((np.abs(coef - oc) / scale)[ok]) < COEF_TOL
+
+
+@pytest.mark.parametrize("n,K,k", [(16, 64, 3), (32, 128, 8), (64, 256, 5), (64, 700, 10), (64, 1024, 10), (100, 1024, 20),
+                                   (64, 2048, 10), (64, 4096, 20)])
+def test_omp_template_sweep(eng, n, K, k):
+    """'omp' (`_omp`, sparse_coding.py:19-57: true Gram diagonal in the pivot) on NON-unit-norm dictionaries through the
+    same kernel families, against the numpy oracle on 120 signals."""
+    from oracle import lyssa_oracle as orc
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    rs = np.random.RandomState(n + K + k)
+    N = 120
+    D = rs.randn(n, K)
+    D = D / np.linalg.norm(D, axis=0) * rs.uniform(0.7, 1.4, size=K)[None, :]
+    D = D.astype(np.float32).astype(np.float64)
+    X = rs.randn(n, N).astype(np.float32).astype(np.float64)
+    Z = sparse_encoder(algorithm='omp', params={'n_nonzero_coefs': k}, verbose=False).encode(X, D)
+    Zo = orc.omp_encode(X, D, k)
+    same = np.array([np.array_equal(Z[:, i] != 0, Zo[:, i] != 0) for i in range(N)])
+    assert same.mean() > 0.95                                       # near-tie signals may pick another atom
+    assert np.abs(Z - Zo)[:, same].max() < 1e-5 * np.abs(Zo).max()
