@@ -58,10 +58,7 @@ class sparse_encoder(object):
             assert self.params.get('lambda') <= n_atoms
         self._check_algorithm()
         idx, coef, nnz = self.encode_sparse(X, D)
-        if self.mmap:
-            out = _empty_mmap((n_atoms, n_samples))
-        else:
-            out = np.zeros((n_atoms, n_samples))
+        out = _empty_mmap((n_atoms, n_samples)) if self.mmap else None
         return engine.densify(idx, coef, nnz, n_atoms, out=out)
 
     # -- extended API ----------------------------------------------------------------------------------
