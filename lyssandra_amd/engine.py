@@ -234,15 +234,25 @@ def densify(idx, coef, nnz, K, out=None):
             return Zh.numpy()                                    # shares the tensor's memory (kept alive through .base)
         out[:] = Zd.cpu().numpy()
         return out
-    # very large outputs: move only the triplet over PCIe and scatter on the host (format conversion only)
+    # very large outputs: column blocks of <= 1 GiB, each densified on the device and copied through one page-locked
+    # staging buffer into the (pageable) result
     if out is None:
-        out = np.zeros((K, N))
-    else:
-        out[:] = 0
-    hi, hc, hn = idx.cpu().numpy(), coef.cpu().numpy(), nnz.cpu().numpy()
-    valid = np.arange(k)[None, :] < hn[:, None]
-    cols = np.broadcast_to(np.arange(N)[:, None], (N, k))
-    out[hi[valid], cols[valid]] = hc[valid]
+        out = np.empty((K, N))
+    cols = max(1, (1 << 30) // (K * 8))
+    stage = None
+    for c0 in range(0, N, cols):
+        c1 = min(N, c0 + cols)
+        w = c1 - c0
+        Zd = torch.empty((K, w), dtype=torch.float64, device=idx.device)
+        _lib.check(lib.lys_densify_f64(_ptr(idx[c0:c1]), _ptr(coef[c0:c1]), _ptr(nnz[c0:c1]), K, k, w, _ptr(Zd),
+                                       _stream()), "lys_densify_f64")
+        if stage is None or stage.shape[1] != w:
+            try:
+                stage = torch.empty((K, w), dtype=torch.float64, pin_memory=True)
+            except RuntimeError:
+                stage = torch.empty((K, w), dtype=torch.float64)
+        stage.copy_(Zd)
+        out[:, c0:c1] = stage.numpy()
     return out
 
 
