@@ -14,32 +14,37 @@ int gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, 
             int Kin, hipStream_t stream, bool stream_c = false);
 int transpose(const float* src, int rows, int cols, int ld_src, float* dst, int ld_dst, hipStream_t stream);
 
-__global__ __launch_bounds__(256) void odl_increment_kernel(const float* __restrict__ X, int64_t ldx, int n, int Kp,
-                                                            int ldd, int k, const int32_t* __restrict__ idx,
-                                                            const float* __restrict__ coef,
-                                                            const int32_t* __restrict__ nnz,
-                                                            const int32_t* __restrict__ row_ptr,
-                                                            const int32_t* __restrict__ entry,
-                                                            float* __restrict__ dA, float* __restrict__ dB) {
+// One workgroup per atom, 64 teams of 16 lanes; a team takes every 64th signal of the atom (each signal is a chain of
+// dependent loads: entry -> coefficient / support row / patch row), so a workgroup keeps 64 chains in flight instead of
+// 4 (315 -> 273 us per 65 536-signal mini-batch at K = 1024: the rest is the latency of those chains).
+constexpr int ODL_THREADS = 1024;
+__global__ __launch_bounds__(ODL_THREADS) void odl_increment_kernel(const float* __restrict__ X, int64_t ldx, int n,
+                                                                    int Kp, int ldd, int k,
+                                                                    const int32_t* __restrict__ idx,
+                                                                    const float* __restrict__ coef,
+                                                                    const int32_t* __restrict__ nnz,
+                                                                    const int32_t* __restrict__ row_ptr,
+                                                                    const int32_t* __restrict__ entry,
+                                                                    float* __restrict__ dA, float* __restrict__ dB) {
     extern __shared__ float s_mem[];
     float* s_row = s_mem;       // [Kp]   row `a` of Z Z'
     float* s_b = s_mem + Kp;    // [ldd]  column `a` of X Z'
     const int a = blockIdx.x;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int x = threadIdx.x; x < Kp + ldd; x += 256) s_mem[x] = 0.f;
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    for (int x = threadIdx.x; x < Kp + ldd; x += ODL_THREADS) s_mem[x] = 0.f;
     __syncthreads();
     const int beg = row_ptr[a], end = row_ptr[a + 1];
-    for (int e = beg + wid; e < end; e += 4) {
+    for (int e = beg + team; e < end; e += ODL_THREADS / 16) {
         const int ss = entry[e];
         const int64_t sig = ss / k;
         const float xa = coef[ss];
         const int m = nnz[sig];
-        for (int j = lane; j < m; j += 64) atomicAdd(&s_row[idx[sig * k + j]], xa * coef[sig * k + j]);
-        for (int f = lane; f < n; f += 64) atomicAdd(&s_b[f], xa * X[sig * ldx + f]);
+        for (int j = q; j < m; j += 16) atomicAdd(&s_row[idx[sig * k + j]], xa * coef[sig * k + j]);
+        for (int f = q; f < n; f += 16) atomicAdd(&s_b[f], xa * X[sig * ldx + f]);
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < Kp; x += 256) dA[(int64_t)a * Kp + x] = s_row[x];
-    for (int f = threadIdx.x; f < ldd; f += 256) dB[(int64_t)a * ldd + f] = s_b[f];
+    for (int x = threadIdx.x; x < Kp; x += ODL_THREADS) dA[(int64_t)a * Kp + x] = s_row[x];
+    for (int f = threadIdx.x; f < ldd; f += ODL_THREADS) dB[(int64_t)a * ldd + f] = s_b[f];
 }
 
 int odl_increments(const float* X, int64_t ldx, int n, int K, int k, const int32_t* idx, const float* coef,
@@ -54,7 +59,7 @@ int odl_increments(const float* X, int64_t ldx, int n, int K, int k, const int32
     // rows >= K of dA/dB are written by nobody: the caller provides zeroed (or previously zero) buffers
     LYS_CHECK_HIP(hipMemsetAsync(dA, 0, (size_t)Kp * Kp * sizeof(float), stream));
     LYS_CHECK_HIP(hipMemsetAsync(dB, 0, (size_t)Kp * ldd * sizeof(float), stream));
-    hipLaunchKernelGGL(odl_increment_kernel, dim3(K), dim3(256), lds, stream, X, ldx, n, Kp, ldd, k, idx, coef, nnz,
+    hipLaunchKernelGGL(odl_increment_kernel, dim3(K), dim3(ODL_THREADS), lds, stream, X, ldx, n, Kp, ldd, k, idx, coef, nnz,
                        row_ptr, entry, dA, dB);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
