@@ -174,18 +174,42 @@ __global__ __launch_bounds__(64) void csr_count_or_fill_kernel(const int32_t* __
     __syncthreads();
     const int64_t s0 = (int64_t)chunk * S;
     const int64_t s1 = (s0 + S < N) ? s0 + S : N;
-    for (int64_t s = s0; s < s1; ++s) {
-        const int m = nnz[s];
-        for (int j = lane; j < m; j += 64) {
-            const int a = idx[s * k + j];
-            const float c = coef[s * k + j];
-            if (c != 0.f && a >= 0 && a < K) {
-                const int pos = atomicAdd(&s_cnt[a], 1);
-                if (fill) entry[pos] = (int32_t)(s * k + j);
+    if (k <= 64) {
+        // the usual case: one lane per slot.  The loads of U signals are issued together (slots past nnz hold idx = -1,
+        // coef = 0 and filter themselves out, so nnz is not on the dependency chain); the LDS adds follow signal by
+        // signal: atoms inside one signal are distinct, so the adds of one step never collide, and the next signal's
+        // adds are issued after these (same wave, in order) => signal order is preserved.
+        constexpr int U = 8;
+        for (int64_t sb = s0; sb < s1; sb += U) {
+            int av[U];
+            float cv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t s = sb + u;
+                const bool in = (s < s1) && (lane < k);
+                av[u] = in ? idx[s * k + lane] : -1;
+                cv[u] = in ? coef[s * k + lane] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (cv[u] != 0.f && av[u] >= 0 && av[u] < K) {
+                    const int pos = atomicAdd(&s_cnt[av[u]], 1);
+                    if (fill) entry[pos] = (int32_t)((sb + u) * k + lane);
+                }
             }
         }
-        // atoms inside one signal are distinct, so the LDS adds of one step never collide; the next
-        // signal's adds are issued after these (same wave, in order) => signal order is preserved.
+    } else {
+        for (int64_t s = s0; s < s1; ++s) {
+            const int m = nnz[s];
+            for (int j = lane; j < m; j += 64) {
+                const int a = idx[s * k + j];
+                const float c = coef[s * k + j];
+                if (c != 0.f && a >= 0 && a < K) {
+                    const int pos = atomicAdd(&s_cnt[a], 1);
+                    if (fill) entry[pos] = (int32_t)(s * k + j);
+                }
+            }
+        }
     }
     if (!fill) {
         __syncthreads();
