@@ -526,10 +526,14 @@ __global__ __launch_bounds__(16 * TEAMS) void ksvd_fused_kernel(int atom, int K,
     const bool blk_prev = do_a && (pbeg + blk * TEAMS < pend), blk_cur = do_b && (cbeg + blk * TEAMS < cend);
     if (!blk_prev && !blk_cur && !(blockIdx.x == 0 && have_prev)) return;  // uniform per block
 
-    // ---- d_new of the previous atom (fp64, every team redundantly; block 0 / team 0 publishes it)
+    // ---- d_new of the previous atom (fp64, per team; block 0 / team 0 publishes it).  Pass-A teams need it at once;
+    // a pass-B team needs it only for a signal that also uses the previous atom (about 1 % of them), so there it is
+    // computed on first use and the statistics load + fp64 normalisation leave the head of that pass' latency chain.
     float4 dold[FB], dnew[FB];
     float dd = 0.f;
-    if (have_prev) {
+    bool dnew_ready = false;
+    auto compute_dnew = [&]() {
+        dnew_ready = true;
         const double* s = sbuf + (int64_t)prev * (n + 1);
         const double sumsq = s[n];
         double v[FB][4];
@@ -565,7 +569,9 @@ __global__ __launch_bounds__(16 * TEAMS) void ksvd_fused_kernel(int atom, int K,
                 if (f < n) *reinterpret_cast<float4*>(Dnext + (int64_t)prev * ldd + f) = dnew[b];
             }
         }
-    }
+    };
+    // (deferring it behind the first residual-row load in pass A as well was measured slower: 10.0 vs 9.2 ms/sweep)
+    if (have_prev && (do_a || blockIdx.x == 0)) compute_dnew();
     // apply the pending update of `prev` to the residual row held in r[] (coefficient slot ss_prev)
     auto apply_prev = [&](float4 (&r)[FB], int ss_prev) {
         const float xo = coef[ss_prev];
@@ -644,6 +650,7 @@ __global__ __launch_bounds__(16 * TEAMS) void ksvd_fused_kernel(int atom, int K,
         if (have_prev) {
             const int sp = find_slot(sig, prev);
             if (sp >= 0) {
+                if (!dnew_ready) compute_dnew();
                 apply_prev(r, (int)(sig * k + sp));
                 store_row(r, sig);
             }
