@@ -628,9 +628,9 @@ __global__ __launch_bounds__(16 * TEAMS) void ksvd_fused_kernel(int atom, int K,
         for (int e = pbeg + gteam; e < pend; e += nteams) {
             const int ss = entry[e];
             const int64_t sig = ss / k;
-            if (have_cur && find_slot(sig, atom) >= 0) continue;  // uniform per team
             float4 r[FB];
-            load_row(r, sig);
+            load_row(r, sig);  // issued before the ownership test: the row and the support row travel together
+            if (have_cur && find_slot(sig, atom) >= 0) continue;  // uniform per team
             apply_prev(r, ss);
             store_row(r, sig);
         }
