@@ -860,9 +860,9 @@ __device__ __forceinline__ double block_sum_d(double x, double* pr /* [256] */, 
 
 // One workgroup (256 threads).  Dynamic LDS: Q[(EIG_M + 1) * n] doubles.
 __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const int32_t* __restrict__ row_ptr,
-                                                       const double* __restrict__ C, const float* __restrict__ D,
-                                                       int ldd, float* __restrict__ Dnext) {
-    extern __shared__ __attribute__((aligned(16))) double Q[];  // [EIG_M + 1][n]
+                                                       const double* __restrict__ Cg, const float* __restrict__ D,
+                                                       int ldd, float* __restrict__ Dnext, int c_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) double Q[];  // [EIG_M + 1][n], then (c_in_lds) a copy of C [n][n]
     __shared__ double H[EIG_M][EIG_M], T[EIG_M][EIG_M];
     __shared__ double hh[EIG_M + 1], red[16], wv[256], pr[256], cvec[EIG_M];
     __shared__ int m_used;
@@ -877,6 +877,13 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
         if (tid < n) Q[tid] = q0;
     }
     if (tid == 0) m_used = EIG_M;
+    // small n: C (32 KB at n = 64) is copied into LDS once, the 32 matrix-vector products then never leave the CU
+    const double* C = Cg;
+    if (c_in_lds) {
+        double* Cl = Q + (int64_t)(EIG_M + 1) * n;
+        for (int i = tid; i < n * n; i += 256) Cl[i] = Cg[i];
+        C = Cl;
+    }
     __syncthreads();
     double scale0 = 0.0;
     int m = 0;
@@ -1061,7 +1068,8 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     static bool attr_set[64] = {};
     int dev = 0;
     LYS_CHECK_HIP(hipGetDevice(&dev));
-    const size_t eig_lds = (size_t)(EIG_M + 1) * n * sizeof(double);
+    const int c_in_lds = (n <= 64) ? 1 : 0;
+    const size_t eig_lds = ((size_t)(EIG_M + 1) * n + (c_in_lds ? (size_t)n * n : 0)) * sizeof(double);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ksvd_eig_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (EIG_M + 1) * 256 * (int)sizeof(double)));
@@ -1073,7 +1081,7 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
         LYS_CHECK_HIP(hipMemsetAsync(work, 0, (size_t)n * n * sizeof(double), stream));
         hipLaunchKernelGGL(ksvd_gram_kernel, dim3(gx, nb * (nb + 1) / 2), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
                            entry, coef, D, ldd, work);
-        hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, a, n, row_ptr, work, D, ldd, Dnext);
+        hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, a, n, row_ptr, work, D, ldd, Dnext, c_in_lds);
         switch (fb) {
             case 1: hipLaunchKernelGGL(ksvd_exact_apply_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
             case 2: hipLaunchKernelGGL(ksvd_exact_apply_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
