@@ -148,7 +148,7 @@ int lys_ksvd_atom_apply(int atom, float* R, int64_t ldr, int n, int k,
  * singular triplet (u, sigma, v) of Rk = R[:, omega] + d_old x_omega replaces (d, x_omega) and R[:, omega] = Rk - u sigma v'.
  * The reference calls sklearn's randomized_svd(n_iter=10, flip_sign=False) (random sign, not bit-reproducible);
  * here, per atom: C = Rk Rk' (n x n, fp64), its leading eigenvector u by Lanczos with full re-orthogonalisation
- * (<= 32 steps, started at d_old) + Rayleigh-Ritz, then x_omega = Rk'u; sign u . d_old >= 0.
+ * (<= 24 steps, started at d_old) + Rayleigh-Ritz, then x_omega = Rk'u; sign u . d_old >= 0.
  * work: lys_ksvd_exact_workspace_bytes(n).  max_support >= max_a |omega_a| (N is always valid).  Unused atoms keep
  * their column.  Single GPU.
  */

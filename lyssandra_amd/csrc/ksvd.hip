@@ -758,7 +758,7 @@ int ksvd_commit(int n, int K, const int32_t* row_ptr, const float* Dnext, float*
 // Exact rank-1 K-SVD atom update (lyssa/dict_learning/ksvd.py:19-43).  The reference takes the leading singular
 // triplet of Rk = R[:, omega] + d_old x_omega with sklearn's randomized_svd(n_components=1, n_iter=10).  Here, per atom:
 //   1. ksvd_gram_kernel   C = Rk Rk' (n x n, fp64 atomics of fp32 64x64 register tiles; one pass over the atom's rows)
-//   2. ksvd_eig_kernel    leading eigenvector u of C: Lanczos with full re-orthogonalisation (<= 32 steps, one
+//   2. ksvd_eig_kernel    leading eigenvector u of C: Lanczos with full re-orthogonalisation (<= 24 steps, one
 //                         workgroup, basis in LDS, C read from L2) + Rayleigh-Ritz on the small projected matrix
 //   3. ksvd_exact_apply_kernel   x_i = rk_i . u (= sigma v_i), R_i = rk_i - u x_i
 // Sign convention: u . d_old >= 0 (the reference's sign is arbitrary, flip_sign=False).
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) void ksvd_gram_kernel(int atom, const float* _
         }
 }
 
-constexpr int EIG_M = 32;  // Lanczos steps (Krylov dimension)
+constexpr int EIG_M = 24;  // Lanczos steps (Krylov dimension)
 
 // sum over the 256 threads of the workgroup through LDS (two levels of 16; no cross-lane fp64 shuffles)
 __device__ __forceinline__ double block_sum_d(double x, double* pr /* [256] */, double* red /* [16] */) {
@@ -965,17 +965,22 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
         mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
         if (!(mx > 0.0)) break;
         const double inv = 1.0 / mx;
-        double tnew[4];
+        constexpr int PER = (EIG_M * EIG_M + 255) / 256;  // entries of the projected matrix per thread
+        double tnew[PER];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = tid + 256 * e, r = i / EIG_M, c = i % EIG_M;
+        for (int e = 0; e < PER; ++e) {
+            const int i = tid + 256 * e;
             double t = 0.0;
-            for (int l = 0; l < EIG_M; ++l) t = fma(T[r][l] * inv, T[l][c] * inv, t);
+            if (i < EIG_M * EIG_M) {
+                const int r = i / EIG_M, c = i % EIG_M;
+                for (int l = 0; l < EIG_M; ++l) t = fma(T[r][l] * inv, T[l][c] * inv, t);
+            }
             tnew[e] = t;
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) (&T[0][0])[tid + 256 * e] = tnew[e];
+        for (int e = 0; e < PER; ++e)
+            if (tid + 256 * e < EIG_M * EIG_M) (&T[0][0])[tid + 256 * e] = tnew[e];
         __syncthreads();
     }
     if (tid == 0) {
