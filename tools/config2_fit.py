@@ -1,0 +1,21 @@
+"""configs[1] end to end through the drop-in class: ksvd_coder(approx=True).fit on 2^20 synthetic 8x8 patches (host float64
+array in), 1024 atoms, k = 10, max_iter = 50 (the reference's patience quirk stops it after 11 iterations)."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from lyssandra_amd.dict_learning import ksvd_coder
+from lyssandra_amd.sparse_coding import sparse_encoder
+
+n, K, k, N = 64, 1024, 10, 1 << 20
+rs = np.random.RandomState(0)
+X = rs.randn(n, N)
+se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+np.random.seed(1)
+kc = ksvd_coder(n_atoms=K, sparse_coder=se, max_iter=50, approx=True, verbose=False)
+t0 = time.perf_counter()
+kc.fit(X)
+t = time.perf_counter() - t0
+print("ksvd_coder.fit: N=%d K=%d k=%d max_iter=50 -> %.2f s wall (host float64 input, 11 alternations), D %s"
+      % (N, K, k, t, kc.D.shape))
