@@ -19,7 +19,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
     has_pmc = cur.execute("select count(*) from pmc_events").fetchone()[0] > 0
     if not has_pmc:
         print("== rocprofv3 --kernel-trace --stats :: %s ==" % os.path.relpath(f, root))
-        print("%-86s %7s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+        print("%-86s %7s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, calls, tot, avg, pct in cur.execute(
                 "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 16"):
             print("%-86s %7d %14d %12.0f %7.2f" % (short(name), calls, tot, avg, pct))
