@@ -6,7 +6,7 @@ from ..utils.math import norm_cols, normalize as _normalize
 
 
 def init_dictionary(X, n_atoms, method='data', return_unused_data=False, normalize=True):
-    """lyssa/dict_learning/utils.py:35-75, method='data' (and 'random').
+    """lyssa/dict_learning/utils.py:35-75, methods 'data', 'random' and 'svd'.
 
     Host logic, global numpy RNG exactly like the reference (:60): candidates are the columns with energy
     > 1e-6, ``np.random.choice(len(idxs), n_atoms, replace=False)``, D = X[:, chosen] (a copy), optional
@@ -30,7 +30,15 @@ def init_dictionary(X, n_atoms, method='data', return_unused_data=False, normali
     if method == "random":
         D = np.random.randn(X.shape[0], n_atoms)
         return norm_cols(D)
-    raise NotImplementedError("init_dictionary(method=%r) is outside the accelerated path" % (method,))
+    if method == "svd":
+        # :38-48: left singular vectors of X, zero-padded when n_atoms exceeds the rank (one-off host LAPACK call on an
+        # n x N matrix, like the reference; the reference computes the matching codes too but returns only D)
+        U, _, _ = np.linalg.svd(X, full_matrices=False)
+        r = U.shape[1]
+        if n_atoms <= r:
+            return np.array(U[:, :n_atoms], dtype=np.float64)
+        return np.c_[U, np.zeros((U.shape[0], n_atoms - r))]
+    raise ValueError("init_dictionary: unknown method %r" % (method,))
 
 
 def approx_error(D, Z, X, n_jobs=1):

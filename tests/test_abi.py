@@ -102,6 +102,21 @@ def test_init_dictionary_reference_unit_test():
     assert np.array_equal(D1, D2) and u1 == u2
 
 
+def test_init_dictionary_svd_and_random():
+    """dict_learning/utils.py:38-48,72-74: 'svd' (truncated / zero-padded left singular vectors) and 'random'."""
+    from lyssandra_amd.dict_learning.utils import init_dictionary
+    rs = np.random.RandomState(0)
+    X = rs.randn(6, 40)
+    U = np.linalg.svd(X, full_matrices=False)[0]
+    assert np.allclose(init_dictionary(X, 4, method='svd'), U[:, :4])
+    D9 = init_dictionary(X, 9, method='svd')
+    assert D9.shape == (6, 9) and np.allclose(D9[:, :6], U) and np.all(D9[:, 6:] == 0)
+    Dr = init_dictionary(X, 11, method='random')
+    assert Dr.shape == (6, 11) and np.allclose(np.linalg.norm(Dr, axis=0), 1.0)
+    with pytest.raises(ValueError):
+        init_dictionary(X, 4, method='nope')
+
+
 def test_run_parallel_matches_reference_semantics():
     """lyssa/utils/__init__.py:40-163: one call for n_jobs == 1, else even column batches scattered back --
     identical results either way (n_jobs=1 vs n_jobs=4/8 bit-identical)."""
