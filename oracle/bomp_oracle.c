@@ -123,3 +123,98 @@ void lyso_bomp(const double* X, const double* D, const double* G, int n, int K, 
         free(a0); free(a); free(L); free(w); free(z); free(y);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * approximate K-SVD atom update, float64, on the sparse triplet (TEST INFRASTRUCTURE ONLY).
+ * Restates lyssa/dict_learning/ksvd.py:98-126 (`approx_ksvd`): R = Y - DX (:103); for every cycle, atoms in order
+ * 0..K-1 (:105-106): omega = X[k,:] != 0 evaluated on the CURRENT coefficients (:111), skip + record when empty
+ * (:112-115); Rk = R[:,omega] + d_k x_k (:116); d_k = normalize(Rk x_k) = v / (||v|| + eps) (:118-119,
+ * utils/math.py:61-62); x_k = Rk' d_k (:121); R[:,omega] = Rk - d_k x_k (:123).
+ * The reference's dense X (K,N) is 8 GB at config 2, so the codes stay in the triplet the engine uses: idx [N][k]
+ * (-1 padded), coef [N][k] (updated in place), nnz [N].  X [N][n] signal-major, D [K][n] atom-major (updated in
+ * place).  unused [K * n_cycles] receives the skipped atoms in visiting order, the return value is their number.
+ * err (optional) receives ||Y - D X||_F^2 of the result, recomputed from scratch.
+ * Pinned against oracle/lyssa_oracle.py::approx_ksvd and golden F5 in tests/test_oracle_golden.py.
+ */
+int lyso_approx_ksvd(const double* X, double* D, int n, int K, int k, int64_t N, const int32_t* idx, double* coef,
+                     const int32_t* nnz, int n_cycles, int32_t* unused, double* err) {
+    double* R = (double*)malloc((size_t)N * n * sizeof(double));
+    /* candidate lists by atom (signals ascending): every stored slot, zero or not; omega is filtered at visit time */
+    int64_t* ptr = (int64_t*)calloc((size_t)K + 1, sizeof(int64_t));
+    for (int64_t s = 0; s < N; ++s)
+        for (int j = 0; j < nnz[s]; ++j) ptr[idx[s * k + j] + 1]++;
+    for (int a = 0; a < K; ++a) ptr[a + 1] += ptr[a];
+    int64_t* fill = (int64_t*)malloc((size_t)K * sizeof(int64_t));
+    memcpy(fill, ptr, (size_t)K * sizeof(int64_t));
+    int64_t* ent = (int64_t*)malloc((size_t)(ptr[K] > 0 ? ptr[K] : 1) * sizeof(int64_t));
+    for (int64_t s = 0; s < N; ++s)
+        for (int j = 0; j < nnz[s]; ++j) ent[fill[idx[s * k + j]]++] = s * k + j;
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < N; ++s) { /* R = Y - D X */
+        double* r = R + (size_t)s * n;
+        memcpy(r, X + (size_t)s * n, (size_t)n * sizeof(double));
+        for (int j = 0; j < nnz[s]; ++j) {
+            const double c = coef[s * k + j];
+            const double* d = D + (size_t)idx[s * k + j] * n;
+            for (int f = 0; f < n; ++f) r[f] -= d[f] * c;
+        }
+    }
+    int n_unused = 0;
+    double* v = (double*)malloc((size_t)n * sizeof(double));
+    double* dold = (double*)malloc((size_t)n * sizeof(double));
+    for (int cyc = 0; cyc < n_cycles; ++cyc) {
+        for (int a = 0; a < K; ++a) {
+            double* d = D + (size_t)a * n;
+            int64_t used = 0;
+            memset(v, 0, (size_t)n * sizeof(double));
+            /* v = Rk x_k = sum_i (R_i + d x_i) x_i */
+#pragma omp parallel for schedule(static) reduction(+ : v[:n]) reduction(+ : used)
+            for (int64_t e = ptr[a]; e < ptr[a + 1]; ++e) {
+                const double x = coef[ent[e]];
+                if (x == 0.0) continue;
+                ++used;
+                const double* r = R + (size_t)(ent[e] / k) * n;
+                for (int f = 0; f < n; ++f) v[f] += (r[f] + d[f] * x) * x;
+            }
+            if (used == 0) {
+                unused[n_unused++] = a;
+                continue;
+            }
+            double nrm = 0.0;
+            for (int f = 0; f < n; ++f) nrm += v[f] * v[f];
+            nrm = sqrt(nrm) + EPS64;
+            memcpy(dold, d, (size_t)n * sizeof(double));
+            for (int f = 0; f < n; ++f) d[f] = v[f] / nrm;
+#pragma omp parallel for schedule(static)
+            for (int64_t e = ptr[a]; e < ptr[a + 1]; ++e) {
+                const double x = coef[ent[e]];
+                if (x == 0.0) continue;
+                double* r = R + (size_t)(ent[e] / k) * n;
+                double xn = 0.0;
+                for (int f = 0; f < n; ++f) {
+                    r[f] += dold[f] * x; /* Rk column */
+                    xn += r[f] * d[f];
+                }
+                for (int f = 0; f < n; ++f) r[f] -= d[f] * xn;
+                coef[ent[e]] = xn;
+            }
+        }
+    }
+    if (err) {
+        double tot = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : tot)
+        for (int64_t s = 0; s < N; ++s) {
+            const double* x = X + (size_t)s * n;
+            double e2 = 0.0;
+            for (int f = 0; f < n; ++f) {
+                double r = x[f];
+                for (int j = 0; j < nnz[s]; ++j) r -= D[(size_t)idx[s * k + j] * n + f] * coef[s * k + j];
+                e2 += r * r;
+            }
+            tot += e2;
+        }
+        *err = tot;
+    }
+    free(R); free(ptr); free(fill); free(ent); free(v); free(dold);
+    return n_unused;
+}

@@ -45,3 +45,26 @@ def bomp_encode_sparse(X, D, k):
     lib.lyso_bomp(P(Xs), P(Da), P(G), ctypes.c_int(n), ctypes.c_int(K), ctypes.c_int(k), ctypes.c_int64(N), P(idx),
                   P(coef), P(nnz), P(gap))
     return idx, coef, nnz, gap
+
+
+def approx_ksvd_sparse(X, D, idx, coef, nnz, n_cycles=1):
+    """float64 approx K-SVD sweep on the sparse triplet (lyssa/dict_learning/ksvd.py:98-126).
+
+    X (n, N), D (n, K) -> (D_new (n, K), coef_new [N, k], unused list, error).  Inputs are not modified."""
+    lib = load()
+    X = np.asarray(X, dtype=np.float64)
+    n, N = X.shape
+    K = np.asarray(D).shape[1]
+    Xs = np.ascontiguousarray(X.T)
+    Da = np.ascontiguousarray(np.asarray(D, dtype=np.float64).T)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    coef = np.array(coef, dtype=np.float64, order='C', copy=True)
+    nnz = np.ascontiguousarray(nnz, dtype=np.int32)
+    k = idx.shape[1]
+    unused = np.empty(max(1, K * n_cycles), dtype=np.int32)
+    err = ctypes.c_double(0.0)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    lib.lyso_approx_ksvd.restype = ctypes.c_int
+    nu = lib.lyso_approx_ksvd(P(Xs), P(Da), ctypes.c_int(n), ctypes.c_int(K), ctypes.c_int(k), ctypes.c_int64(N),
+                              P(idx), P(coef), P(nnz), ctypes.c_int(n_cycles), P(unused), ctypes.byref(err))
+    return np.ascontiguousarray(Da.T), coef, unused[:nu].tolist(), float(err.value)

@@ -183,20 +183,26 @@ def densify(idx, coef, nnz, K):
 
 
 # --------------------------------------------------------------------------- 'omp' and 'thresh' 
-def omp_signal(x, D, Gram, alpha, n_nonzero_coefs):
+def omp_signal(x, D, Gram, alpha, n_nonzero_coefs, want_gap=False):
     """lyssa/sparse_coding.py:19-57 (`_omp`, fixed sparsity): residual-domain OMP.  argmax|alpha| :39, stop on
     re-selection :40-41, z[Dx] = inv(G[Dx,Dx]) (D'x)[Dx] :44-52 (TRUE Gram diagonal, unlike batch_omp),
-    r = x - D[:,Dx] z :53, alpha = D'r :54; loop while i < k and ||r|| > 1e-10 :27-31."""
+    r = x - D[:,Dx] z :53, alpha = D'r :54; loop while i < k and ||r|| > 1e-10 :27-31.
+    ``want_gap`` also returns the minimum relative top-1/top-2 gap of |alpha| along the greedy path (tie classifier of
+    the parity tests, same definition as batch_omp_signal)."""
     K = D.shape[1]
     Dx = []
     z = np.zeros(K)
     r = np.copy(x)
     i = 0
     a0 = np.dot(D.T, x)
+    min_gap = np.inf
     while i < n_nonzero_coefs and norm(r) > 1e-10:
         kk = int(np.argmax(np.abs(alpha)))
         if kk in Dx:
             break
+        if want_gap and K > 1:
+            two = np.partition(np.abs(alpha), K - 2)[K - 2:]
+            min_gap = min(min_gap, (two[1] - two[0]) / two[1] if two[1] > 0 else 0.0)
         Dx.append(kk)
         Gs = np.atleast_2d(Gram[Dx, :][:, Dx])
         try:
@@ -207,17 +213,34 @@ def omp_signal(x, D, Gram, alpha, n_nonzero_coefs):
         r = x - np.dot(D[:, Dx], z[Dx])
         alpha = np.dot(D.T, r)
         i += 1
+    if want_gap:
+        return z, (min_gap if np.isfinite(min_gap) else 0.0)
     return z
 
 
-def omp_encode(X, D, k):
-    """sparse_encoder 'omp' branch: lyssa/sparse_coding.py:620-627 + `omp` :60-66."""
+def omp_encode(X, D, k, want_gap=False):
+    """sparse_encoder 'omp' branch: lyssa/sparse_coding.py:620-627 + `omp` :60-66.  ``want_gap`` -> (Z, gap [N])."""
     Gram = fast_dot(D.T, D)
     Alpha = fast_dot(D.T, X)
     Z = np.zeros((D.shape[1], X.shape[1]))
+    gap = np.zeros(X.shape[1])
     for i in range(X.shape[1]):
-        Z[:, i] = omp_signal(X[:, i], D, Gram, Alpha[:, i], k)
-    return Z
+        if want_gap:
+            Z[:, i], gap[i] = omp_signal(X[:, i], D, Gram, Alpha[:, i], k, want_gap=True)
+        else:
+            Z[:, i] = omp_signal(X[:, i], D, Gram, Alpha[:, i], k)
+    return (Z, gap) if want_gap else Z
+
+
+def thresh_gap(Alpha, n_nonzero_coefs):
+    """Tie classifier of 'thresh': relative gap between the k-th and the (k+1)-th largest SIGNED correlation of every
+    column (the only place where rounding can change the selected set of sparse_coding.py:416-425)."""
+    K, N = Alpha.shape
+    if n_nonzero_coefs >= K:
+        return np.full(N, np.inf)
+    srt = np.sort(Alpha, axis=0)[::-1]
+    a, b = srt[n_nonzero_coefs - 1], srt[n_nonzero_coefs]
+    return (a - b) / np.maximum(np.abs(Alpha).max(axis=0), 1e-300)
 
 
 def thresholding(Alpha, nonzero_percentage=None, n_nonzero_coefs=None):

@@ -1,0 +1,157 @@
+"""GPU parity at the sizes / shapes of BASELINE.json's configs that the small golden fixtures do not reach.
+
+  * config 2 (approx K-SVD, 2^20 patches of 64 dims, 1024 atoms, k = 10): the device sweep against the float64 C
+    restatement of `approx_ksvd` (oracle/bomp_oracle.c::lyso_approx_ksvd, pinned to the reference's F5 outputs) --
+    atoms, codes and error to 1e-5, one and two cycles.  This is the regime where an atom's support spans hundreds of
+    workgroups (cross-workgroup fp64 reductions, ownership splits), which F5 (80 signals per atom) never enters.
+  * config 4 shape (online DL, n = 128, K = 8192, mini-batch 32 768, l1 coder): KKT of the device lasso codes in
+    float64 and the A / B / D update against the float64 oracle update computed from the same codes.
+  * config 3 per-GPU shard (12.5 M signals of 256 dims, K = 4096, k = 20): size-independent properties.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from lyssandra_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def _atom_err(D, Dref):
+    return np.max(np.linalg.norm(D - Dref, axis=0) / np.maximum(np.linalg.norm(Dref, axis=0), 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ config 2
+@pytest.mark.parametrize("N,cycles", [(1 << 20, 1), (1 << 18, 2)])
+def test_approx_ksvd_sweep_config2_size(eng, N, cycles):
+    """lyssa/dict_learning/ksvd.py:98-126 at configs[1] size, from the engine's own Batch-OMP codes."""
+    import torch
+    from oracle import c_oracle
+    n, K, k = 64, 1024, 10
+    gen = torch.Generator(device="cuda").manual_seed(1234 + cycles)
+    Dt = torch.randn((n, K), device="cuda", generator=gen)
+    Dt = Dt / Dt.norm(dim=0, keepdim=True)
+    Xs = torch.randn((N, n), device="cuda", generator=gen)
+    dd = eng.DeviceDictionary(n, K)
+    dd.set(Dt)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    h_idx, h_coef0, h_nnz = idx.cpu().numpy(), coef.double().cpu().numpy(), nnz.cpu().numpy()
+    D0 = dd.D[:K, :n].t().contiguous().double().cpu().numpy()       # the fp32 values the engine starts from
+    X = Xs.t().contiguous().double().cpu().numpy()
+    R, err0 = eng.residual(Xs, dd, idx, coef, nnz)
+    buffers = {}
+    unused = []
+    for _ in range(cycles):
+        unused += eng.ksvd_cycle(R, dd, idx, coef, nnz, buffers=buffers)
+    err_dev = eng.approx_error(Xs, dd, idx, coef, nnz)
+    # the maintained residual must still be X - D Z for the NEW D and Z (Gauss-Seidel bookkeeping intact)
+    R2, _ = eng.residual(Xs, dd, idx, coef, nnz)
+    drift = (R[:, :n] - R2[:, :n]).abs().max().item()
+    assert drift < 2e-5 * Xs.abs().max().item(), drift
+    Do, co, uo, err_o = c_oracle.approx_ksvd_sparse(X, D0, h_idx, h_coef0, h_nnz, n_cycles=cycles)
+    assert unused == uo
+    Dg = dd.to_host()
+    ae = _atom_err(Dg, Do)
+    ce = np.max(np.abs(coef.double().cpu().numpy() - co)) / np.abs(co).max()
+    ee = abs(err_dev - err_o) / err_o
+    print("N=%d cycles=%d: atom err %.3g, code err %.3g (of max|z|), error rel %.3g, err %.6g -> %.6g"
+          % (N, cycles, ae, ce, ee, err0, err_dev))
+    assert ae < 1e-5 and ce < 1e-5 and ee < 1e-5
+    assert err_dev < err0                                             # the sweep lowers the objective
+
+
+# ------------------------------------------------------------------------------------------------ config 4 shape
+def test_online_dl_config4_shape(eng):
+    """lyssa/dict_learning/online_dict_learn.py:84-98 with the l1 coder (sparse_coding.py:487-509) at n = 128,
+    K = 8192, two mini-batches of 32 768 signals (beta_i = 0 then 0.9)."""
+    import scipy.sparse as sp
+    import torch
+    from oracle import lyssa_oracle as orc
+    n, K, bs, lam = 128, 8192, 32768, 0.2
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    Dt = torch.randn((n, K), device="cuda", generator=gen)
+    Dt = Dt / Dt.norm(dim=0, keepdim=True)
+    Xs = torch.randn((2 * bs, n), device="cuda", generator=gen)
+    Xs = Xs / Xs.norm(dim=1, keepdim=True)
+    dd = eng.DeviceDictionary(n, K)
+    dd.set(Dt)
+    state = eng.OdlState(dd)
+    Do = dd.to_host()
+    Ao, Bo = np.zeros((K, K)), np.zeros((n, K))
+    for b, beta_i in enumerate([0.0, 0.9]):
+        xb = Xs[b * bs:(b + 1) * bs]
+        idx, coef, nnz, steps = eng.lasso_encode(xb, dd, lam, return_steps=True)
+        st = steps.cpu().numpy()
+        assert st.min() >= 0 and st.max() < 50 * n, (st.min(), st.max())       # converged, no truncated support
+        hi, hc, hn = idx.cpu().numpy(), coef.double().cpu().numpy(), nnz.cpu().numpy()
+        assert hn.max() <= n and hn.mean() > 2
+        X = xb.t().contiguous().double().cpu().numpy()
+        Dcur = dd.to_host()
+        # KKT of min 0.5||x - Da||^2 + lam||a||_1 in float64 on a subsample (dense Z of the whole batch is 2 GB)
+        sub = np.arange(0, bs, 16)
+        Zsub = orc.densify(hi[sub], hc[sub], hn[sub], K)
+        kkt = orc.lasso_kkt_violation(X[:, sub], Dcur, Zsub, lam)
+        assert kkt < 1e-5, kkt
+        # statistics + dictionary update from the SAME codes, float64 (sparse Z on the host)
+        valid = np.arange(hi.shape[1])[None, :] < hn[:, None]
+        cols = np.broadcast_to(np.arange(bs)[:, None], hi.shape)
+        Zs = sp.csr_matrix((hc[valid], (hi[valid], cols[valid])), shape=(K, bs))
+        Ao = beta_i * Ao + (Zs @ Zs.T).toarray()
+        Bo = beta_i * Bo + (Zs @ X.T).T
+        DA = Dcur @ Ao
+        Dn = Dcur + (Bo - DA) / (np.diag(Ao) + orc.EPS64)[None, :]
+        Do = orc.norm_cols(Dn)
+        state.batch_update(xb, idx, coef, nnz, beta_i)
+        Ag, Bg = state.A_host(), state.B_host()
+        ea = np.max(np.abs(Ag - Ao)) / np.abs(Ao).max()
+        eb = np.max(np.abs(Bg - Bo)) / np.abs(Bo).max()
+        ed = _atom_err(dd.to_host(), Do)
+        print("batch %d: nnz mean %.1f max %d, steps max %d, KKT %.2e, A err %.2e, B err %.2e, atom err %.2e"
+              % (b, hn.mean(), hn.max(), st.max(), kkt, ea, eb, ed))
+        assert ea < 1e-5 and eb < 1e-5 and ed < 1e-5
+        dd.set(Do)                                                   # next batch starts from the oracle's dictionary
+
+
+# ------------------------------------------------------------------------------------------------ config 3 shard
+def test_bomp_config3_per_gpu_shard_properties(eng):
+    """configs[2]: one GPU's shard of the 100 M-signal job (12.5 M signals of 256 dims = 12.8 GB, K = 4096, k = 20):
+    k distinct valid atoms per signal, residual orthogonal to the support, sharding invariance (bit-identical)."""
+    import torch
+    n, K, k, N = 256, 4096, 20, 12_500_000
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    Dt = torch.randn((n, K), device="cuda", generator=gen)
+    Dt = Dt / Dt.norm(dim=0, keepdim=True)
+    Xs = torch.empty((N, n), device="cuda", dtype=torch.float32)
+    step = 1 << 20
+    for s in range(0, N, step):
+        Xs[s:s + step].normal_(generator=gen)
+    dd = eng.DeviceDictionary(n, K)
+    dd.set(Dt)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print("config-3 shard: %.2f s, %.2f M patches/s" % (dt, N / dt / 1e6))
+    assert int(nnz.min()) == k and int(nnz.max()) == k
+    assert int(idx.min()) >= 0 and int(idx.max()) < K
+    for s in range(0, N, 1 << 21):                                   # distinct atoms, checked in slabs
+        srt = torch.sort(idx[s:s + (1 << 21)], dim=1).values
+        assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    Dam = dd.D[:K, :n]
+    for s0 in (0, N // 2, N - (1 << 15)):                            # residual orthogonal to the support
+        sub = slice(s0, s0 + (1 << 15))
+        atoms = Dam[idx[sub].long()]
+        r = Xs[sub] - torch.einsum("mk,mkn->mn", coef[sub], atoms)
+        corr = torch.einsum("mn,mkn->mk", r, atoms).abs().max().item()
+        assert corr < 1e-3, corr
+        assert (r.norm(dim=1) < Xs[sub].norm(dim=1)).all()
+    # sharding invariance: an unaligned slice encoded on its own (remainder-style boundaries) is bit-identical
+    a, b = 5_000_003, 5_000_003 + 300_001
+    i2, c2, z2 = eng.bomp_encode(Xs[a:b], dd, k)
+    assert torch.equal(i2, idx[a:b]) and torch.equal(c2, coef[a:b]) and torch.equal(z2, nnz[a:b])

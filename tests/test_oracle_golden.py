@@ -276,3 +276,42 @@ def test_c_oracle_matches_numpy_oracle_and_reference():
         X, D, k = g[case + "_X"].astype(np.float64), g[case + "_D"].astype(np.float64), int(g[case + "_k"])
         Z = orc.densify(*c_oracle.bomp_encode_sparse(X, D, k)[:3], D.shape[1])
         assert np.array_equal(Z != 0, g[case + "_Z"] != 0) and np.max(np.abs(Z - g[case + "_Z"])) <= 1e-12, case
+
+
+def test_c_oracle_approx_ksvd_matches_reference_and_numpy_oracle():
+    """oracle/bomp_oracle.c::lyso_approx_ksvd (sparse-triplet float64 sweep used for the config-2-size GPU parity run)
+    against the reference's own per-iteration outputs (F5) and the numpy oracle, unused atoms and n_cycles=2 included."""
+    from oracle import c_oracle
+    g = load_golden("F5")
+    X = g["X"].astype(np.float64)
+    k = int(g["k"])
+    for it in range(3):
+        Dprev = g["D0"].astype(np.float64) if it == 0 else g["it%d_D" % (it - 1)]
+        gi, gc_in, gn = g["it%d_idx" % it], g["it%d_coef_in" % it], g["it%d_nnz" % it]
+        D, coef, unused, err = c_oracle.approx_ksvd_sparse(X, Dprev, gi, gc_in, gn, n_cycles=1)
+        assert np.max(np.abs(D - g["it%d_D" % it])) <= 1e-10
+        assert np.max(np.abs(coef - g["it%d_coef" % it])) <= 1e-10
+        assert unused == list(g["it%d_unused" % it])
+        assert abs(err - float(g["it%d_err" % it])) <= 1e-8 * float(g["it%d_err" % it])
+    D, _, _, _ = c_oracle.approx_ksvd_sparse(X, g["D0"].astype(np.float64), g["it0_idx"], g["it0_coef_in"],
+                                             g["it0_nnz"], n_cycles=2)
+    assert np.max(np.abs(D - g["cyc2_D"])) <= 1e-10
+    # a shape with unused atoms, ragged supports and a coefficient that is exactly zero, against the numpy oracle
+    rs = np.random.RandomState(5)
+    n, K, kk, N = 24, 40, 4, 300
+    Dm = orc.norm_cols(rs.randn(n, K))
+    Xm = rs.randn(n, N)
+    idx = -np.ones((N, kk), dtype=np.int32)
+    coef = np.zeros((N, kk))
+    nnz = rs.randint(0, kk + 1, size=N).astype(np.int32)
+    for i in range(N):
+        idx[i, :nnz[i]] = rs.choice(K - 3, size=nnz[i], replace=False)      # atoms K-3.. never used
+        coef[i, :nnz[i]] = rs.randn(nnz[i])
+    coef[7, 0] = 0.0                                                         # stored slot with a zero value: not in omega
+    Z = orc.densify(idx, coef, nnz, K)
+    Do, Zo, uo = orc.approx_ksvd(Xm, Dm.copy(), Z.copy(), n_cycles=2)
+    Dc, cc, uc, err = c_oracle.approx_ksvd_sparse(Xm, Dm, idx, coef, nnz, n_cycles=2)
+    assert uc == list(uo)
+    assert np.max(np.abs(Dc - Do)) <= 1e-12
+    assert np.max(np.abs(orc.densify(idx, cc, nnz, K) - Zo)) <= 1e-11
+    assert abs(err - orc.approx_error(Do, Zo, Xm)) <= 1e-9 * err
