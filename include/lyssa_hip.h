@@ -177,6 +177,47 @@ int lys_ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k,
                         double* sbuf, const float* D_packed, float* D_next, void* stream);
 int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, float* D_packed, void* stream);
 
+/* ---- block Gauss-Seidel form of the same sweep (csrc/ksvd_block.hip) ---------------------------
+ * Replaces the atom loop of `approx_ksvd`, lyssa/dict_learning/ksvd.py:105-123, with 2 K/B + 1 dependent launches
+ * (B = 4 or 8 atoms per block) that produce the sequential result: signals using several atoms of one block are
+ * handled through aggregated "tuple moments" (see the header of ksvd_block.hip).  One cycle, nb = ceil(K / B):
+ *     lys_bksvd_index; zero `stats`;
+ *     for c = 0 .. nb:   lys_bksvd_step(0, c)   X(c): [the B sequential atom updates of block c-1 from its slab] ||
+ *                                                      [statistics of block c over the signals that do not use c-1]
+ *                        if c >= 1: lys_bksvd_step(1, c)   Y(c): [block c-1 applied to the residual rows / codes] +
+ *                                                      [statistics of block c over the signals that also use c-1]
+ *                        (multi-GPU: all-reduce slab c = stats + c * stride, `stride` doubles, here -- the per-atom sum
+ *                         of ksvd.py:118 for B atoms at once)
+ *     D_packed <- D_next.
+ *   row_ptr / entry / entry_meta / entry_coef [N*k each]: lys_bksvd_index of the current codes = the by-atom index
+ *   (a block's entries are one contiguous range) with, per entry, the signal id, the coefficient, and slot | flags
+ *   (bit 8: the signal uses another atom of the same block, 9: of the previous block, 10: of the next block), so that
+ *   the common case moves only the residual row; workspace: lys_csr_workspace_bytes.  stats fp64
+ *   [lys_bksvd_stats_bytes], zeroed by the caller once per cycle (lys_bksvd_sweep builds the index and zeroes it).
+ *   lys_bksvd_layout: out6 = {stride, offQ, offC, offGC, groups, B*(n+2)}; slab c holds per atom t of the block
+ *   [sum x R (n), sum x^2, count] at t*(n+2): count == 0 after the reduction <=> unused atom (ksvd.py:112-115).
+ *   D_next receives every atom of the block (unused atoms: a copy of the old column); D_packed is read-only until the
+ *   caller copies D_next over it at the end of the cycle (lys_bksvd_sweep does).
+ */
+int lys_bksvd_block_size(int n);
+/* debugging aid: 64 phase timestamps (100 MHz device wall clock) of the last block-sweep launches (host buffer) */
+int lys_debug_timestamps(uint64_t* out64);
+int lys_bksvd_layout(int n, int B, int32_t* out6);
+size_t lys_bksvd_stats_bytes(int n, int K, int B);
+int lys_bksvd_index(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int B,
+                    int32_t* row_ptr, int32_t* entry, int32_t* entry_meta, float* entry_coef,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* one half step: mode 0 = X(c), c in [0, nb]; mode 1 = Y(c), c in [1, nb] */
+int lys_bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int k,
+                   const int32_t* row_ptr, const int32_t* entry, const int32_t* entry_meta, const float* entry_coef,
+                   const int32_t* idx, float* coef, const float* D_packed, float* D_next, double* stats,
+                   void* stream);
+/* one whole cycle on one GPU: by-atom index (workspace: lys_csr_workspace_bytes) + all launches + D_packed <- D_next */
+int lys_bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
+                    const int32_t* nnz, int B, int32_t* row_ptr, int32_t* entry, int32_t* entry_meta,
+                    float* entry_coef, void* workspace, size_t workspace_bytes, double* stats, float* D_packed,
+                    float* D_next, void* stream);
+
 /* ---- online dictionary learning (online_dict_learn.py:84-98) ---------------------------------- */
 /*
  * dA = Z Z' (K x K, ld = Kp), dB = X Z' stored atom-major [Kp][ldd] -- the per-batch increments of

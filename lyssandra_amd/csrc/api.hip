@@ -46,7 +46,7 @@ int residual(const float*, int64_t, const float*, int, int, int, int64_t, const 
              float*, int64_t, double*, hipStream_t);
 size_t csr_workspace_bytes(int, int, int64_t);
 int csr_by_atom(const int32_t*, const float*, const int32_t*, int, int, int64_t, int32_t*, int32_t*, void*, size_t,
-                hipStream_t);
+                hipStream_t, int32_t* emeta = nullptr, float* ecoef = nullptr, int logb = 0);
 int ksvd_atom_accumulate(int, const float*, int64_t, int, int, const int32_t*, const int32_t*, const float*, double*,
                          hipStream_t);
 int ksvd_atom_apply(int, float*, int64_t, int, int, const int32_t*, const int32_t*, float*, const double*,
@@ -63,6 +63,17 @@ int ksvd_sweep_fused(float*, int64_t, int, int, int, const int32_t*, const int32
                      float*, float*, hipStream_t);
 int ksvd_fused_step(int, int, float*, int64_t, int, int, const int32_t*, const int32_t*, const int32_t*, float*, double*,
                     const float*, float*, hipStream_t, const int32_t* row_ptr_host = nullptr);
+int bksvd_default_block(int n);
+int bk_debug_timestamps(unsigned long long* out64);
+size_t bksvd_stats_doubles(int n, int K, int B);
+struct BkLayout {
+    int B, G, stride, offQ, offC, offGC;
+};
+BkLayout bk_layout(int n, int B);
+int bksvd_step(int, int, int, float*, int64_t, int, int, int, const int32_t*, const int32_t*, const int32_t*, const float*,
+               const int32_t*, float*, const float*, float*, double*, hipStream_t);
+int bksvd_sweep(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const int32_t*, int, int32_t*, int32_t*,
+                int32_t*, float*, void*, size_t, double*, float*, float*, hipStream_t);
 int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const float*, const int32_t*, const int32_t*,
                    const int32_t*, float*, float*, hipStream_t);
 int axpby(float*, float, const float*, int64_t, hipStream_t);
@@ -418,6 +429,51 @@ int lys_ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, co
                     atom <= K,
                 "ksvd_fused_step: bad arguments");
     return ksvd_fused_step(atom, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D_packed, D_next, STREAM(stream));
+}
+
+// ---- block Gauss-Seidel sweep (ksvd_block.hip)
+int lys_bksvd_block_size(int n) { return bksvd_default_block(n); }
+
+int lys_debug_timestamps(uint64_t* out64) {
+    LYS_REQUIRE(out64, "debug_timestamps: null pointer");
+    return bk_debug_timestamps(reinterpret_cast<unsigned long long*>(out64));
+}
+
+int lys_bksvd_layout(int n, int B, int32_t* out6) {
+    LYS_REQUIRE(out6 && n >= 1 && (B == 4 || B == 8), "bksvd_layout: bad arguments");
+    const BkLayout l = bk_layout(n, B);
+    out6[0] = l.stride; out6[1] = l.offQ; out6[2] = l.offC; out6[3] = l.offGC; out6[4] = l.G; out6[5] = B * (n + 2);
+    return LYS_OK;
+}
+
+size_t lys_bksvd_stats_bytes(int n, int K, int B) { return bksvd_stats_doubles(n, K, B) * sizeof(double); }
+
+int lys_bksvd_index(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int B,
+                    int32_t* row_ptr, int32_t* entry, int32_t* entry_meta, float* entry_coef, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    LYS_REQUIRE(idx && coef && nnz && row_ptr && entry && entry_meta && entry_coef && workspace && (B == 4 || B == 8),
+                "bksvd_index: bad arguments");
+    return csr_by_atom(idx, coef, nnz, K, k, N, row_ptr, entry, workspace, workspace_bytes, STREAM(stream), entry_meta,
+                       entry_coef, B == 8 ? 3 : 2);
+}
+
+int lys_bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr,
+                   const int32_t* entry, const int32_t* entry_meta, const float* entry_coef, const int32_t* idx,
+                   float* coef, const float* D_packed, float* D_next, double* stats, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && entry_meta && entry_coef && idx && coef && D_packed && D_next && stats &&
+                    (ldr % 4) == 0 && (B == 4 || B == 8), "bksvd_step: bad arguments");
+    return bksvd_step(mode, c, B, R, ldr, n, K, k, row_ptr, entry, entry_meta, entry_coef, idx, coef, D_packed, D_next,
+                      stats, STREAM(stream));
+}
+
+int lys_bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
+                    const int32_t* nnz, int B, int32_t* row_ptr, int32_t* entry, int32_t* entry_meta, float* entry_coef,
+                    void* workspace, size_t workspace_bytes, double* stats, float* D_packed, float* D_next,
+                    void* stream) {
+    LYS_REQUIRE(R && idx && coef && nnz && row_ptr && entry && entry_meta && entry_coef && workspace && stats &&
+                    D_packed && D_next && (ldr % 4) == 0 && (B == 4 || B == 8), "bksvd_sweep: bad arguments");
+    return bksvd_sweep(R, ldr, n, K, k, N, idx, coef, nnz, B, row_ptr, entry, entry_meta, entry_coef, workspace,
+                       workspace_bytes, stats, D_packed, D_next, STREAM(stream));
 }
 
 size_t lys_ksvd_exact_workspace_bytes(int n) { return ksvd_exact_work_doubles(n) * sizeof(double); }

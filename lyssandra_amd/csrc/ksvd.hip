@@ -166,7 +166,9 @@ __global__ __launch_bounds__(64) void csr_count_or_fill_kernel(const int32_t* __
                                                                const int32_t* __restrict__ nnz, int K, int k, int64_t N,
                                                                int T, int64_t S, int32_t* __restrict__ counts,
                                                                const int32_t* __restrict__ row_ptr,
-                                                               int32_t* __restrict__ entry, int fill) {
+                                                               int32_t* __restrict__ entry, int fill,
+                                                               int32_t* __restrict__ emeta = nullptr,
+                                                               float* __restrict__ ecoef = nullptr, int logb = 0) {
     extern __shared__ int s_cnt[];
     const int lane = threadIdx.x;
     const int chunk = blockIdx.x;
@@ -192,9 +194,32 @@ __global__ __launch_bounds__(64) void csr_count_or_fill_kernel(const int32_t* __
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (cv[u] != 0.f && av[u] >= 0 && av[u] < K) {
+                const bool live = cv[u] != 0.f && av[u] >= 0 && av[u] < K;
+                int meta = lane;
+                if (fill == 2) {
+                    // block sweep (ksvd_block.hip): entry = signal id + the entry's coefficient + its slot and three flags
+                    // about the signal's OTHER atoms: same block of 2^logb atoms (bit 8), previous block (9), next (10)
+                    const int a = live ? av[u] : -1;
+                    const int blk = a >> logb;
+                    for (int j = 0; j < k; ++j) {  // wave-uniform loop over the signal's slots
+                        const int aj = __builtin_amdgcn_readlane(a, j);
+                        if (aj >= 0 && j != lane) {
+                            const int bj = aj >> logb;
+                            meta |= (bj == blk) ? 0x100 : 0;
+                            meta |= (bj == blk - 1) ? 0x200 : 0;
+                            meta |= (bj == blk + 1) ? 0x400 : 0;
+                        }
+                    }
+                }
+                if (live) {
                     const int pos = atomicAdd(&s_cnt[av[u]], 1);
-                    if (fill) entry[pos] = (int32_t)((sb + u) * k + lane);
+                    if (fill == 2) {
+                        entry[pos] = (int32_t)(sb + u);
+                        emeta[pos] = meta;
+                        ecoef[pos] = cv[u];
+                    } else if (fill) {
+                        entry[pos] = (int32_t)((sb + u) * k + lane);
+                    }
                 }
             }
         }
@@ -269,6 +294,20 @@ __global__ __launch_bounds__(1024) void csr_scan_totals_kernel(const int32_t* __
     if (t == 1023) row_ptr[K] = s_part[1023];
 }
 
+// counts[rows][T] -> exclusive scan inside every row (in place), row totals, and row_ptr[rows+1]; shared with the
+// block index of ksvd_block.hip
+int csr_scan(int32_t* counts, int rows, int T, int32_t* totals, int32_t* row_ptr, hipStream_t stream) {
+    if (rows > 16384 * 1024) {
+        set_error("csr_scan: %d rows", rows);
+        return LYS_ENOSUP;
+    }
+    hipLaunchKernelGGL(csr_scan_atoms_kernel, dim3(rows), dim3(256), 0, stream, counts, T, totals);
+    LYS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, totals, rows, row_ptr);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 static void csr_plan(int64_t N, int& T, int64_t& S) {
     int64_t t = (N + 255) / 256;
     if (t < 1) t = 1;
@@ -284,8 +323,14 @@ size_t csr_workspace_bytes(int K, int k, int64_t N) {
     return ((size_t)K * (size_t)T + (size_t)K) * sizeof(int32_t);
 }
 
+// emeta == nullptr: entry = signal*k + slot (per-atom kernels, online DL).  Otherwise (block sweep, k <= 64): entry =
+// signal id, ecoef = the entry's coefficient, emeta = slot | flags (see csr_count_or_fill_kernel), blocks of 2^logb atoms.
 int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int32_t* row_ptr,
-                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream) {
+                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int32_t* emeta, float* ecoef, int logb) {
+    if (emeta && k > 64) {
+        set_error("csr_by_atom: block-sweep index needs k <= 64 (k = %d)", k);
+        return LYS_ENOSUP;
+    }
     int T;
     int64_t S;
     csr_plan(N, T, S);
@@ -312,7 +357,7 @@ int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K
     hipLaunchKernelGGL(csr_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, totals, K, row_ptr);
     LYS_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_count_or_fill_kernel, dim3(T), dim3(64), lds, stream, idx, coef, nnz, K, k, N, T, S, counts,
-                       row_ptr, entry, 1);
+                       row_ptr, entry, emeta ? 2 : 1, emeta, ecoef, logb);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }

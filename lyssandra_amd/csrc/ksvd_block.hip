@@ -1,0 +1,833 @@
+// Block Gauss-Seidel form of the approximate K-SVD sweep (lyssa/dict_learning/ksvd.py:98-126) for gfx950.
+//
+// The reference visits the atoms strictly in order and every atom's update reads the residual left by the previous
+// one, so a sweep is a chain of K dependent steps; with one launch per atom (ksvd.hip) that chain costs K kernel
+// boundaries plus K in-kernel gather latencies (9 us per atom at config 2).  On MI355X a kernel boundary (~1.7 us) is
+// the cheapest grid-wide synchronisation there is, so the way to go faster is to have FEWER dependent steps, not
+// cheaper ones.  This file processes the atoms in blocks of B = 4 or 8 and still produces exactly the sequential
+// result (same algebra, different summation order):
+//
+//   * A signal that uses ONE atom of the block contributes  x R_i  to that atom's statistics -- independent of the other
+//     atoms of the block.  That is 97 % of the (signal, atom) pairs at config 2.
+//   * A signal that uses the atoms a_1 < ... < a_m of the block (m >= 2) contributes to s_{a_j}
+//         x_j [ P_{j-1}..P_1 R_i + sum_{l<j} P_{j-1}..P_l d_l^old x_l + d_j^old x_j ],   P_l = I - d_l^new d_l^new'
+//     which is LINEAR in (R_i, x_i) with operators that depend only on the tuple of atoms, not on the signal.  So all
+//     signals with the same (prefix set pi, target a_j) are aggregated into one n-vector  Q = sum x_j R_i  and |pi|
+//     scalars  c_l = sum x_j x_l  ("tuple moments", 2^B - 1 - B groups per block), BEFORE any new atom is known.
+//   * NARROW step of block c (one workgroup): the B sequential atom updates on the aggregated statistics alone (fp64):
+//     s_a = S_a + sum_groups Horner(P.., Q, c) + d_a^old sum x^2,  d_a^new = s_a / (||s_a|| + eps)  (utils/math.py:61-62).
+//   * APPLY of block c: per signal the in-block updates run sequentially in registers (ksvd.py:116-123), the residual
+//     row is read and written once per block visit.
+//   One launch of `bksvd_step_kernel` per half step, 2 K/B + 1 dependent launches per sweep (257 instead of 1025):
+//       X(c):  [narrow step of block c-1 on the last workgroup]  ||  [accumulate block c over the signals that do NOT
+//              use block c-1 -- their residual rows do not depend on it -- on all other workgroups]
+//       Y(c):  [apply block c-1]  +  [accumulate block c over the signals that also use block c-1, after applying it]
+//   so the serial narrow step hides behind 92 % of the accumulation.  In a multi-GPU run the exchange is ONE all-reduce
+//   of block c's statistics slab between Y(c) and X(c+1) instead of one per atom (dist.ksvd_cycle_blocks).
+//
+// The kernels are bound by the BYTES of scattered accesses (every 40-byte support read costs a 128-byte line), so the
+// by-atom index carries, per entry, the signal id, the entry's coefficient, its slot and three flags (the signal uses
+// another atom of the same / previous / next block): the common case moves the residual row and nothing else; the
+// rest (11 % at config 2) goes through a workgroup LDS queue to a slow path that loads the support.
+//
+// Statistics slab of block c (fp64, `bbuf + c * stride`, zeroed by the caller once per cycle):
+//     S [B][n+2]   per atom: sum_i x R_i (n), sum x^2, number of non-zeros (0 => unused atom, ksvd.py:112-115)
+//     Q [G][n]     per group g = (target t, prefix set pi != 0 below t):  sum x_t R_i
+//     C [G][B]     sum x_t x_l for l in pi (indexed by l's position in the block)
+//     GC[G]        number of contributing signals (0 => group skipped)
+//   G = 2^B - 1 - B, group index g = (2^t - 1 - t) + (pi - 1).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace lys {
+
+struct BkLayout {
+    int B, G, stride, offQ, offC, offGC;
+};
+
+BkLayout bk_layout(int n, int B) {
+    BkLayout l;
+    l.B = B;
+    l.G = (1 << B) - 1 - B;
+    l.offQ = B * (n + 2);
+    l.offC = l.offQ + l.G * n;
+    l.offGC = l.offC + l.G * B;
+    l.stride = l.offGC + l.G;
+    return l;
+}
+
+int bksvd_default_block(int n) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("LYS_KSVD_BLOCK");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 4 || (forced == 8 && n <= 128)) return forced;
+    return (n <= 128) ? 8 : 4;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers: a "team" is one 16-lane DPP row; lane q owns features 64*b + 4*q .. +3 (b < FB) of a signal and the
+// support slots q, q+16, .. (SL per lane, k <= 16*SL).  All cross-lane steps are DPP with bound_ctrl and a zero
+// `old`, which the compiler folds into the consuming op (v_add_f32_dpp / v_or_b32_dpp): one instruction per step.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int bk_dpp_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float bk_dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double bk_dpp_d(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float bk_row16_sum(float x) {
+    x += bk_dpp_f<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += bk_dpp_f<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += bk_dpp_f<0x124>(x);  // row_ror:4
+    x += bk_dpp_f<0x128>(x);  // row_ror:8
+    return x;
+}
+__device__ __forceinline__ double bk_row16_sum_d(double x) {
+    x += bk_dpp_d<0xB1>(x);
+    x += bk_dpp_d<0x4E>(x);
+    x += bk_dpp_d<0x124>(x);
+    x += bk_dpp_d<0x128>(x);
+    return x;
+}
+__device__ __forceinline__ unsigned bk_row16_or(unsigned x) {
+    x |= (unsigned)bk_dpp_i<0xB1>((int)x);
+    x |= (unsigned)bk_dpp_i<0x4E>((int)x);
+    x |= (unsigned)bk_dpp_i<0x124>((int)x);
+    x |= (unsigned)bk_dpp_i<0x128>((int)x);
+    return x;
+}
+// lane L of every 16-lane row, in all lanes of that row (row_newbcast on gfx90a+)
+template <int L>
+__device__ __forceinline__ int bk_row_bcast(int x) {
+    return bk_dpp_i<0x150 + L>(x);
+}
+
+// same with a lane index that is a constant after unrolling
+__device__ __forceinline__ int bk_row_bcast_dyn(int x, int L) {
+    switch (L & 15) {
+        case 0: return bk_row_bcast<0>(x);
+        case 1: return bk_row_bcast<1>(x);
+        case 2: return bk_row_bcast<2>(x);
+        case 3: return bk_row_bcast<3>(x);
+        case 4: return bk_row_bcast<4>(x);
+        case 5: return bk_row_bcast<5>(x);
+        case 6: return bk_row_bcast<6>(x);
+        case 7: return bk_row_bcast<7>(x);
+        case 8: return bk_row_bcast<8>(x);
+        case 9: return bk_row_bcast<9>(x);
+        case 10: return bk_row_bcast<10>(x);
+        case 11: return bk_row_bcast<11>(x);
+        case 12: return bk_row_bcast<12>(x);
+        case 13: return bk_row_bcast<13>(x);
+        case 14: return bk_row_bcast<14>(x);
+        default: return bk_row_bcast<15>(x);
+    }
+}
+
+constexpr int BK_WBLOCKS = 256;  // workgroups of a step launch
+
+// phase timestamps (100 MHz wall clock) of the last launches, read by lys_debug_timestamps: [0..7] narrow step,
+// [32..39] workgroup 0, [48..55] workgroup gridDim/2.  They stay in registers and are written once at the very end (a
+// store inside the kernel would be waited for by the next barrier and distort what it measures).
+__device__ unsigned long long g_bk_stamp[64];
+
+// groups staged in LDS by the narrow step; further non-empty groups (not seen in practice) are read in place
+__host__ __device__ constexpr int bk_maxg(int B) { return ((1 << B) - 1 - B) < 64 ? ((1 << B) - 1 - B) : 64; }
+
+// ---------------------------------------------------------------------------------------------
+// The B sequential atom updates of block c on the aggregated statistics (one workgroup of NTH threads, fp64).
+// Everything is staged in LDS first (the slab was written by atomics: every access to it is a fabric round trip),
+// then the atom loop runs on 4 waves = 16 sixteen-lane teams and costs ONE barrier per atom: the teams evaluate the
+// atom's non-empty groups (Horner over the prefix set with 16-lane DPP dot products) into stot[t], barrier, and every
+// team normalises redundantly and writes the same d_new into LDS (no second barrier: a team only reads back what it
+// wrote itself).
+// ---------------------------------------------------------------------------------------------
+template <int LOGB, int FB, int NTH>
+__device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D, float* __restrict__ Dnext, int ldd,
+                               const double* __restrict__ bbuf, const BkLayout lay, double* sm) {
+    constexpr int B = 1 << LOGB;
+    constexpr int G = (1 << B) - 1 - B;
+    constexpr int NF = FB * 64;  // padded feature count of the LDS rows
+    constexpr int MAXG = bk_maxg(B);
+    // sm: dold[B][NF], dnew[B][NF], S[B][n+2], stot[B][NF], QC[MAXG][NF+B]
+    __shared__ short gslot[G > 0 ? G : 1];
+    __shared__ short glist[G > 0 ? G : 1];  // non-empty groups in ascending order (grouped by target)
+    __shared__ int gfirst[B + 1];           // first entry of glist per target
+    double* dold = sm;
+    double* dnew = dold + (size_t)B * NF;
+    double* S = dnew + (size_t)B * NF;
+    double* stot = S + (size_t)B * (n + 2);
+    double* QC = stot + (size_t)B * NF;
+    const double* bb = bbuf + (int64_t)c * lay.stride;
+    const int tid = threadIdx.x, lane = tid & 63, team = tid >> 4, q = tid & 15;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BK_NSTAMP(i) do { if (tid == 0) ts[i] = wall_clock64(); } while (0)
+    BK_NSTAMP(0);
+    // round 1: atoms, per-atom statistics, group counts (all loads independent)
+    for (int i = tid; i < B * NF; i += NTH) {
+        const int t = i / NF, f = i % NF, a = c * B + t;
+        const double v = (a < K && f < n) ? (double)D[(int64_t)a * ldd + f] : 0.0;
+        dold[i] = v;
+        dnew[i] = v;
+        stot[i] = 0.0;
+    }
+    for (int i = tid; i < B * (n + 2); i += NTH) S[i] = bb[i];
+    if (tid < 64) {  // wave 0: ordered compaction of the non-empty groups (all count loads first, then ballots)
+        constexpr int NW = (G + 63) / 64;
+        bool ne[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int g = 64 * w + lane;
+            ne[w] = (g < G) && (bb[lay.offGC + g] > 0.0);
+        }
+        unsigned long long bal[NW];
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int g = 64 * w + lane;
+            bal[w] = __ballot(ne[w]);
+            const int pos = base + __popcll(bal[w] & ((1ull << lane) - 1ull));
+            if (g < G) gslot[g] = ne[w] ? (short)((pos < MAXG) ? pos : -2) : (short)-1;
+            if (ne[w]) glist[pos] = (short)g;
+            base += __popcll(bal[w]);
+        }
+        if (lane <= B) {  // groups are numbered target-major: first list entry of target t = #non-empty groups below g0(t)
+            const int gstart = (lane < B) ? ((1 << lane) - 1 - lane) : G;
+            int cntb = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int hi = gstart - 64 * w;  // groups of word w below gstart
+                const unsigned long long msk = (hi >= 64) ? ~0ull : (hi <= 0) ? 0ull : ((1ull << hi) - 1ull);
+                cntb += __popcll(bal[w] & msk);
+            }
+            gfirst[lane] = cntb;
+        }
+    }
+    __syncthreads();
+    BK_NSTAMP(1);
+    // round 2: moments of the staged groups, flat over (slot, element) so that all loads are in flight together; the
+    // padding columns n..NF of a staged row are zero-filled
+    {
+        const int nst = min(gfirst[B], MAXG), per = NF + B, total = nst * per;
+        for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + r * NTH + tid;
+                v[r] = 0.0;
+                if (i < total) {
+                    const int sl = i / per, e = i % per, g = glist[sl];
+                    if (e < n) v[r] = bb[lay.offQ + (int64_t)g * n + e];
+                    if (e >= NF) v[r] = bb[lay.offC + (int64_t)g * B + (e - NF)];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + r * NTH + tid;
+                if (i < total) QC[i] = v[r];
+            }
+        }
+    }
+    __syncthreads();
+    BK_NSTAMP(2);
+    // the atom loop runs on 4 waves (one per SIMD, 16 teams): with more waves the redundant per-team normalisation
+    // below, not the group evaluation, is most of an atom's time.  The other waves were only needed to stage the slab.
+    constexpr int NT = 16;  // teams in the atom loop
+    if (tid >= 16 * NT) return;
+    for (int t = 0; t < B; ++t) {
+        const int a = c * B + t;
+        if (a >= K) break;
+        const double cnt = S[t * (n + 2) + n + 1];
+        if (cnt == 0.0) continue;  // unused atom keeps its column (ksvd.py:112-115): dnew[t] == dold[t]; uniform
+        // groups with target t: team j evaluates list entries gfirst[t] + j, + NT, ..
+        for (int li = gfirst[t] + team; li < gfirst[t + 1]; li += NT) {
+            const int g = glist[li];
+            const int sl = gslot[g];
+            const unsigned pi = (unsigned)(g - ((1 << t) - 1 - t)) + 1u;
+            double u[FB][4];
+            if (sl >= 0) {
+                const double* src = QC + (size_t)sl * (NF + B);
+#pragma unroll
+                for (int b = 0; b < FB; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u[b][e] = src[64 * b + 4 * q + e];
+            } else {
+#pragma unroll
+                for (int b = 0; b < FB; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int f = 64 * b + 4 * q + e;
+                        u[b][e] = (f < n) ? bb[lay.offQ + (int64_t)g * n + f] : 0.0;
+                    }
+            }
+            for (int l = 0; l < t; ++l) {  // Horner: u = P_l (u + c_l d_l^old), l ascending over the prefix set
+                if (!((pi >> l) & 1u)) continue;
+                const double cl = (sl >= 0) ? QC[(size_t)sl * (NF + B) + NF + l] : bb[lay.offC + (int64_t)g * B + l];
+                double dot = 0.0;
+#pragma unroll
+                for (int b = 0; b < FB; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int f = 64 * b + 4 * q + e;
+                        u[b][e] = fma(cl, dold[l * NF + f], u[b][e]);
+                        dot = fma(u[b][e], dnew[l * NF + f], dot);
+                    }
+                dot = bk_row16_sum_d(dot);
+#pragma unroll
+                for (int b = 0; b < FB; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int f = 64 * b + 4 * q + e;
+                        u[b][e] = fma(-dnew[l * NF + f], dot, u[b][e]);
+                    }
+            }
+#pragma unroll
+            for (int b = 0; b < FB; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(&stot[t * NF + 64 * b + 4 * q + e], u[b][e]);
+        }
+        __syncthreads();  // waves 4.. have exited: the barrier counts the live waves only
+        // every team: s = S_t + d_old sum x^2 + groups, d_new = s / (||s|| + eps)
+        const double sqs = S[t * (n + 2) + n];
+        double sv[FB][4];
+        double v2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = 64 * b + 4 * q + e;
+                const double base = (f < n) ? S[t * (n + 2) + f] : 0.0;
+                sv[b][e] = base + dold[t * NF + f] * sqs + stot[t * NF + f];
+                v2 = fma(sv[b][e], sv[b][e], v2);
+            }
+        v2 = bk_row16_sum_d(v2);
+        // x / (||x|| + eps) (utils/math.py:61-62) with 1/||x|| from v_rsq_f64 + two Newton steps: every team does this
+        // redundantly, a full IEEE sqrt + divide costs several times more.  eps only matters for x = 0, where the
+        // result is the zero vector either way.
+        double scale = 0.0;
+        if (v2 > 0.0) {
+            double y = __builtin_amdgcn_rsq(v2);
+            y = y * fma(-0.5 * v2 * y, y, 1.5);
+            scale = y * fma(-0.5 * v2 * y, y, 1.5);
+        }
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dnew[t * NF + 64 * b + 4 * q + e] = sv[b][e] * scale;
+        if (t == 0) BK_NSTAMP(3);
+    }
+    BK_NSTAMP(4);
+    __syncthreads();
+    // the new atoms leave LDS once, at the end: a global store inside the loop would put a fabric write-acknowledge
+    // (the fence of __syncthreads) on every atom's critical path
+    for (int i = tid; i < B * ldd; i += 16 * NT) {
+        const int t = i / ldd, f = i % ldd, a = c * B + t;
+        if (a < K) Dnext[(int64_t)a * ldd + f] = (f < n) ? (float)dnew[t * NF + f] : 0.f;
+    }
+    BK_NSTAMP(5);
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) g_bk_stamp[i] = ts[i];
+#undef BK_NSTAMP
+}
+
+// ---------------------------------------------------------------------------------------------
+// One half step (see the header): mode 0 = X(c), mode 1 = Y(c).
+// The workgroups walk the BY-ATOM index (lys_bksvd_index: atoms contiguous, signals ascending inside an atom): the
+// entries of a block of atoms are one contiguous range, every team takes a contiguous chunk of it, so a team sees one
+// atom (rarely two), knows the atom of an entry from the entry's POSITION, and keeps ONE accumulator that it flushes
+// into the workgroup's fp64 LDS accumulators when the atom changes.  A signal that uses several atoms of a block
+// appears once per atom: only its LEADER entry (smallest atom of the block in the signal's support) does the work.
+// Loads are unconditional on clamped indices with 32-bit offsets, entries are broadcast with row_newbcast, all
+// cross-lane sums are fused DPP, FULL (n a multiple of 64) drops the feature guards.
+// ---------------------------------------------------------------------------------------------
+template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
+__global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c, int nb, int K, float* __restrict__ R,
+                                                                int64_t ldr, int n, int k,
+                                                                const int32_t* __restrict__ row_ptr,
+                                                                const int32_t* __restrict__ entry,
+                                                                const int32_t* __restrict__ emeta,
+                                                                const float* __restrict__ ecoef,
+                                                                const int32_t* __restrict__ idx,
+                                                                float* __restrict__ coef, const float* __restrict__ D,
+                                                                float* __restrict__ Dnext, int ldd,
+                                                                double* __restrict__ bbuf, BkLayout lay) {
+    constexpr int B = 1 << LOGB;
+    constexpr int U = (FB == 1) ? 8 : 4;  // signals in flight per team
+    constexpr int NTH = 16 * TEAMS;
+    extern __shared__ double sm[];  // narrow step only
+    int nwg = (int)gridDim.x;
+    if (mode == 0 && c >= 1) {
+        --nwg;
+        if ((int)blockIdx.x == nwg) {
+            bk_narrow_body<LOGB, FB, NTH>(c - 1, K, n, D, Dnext, ldd, bbuf, lay, sm);
+            return;
+        }
+    }
+    if (mode == 0 && c >= nb) return;  // X(nb): only the narrow step of the last block
+
+    __shared__ __attribute__((aligned(16))) float s_d[2][B][FB * 64];  // old / new atoms of block c-1 (mode Y)
+    __shared__ double s_acc[B][FB * 64 + 2];                            // workgroup accumulators of block c
+    __shared__ int s_rp[2][B + 1];                                      // row_ptr of block c-1 ([0]) and block c ([1])
+    __shared__ int s_q[NTH][4];                                         // workgroup queue of slow-path entries
+    __shared__ int s_qn;
+    const int p = c - 1;
+    const bool have_p = (mode == 1) && p >= 0;  // block c-1 is applied in this launch
+    const bool have_c = c < nb;
+    const int tid = threadIdx.x, team = tid >> 4, q = tid & 15;
+    const int stamp0 = (blockIdx.x == 0) ? 32 : ((int)blockIdx.x == nwg / 2) ? 48 : -1;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BK_WSTAMP(i) do { if (stamp0 >= 0) ts[i] = wall_clock64(); } while (0)
+    BK_WSTAMP(0);
+    if (tid <= B) {
+        s_rp[0][tid] = (p >= 0) ? row_ptr[(p * B + tid < K) ? p * B + tid : K] : 0;
+        s_rp[1][tid] = have_c ? row_ptr[(c * B + tid < K) ? c * B + tid : K] : 0;
+    }
+    if (tid == 0) s_qn = 0;
+    for (int i = tid; i < B * (FB * 64 + 2); i += NTH) (&s_acc[0][0])[i] = 0.0;
+    if (have_p) {
+        for (int i = tid; i < B * FB * 64; i += NTH) {
+            const int t = i / (FB * 64), f = i % (FB * 64), a = p * B + t;
+            const bool in = (a < K) && (f < ldd);
+            s_d[0][t][f] = in ? D[(int64_t)a * ldd + f] : 0.f;
+            s_d[1][t][f] = in ? Dnext[(int64_t)a * ldd + f] : 0.f;
+        }
+    }
+    __syncthreads();
+    BK_WSTAMP(1);
+
+    float4 acc[FB];
+    float sq = 0.f;
+    int cn = 0, cur = -1;
+#pragma unroll
+    for (int b = 0; b < FB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    double* bb = bbuf + (int64_t)(have_c ? c : 0) * lay.stride;
+    // all per-signal addresses are 32-bit byte offsets on uniform bases (host checks N*ldr*4 and N*k*4 < 4 GB)
+    const unsigned rsz = (unsigned)ldr * 4u, ksz = (unsigned)k * 4u;
+    const int pcmp = have_p ? p : -2;  // dropped slots carry atom -1 = "block -1": must not look like block p
+    const int gteam = (int)blockIdx.x * TEAMS + team, nteams = nwg * TEAMS;
+    // state of the list walk (set by `begin_list`)
+    int which = 0, tbeg = 0, tend = 0, chunk = 0, tpos = 0, rp_next = 0;
+
+    auto value_of = [&](const int (&a)[SL], const float (&x)[SL], int atom) -> float {
+        float v = 0.f;
+#pragma unroll
+        for (int s = 0; s < SL; ++s) v += (a[s] == atom) ? x[s] : 0.f;
+        return bk_row16_sum(v);
+    };
+    // one atom of block p: Rk = R_i + d_old x (ksvd.py:116), x_new = Rk' d_new (:121), R_i = Rk - d_new x_new (:123)
+    auto apply_atom = [&](float4 (&r)[FB], int t, float xo) -> float {
+        float4 dn[FB];
+        float dot = 0.f;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const float4 d0 = *reinterpret_cast<const float4*>(&s_d[0][t][64 * b + 4 * q]);
+            dn[b] = *reinterpret_cast<const float4*>(&s_d[1][t][64 * b + 4 * q]);
+            r[b].x = fmaf(d0.x, xo, r[b].x);
+            r[b].y = fmaf(d0.y, xo, r[b].y);
+            r[b].z = fmaf(d0.z, xo, r[b].z);
+            r[b].w = fmaf(d0.w, xo, r[b].w);
+            dot = fmaf(r[b].x, dn[b].x, dot);
+            dot = fmaf(r[b].y, dn[b].y, dot);
+            dot = fmaf(r[b].z, dn[b].z, dot);
+            dot = fmaf(r[b].w, dn[b].w, dot);
+        }
+        const float xn = bk_row16_sum(dot);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            r[b].x = fmaf(-dn[b].x, xn, r[b].x);
+            r[b].y = fmaf(-dn[b].y, xn, r[b].y);
+            r[b].z = fmaf(-dn[b].z, xn, r[b].z);
+            r[b].w = fmaf(-dn[b].w, xn, r[b].w);
+        }
+        return xn;
+    };
+    auto store_row = [&](const float4 (&r)[FB], unsigned sig) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (FULL || f < n)
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(R) + (sig * rsz + 4u * f)) = r[b];
+        }
+    };
+    // the finished block p on a signal whose support is loaded, in-block atoms in ascending order
+    auto apply_block = [&](float4 (&r)[FB], const int (&a)[SL], const float (&x)[SL], unsigned sig, unsigned m) {
+        while (m) {
+            const int t = __ffs(m) - 1;
+            m &= m - 1;
+            const int atom = p * B + t;
+            const float xn = apply_atom(r, t, value_of(a, x, atom));
+#pragma unroll
+            for (int s = 0; s < SL; ++s)
+                if (a[s] == atom)
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(coef) + (sig * ksz + 4u * (q + 16 * s))) = xn;
+        }
+        store_row(r, sig);
+    };
+    auto flush = [&]() {  // team accumulator -> workgroup accumulators (fp64 LDS atomics), uniform per team
+        if (cur >= 0) {
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                atomicAdd(&s_acc[cur][64 * b + 4 * q + 0], (double)acc[b].x);
+                atomicAdd(&s_acc[cur][64 * b + 4 * q + 1], (double)acc[b].y);
+                atomicAdd(&s_acc[cur][64 * b + 4 * q + 2], (double)acc[b].z);
+                atomicAdd(&s_acc[cur][64 * b + 4 * q + 3], (double)acc[b].w);
+                acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (q == 0) {
+                atomicAdd(&s_acc[cur][FB * 64], (double)sq);
+                atomicAdd(&s_acc[cur][FB * 64 + 1], (double)cn);
+            }
+            sq = 0.f;
+            cn = 0;
+        }
+    };
+    auto accumulate_one = [&](const float4 (&r)[FB], float x1, int t) {
+        if (t != cur) {
+            flush();
+            cur = t;
+        }
+        sq = fmaf(x1, x1, sq);
+        cn += 1;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            acc[b].x = fmaf(r[b].x, x1, acc[b].x);
+            acc[b].y = fmaf(r[b].y, x1, acc[b].y);
+            acc[b].z = fmaf(r[b].z, x1, acc[b].z);
+            acc[b].w = fmaf(r[b].w, x1, acc[b].w);
+        }
+    };
+    // tuple moments of a signal that uses several atoms of block c (about 3 % of the visits at config 2): r is the
+    // residual row BEFORE block c, t1 / x1 the leader, m2 the remaining in-block atoms
+    auto coupled = [&](const float4 (&r)[FB], const int (&a)[SL], const float (&x)[SL], int t1, float x1, unsigned m2) {
+        float xq = (q == t1) ? x1 : 0.f;  // lane q (< B) keeps the old coefficient of the block's atom q
+        unsigned pi = 1u << t1;
+        while (m2) {
+            const int t = __ffs(m2) - 1;
+            m2 &= m2 - 1;
+            const float xj = value_of(a, x, c * B + t);
+            const int g = ((1 << t) - 1 - t) + (int)pi - 1;
+            double* Qg = bb + lay.offQ + (int64_t)g * n;
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                const int f = 64 * b + 4 * q;
+                if (f < n) atomicAdd(Qg + f, (double)(xj * r[b].x));
+                if (f + 1 < n) atomicAdd(Qg + f + 1, (double)(xj * r[b].y));
+                if (f + 2 < n) atomicAdd(Qg + f + 2, (double)(xj * r[b].z));
+                if (f + 3 < n) atomicAdd(Qg + f + 3, (double)(xj * r[b].w));
+            }
+            if (q < B && ((pi >> q) & 1u)) atomicAdd(bb + lay.offC + (int64_t)g * B + q, (double)xj * (double)xq);
+            if (q == 0) {
+                atomicAdd(bb + lay.offGC + g, 1.0);
+                atomicAdd(&s_acc[t][FB * 64], (double)xj * (double)xj);
+                atomicAdd(&s_acc[t][FB * 64 + 1], 1.0);
+            }
+            xq = (q == t) ? xj : xq;
+            pi |= 1u << t;
+        }
+    };
+
+    constexpr int F_COUPLED = 0x100, F_PREV = 0x200, F_NEXT = 0x400;  // see csr_count_or_fill_kernel (ksvd.hip)
+    // What a walk does with an entry (role):
+    //   ROLE_ACC      X(c), list c : PREV -> nothing (Y's job); COUPLED -> queue; else accumulate (fast)
+    //   ROLE_COLLECT  Y(c), list c : PREV -> queue; else nothing (X did it)
+    //   ROLE_APPLY    Y(c), list p : NEXT -> nothing (its list-c entry is PREV, queued above); COUPLED -> queue; else
+    //                                apply the entry's atom (fast: coefficient and slot came with the index)
+    constexpr int ROLE_ACC = 0, ROLE_COLLECT = 1, ROLE_APPLY = 2;
+    auto run_fast = [&](int role, int ent, int emt, float ecf, int j0, int e_base) {
+        float4 rr[U][FB];
+        unsigned sg[U];
+        int mt[U];  // slot, bit 31 = nothing to do, bit 30 = queue
+        float xe[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned sig = (unsigned)bk_row_bcast_dyn(ent, j0 + u);
+            int m = bk_row_bcast_dyn(emt, j0 + u);
+            xe[u] = __builtin_bit_cast(float, bk_row_bcast_dyn(__builtin_bit_cast(int, ecf), j0 + u));
+            bool skip, slow;
+            if (role == ROLE_ACC) {
+                skip = (m & F_PREV) && p >= 0;
+                slow = !skip && (m & F_COUPLED);
+            } else if (role == ROLE_COLLECT) {
+                slow = (m & F_PREV) != 0;
+                skip = !slow;
+            } else {
+                skip = have_c && (m & F_NEXT);
+                slow = !skip && (m & F_COUPLED);
+            }
+            skip = skip || (e_base + u >= tend);
+            m = (m & 63) | (skip ? (int)0x80000000 : 0) | ((slow && !skip) ? 0x40000000 : 0);
+            sg[u] = sig;
+            mt[u] = m;
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                const int f = 64 * b + 4 * q;
+                rr[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(m & 0xC0000000) && (FULL || f < n))
+                    rr[u][b] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R) + (sig * rsz + 4u * f));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e_base + u;
+            if (e >= tend) break;  // uniform per team
+            while (e >= rp_next) {  // next atom of the block (empty atoms are stepped over)
+                ++tpos;
+                rp_next = s_rp[which][tpos + 1];
+            }
+            if (mt[u] < 0) continue;  // nothing to do
+            if (mt[u] & 0x40000000) {
+                if (q == 0) {
+                    const int slot = atomicAdd(&s_qn, 1);  // < NTH: at most 16 entries per team and batch
+                    s_q[slot][0] = (int)sg[u];
+                    s_q[slot][1] = tpos;
+                    s_q[slot][2] = __builtin_bit_cast(int, xe[u]);
+                    s_q[slot][3] = (role == ROLE_APPLY) ? 1 : 0;
+                }
+                continue;
+            }
+            if (role == ROLE_APPLY) {
+                const float xn = apply_atom(rr[u], tpos, xe[u]);
+                store_row(rr[u], sg[u]);
+                if (q == 0)
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(coef) + (sg[u] * ksz + 4u * (unsigned)(mt[u] & 63))) = xn;
+            } else {
+                accumulate_one(rr[u], xe[u], tpos);
+            }
+        }
+    };
+    // slow path: support loaded, leader test, in-block atoms sequentially, tuple moments
+    auto run_slow = [&](unsigned sig, int tp, float x1, bool is_apply) {
+        float4 r[FB];
+        int a[SL];
+        float x[SL];
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            r[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL || f < n)
+                r[b] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R) + (sig * rsz + 4u * f));
+        }
+        unsigned m = 0;
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            const int j = q + 16 * s;
+            const unsigned off = sig * ksz + 4u * (unsigned)((j < k) ? j : k - 1);
+            const int av = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(idx) + off);
+            x[s] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(coef) + off);
+            const bool live = (j < k) && (x[s] != 0.f);  // omega = X[k,:] != 0 (ksvd.py:111)
+            a[s] = live ? av : -1;
+            const int blk = a[s] >> LOGB;  // -1 for a dropped slot
+            const unsigned bit = 1u << (a[s] & (B - 1));
+            m |= (blk == pcmp) ? bit : 0u;
+            m |= (blk == c) ? (bit << 8) : 0u;
+        }
+        m = bk_row16_or(m);  // masks of block p (bits 0-7) and block c (8-15)
+        const unsigned mp = m & 0xffu, mc = m >> 8;
+        if (is_apply) {
+            if (__ffs(mp) - 1 != tp) return;  // not the signal's leader entry in block p
+            if (mc) return;                   // also in block c: its list-c entry was collected as PREV
+            apply_block(r, a, x, sig, mp);
+        } else {
+            if (__ffs(mc) - 1 != tp) return;  // not the leader entry in block c
+            if (mp) apply_block(r, a, x, sig, mp);
+            accumulate_one(r, x1, tp);
+            const unsigned m2 = mc & (mc - 1);
+            if (m2) coupled(r, a, x, tp, x1, m2);
+        }
+    };
+    // walk of one block's entry range with a role; the batch count is uniform per workgroup (every team has the same
+    // chunk size, teams past the end of the list idle) because the queued entries of a batch are drained by ALL teams
+    // between two workgroup barriers
+    auto walk = [&](int role, int blk_id, int w) {
+        which = w;
+        const int lbeg = s_rp[w][0];
+        const int a_hi = (blk_id * B + B < K) ? B : K - blk_id * B;
+        const int lend = s_rp[w][a_hi];
+        chunk = (lend - lbeg + nteams - 1) / nteams;
+        tbeg = lbeg + gteam * chunk;
+        tend = (tbeg + chunk < lend) ? tbeg + chunk : lend;
+        tpos = 0;
+        while (tpos < B - 1 && tbeg >= s_rp[w][tpos + 1]) ++tpos;
+        rp_next = s_rp[w][tpos + 1];
+        for (int bo = 0; bo < chunk; bo += 16) {
+            const int e0 = tbeg + bo;
+            if (e0 < tend) {  // uniform per team
+                const int ei = (e0 + q < tend) ? e0 + q : tend - 1;  // lanes past the chunk repeat its last entry
+                const int ent = entry[ei];
+                const int emt = emeta[ei];
+                const float ecf = ecoef[ei];
+                const int left = __builtin_amdgcn_readfirstlane(tend - e0);  // team 0 of a wave: longest remainder
+#pragma unroll
+                for (int j0 = 0; j0 < 16; j0 += U)
+                    if (left > j0) run_fast(role, ent, emt, ecf, j0, e0 + j0);
+            }
+            if (bo == 0 && role != ROLE_COLLECT) BK_WSTAMP(6);
+            __syncthreads();
+            if (bo == 0 && role != ROLE_COLLECT) BK_WSTAMP(7);
+            const int nq = s_qn;
+            for (int i = team; i < nq; i += TEAMS)  // uniform per team
+                run_slow((unsigned)s_q[i][0], s_q[i][1], __builtin_bit_cast(float, s_q[i][2]), s_q[i][3] != 0);
+            if (bo == 0 && role == ROLE_ACC) BK_WSTAMP(2);
+            __syncthreads();
+            if (tid == 0) s_qn = 0;
+        }
+    };
+
+    if (mode == 0) {
+        walk(ROLE_ACC, c, 1);
+        BK_WSTAMP(3);
+    } else {
+        if (have_c) walk(ROLE_COLLECT, c, 1);
+        BK_WSTAMP(2);
+        if (have_p) walk(ROLE_APPLY, p, 0);
+        BK_WSTAMP(3);
+    }
+    if (have_c) {  // uniform per launch
+        flush();
+        __syncthreads();
+        BK_WSTAMP(4);
+        for (int o = tid; o < B * (n + 2); o += NTH) {
+            const int t = o / (n + 2), f = o % (n + 2);
+            const double tot = s_acc[t][(f < n) ? f : FB * 64 + (f - n)];
+            if (tot != 0.0) atomicAdd(bb + (int64_t)t * (n + 2) + f, tot);
+        }
+    }
+    BK_WSTAMP(5);
+    if (stamp0 >= 0 && tid == 0)
+        for (int i = 0; i < 8; ++i) g_bk_stamp[stamp0 + i] = ts[i];
+#undef BK_WSTAMP
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct BkIndex {
+    const int32_t* row_ptr;
+    const int32_t* entry;
+    const int32_t* emeta;
+    const float* ecoef;
+};
+
+static size_t narrow_lds_bytes(int n, int B) {
+    const size_t nf = (size_t)((n + 63) / 64) * 64;
+    return ((size_t)3 * B * nf + (size_t)B * (n + 2) + (size_t)bk_maxg(B) * (nf + B)) * sizeof(double);
+}
+
+template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
+static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ldr, int n, int k, const BkIndex& ix,
+                            const int32_t* idx, float* coef, const float* D, float* Dnext, double* bbuf,
+                            const BkLayout& lay, hipStream_t stream) {
+    // only X(c >= 1) runs the narrow step and needs its LDS (up to ~100 KB of the 160 KB of a gfx950 workgroup)
+    const bool narrow = (mode == 0 && c >= 1);
+    const size_t lds = narrow ? narrow_lds_bytes(n, 1 << LOGB) : 0;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    LYS_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bksvd_step_kernel<FB, LOGB, SL, TEAMS, FULL>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)narrow_lds_bytes(64 * FB, 1 << LOGB)));
+        attr_set[dev] = true;
+    }
+    const int grid = (mode == 0 && c >= nb) ? 1 : BK_WBLOCKS + (narrow ? 1 : 0);
+    hipLaunchKernelGGL((bksvd_step_kernel<FB, LOGB, SL, TEAMS, FULL>), dim3(grid), dim3(16 * TEAMS), lds, stream, mode,
+                       c, nb, K, R, ldr, n, k, ix.row_ptr, ix.entry, ix.emeta, ix.ecoef, idx, coef, D, Dnext,
+                       padded_features(n), bbuf, lay);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+template <int FB, int LOGB, int TEAMS>
+static int launch_step(int sl, int mode, int c, int nb, int K, float* R, int64_t ldr, int n, int k, const BkIndex& ix,
+                       const int32_t* idx, float* coef, const float* D, float* Dnext, double* bbuf, const BkLayout& lay,
+                       hipStream_t stream) {
+#define BK_A mode, c, nb, K, R, ldr, n, k, ix, idx, coef, D, Dnext, bbuf, lay, stream
+    const bool full = (n == 64 * FB);
+    switch (sl) {
+        case 1: return full ? launch_step_full<FB, LOGB, 1, TEAMS, true>(BK_A) : launch_step_full<FB, LOGB, 1, TEAMS, false>(BK_A);
+        case 2: return full ? launch_step_full<FB, LOGB, 2, TEAMS, true>(BK_A) : launch_step_full<FB, LOGB, 2, TEAMS, false>(BK_A);
+        default: return full ? launch_step_full<FB, LOGB, 4, TEAMS, true>(BK_A) : launch_step_full<FB, LOGB, 4, TEAMS, false>(BK_A);
+    }
+#undef BK_A
+}
+
+// One half step: mode 0 = X(c), c in [0, nb]; mode 1 = Y(c), c in [1, nb] (see the header of this file).
+// row_ptr / entry / emeta / ecoef: lys_bksvd_index.
+int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr,
+               const int32_t* entry, const int32_t* emeta, const float* ecoef, const int32_t* idx, float* coef,
+               const float* D, float* Dnext, double* bbuf, hipStream_t stream) {
+    if (n > 256 || k > 64 || (B != 4 && B != 8) || (B == 8 && n > 128)) {
+        set_error("bksvd_step: unsupported shape n=%d k=%d B=%d", n, k, B);
+        return LYS_ENOSUP;
+    }
+    const int nb = (K + B - 1) / B;
+    if ((mode != 0 && mode != 1) || c < mode || c > nb) {
+        set_error("bksvd_step: mode %d, block %d of %d", mode, c, nb);
+        return LYS_EINVAL;
+    }
+    const BkIndex ix{row_ptr, entry, emeta, ecoef};
+    const BkLayout lay = bk_layout(n, B);
+    const int sl = (k <= 16) ? 1 : (k <= 32) ? 2 : 4;
+    const int fb = (n <= 64) ? 1 : (n <= 128) ? 2 : 4;
+#define BK_ARGS sl, mode, c, nb, K, R, ldr, n, k, ix, idx, coef, D, Dnext, bbuf, lay, stream
+    if (fb == 1) return (B == 8) ? launch_step<1, 3, 64>(BK_ARGS) : launch_step<1, 2, 64>(BK_ARGS);
+    if (fb == 2) return (B == 8) ? launch_step<2, 3, 64>(BK_ARGS) : launch_step<2, 2, 64>(BK_ARGS);
+    return launch_step<4, 2, 32>(BK_ARGS);
+#undef BK_ARGS
+}
+
+int bk_debug_timestamps(unsigned long long* out64) {
+    LYS_CHECK_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_bk_stamp), 64 * sizeof(unsigned long long)));
+    return LYS_OK;
+}
+
+size_t bksvd_stats_doubles(int n, int K, int B) {
+    const BkLayout lay = bk_layout(n, B);
+    return (size_t)((K + B - 1) / B) * (size_t)lay.stride;
+}
+
+int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int32_t* row_ptr,
+                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int32_t* emeta, float* ecoef,
+                int logb);  // ksvd.hip
+
+// One full cycle on one GPU: index, 2 K/B + 1 launches, D <- D_next.  bbuf is zeroed here.
+int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
+                const int32_t* nnz, int B, int32_t* row_ptr, int32_t* entry, int32_t* emeta, float* ecoef, void* ws,
+                size_t ws_bytes, double* bbuf, float* D, float* Dnext, hipStream_t stream) {
+    if (k > 64 || (unsigned long long)N * (unsigned long long)ldr * 4ull >= (1ull << 32) ||
+        (unsigned long long)N * (unsigned long long)k * 4ull >= (1ull << 32)) {
+        set_error("bksvd_sweep: k = %d, N = %lld outside the block sweep's range", k, (long long)N);
+        return LYS_ENOSUP;
+    }
+    if (B != 4 && B != 8) {
+        set_error("bksvd_sweep: block size %d", B);
+        return LYS_EINVAL;
+    }
+    int rc = csr_by_atom(idx, coef, nnz, K, k, N, row_ptr, entry, ws, ws_bytes, stream, emeta, ecoef, B == 8 ? 3 : 2);
+    if (rc) return rc;
+    LYS_CHECK_HIP(hipMemsetAsync(bbuf, 0, bksvd_stats_doubles(n, K, B) * sizeof(double), stream));
+    const int nb = (K + B - 1) / B;
+    for (int c = 0; c <= nb; ++c) {
+        rc = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, entry, emeta, ecoef, idx, coef, D, Dnext, bbuf, stream);
+        if (rc) return rc;
+        if (c >= 1) {
+            rc = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, entry, emeta, ecoef, idx, coef, D, Dnext, bbuf, stream);
+            if (rc) return rc;
+        }
+    }
+    LYS_CHECK_HIP(hipMemcpyAsync(D, Dnext, (size_t)K * padded_features(n) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return LYS_OK;
+}
+
+}  // namespace lys

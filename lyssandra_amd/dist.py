@@ -110,6 +110,28 @@ def ksvd_cycle_sharded(ops, K, group=None):
     return [int(a) for a in (counts == 0).nonzero().flatten().tolist()]
 
 
+def ksvd_cycle_blocks(ops, group=None):
+    """One cycle of the BLOCK sweep over signal shards (csrc/ksvd_block.hip).  Per block c of B atoms:
+
+        ops.step(0, c) -> X(c): the B sequential atom updates of block c-1 from its (reduced) statistics slab,
+                                replicated on every rank, next to block c's statistics over the local signals that do
+                                not use block c-1
+        ops.step(1, c) -> Y(c): block c-1 applied to the local residual rows / codes + the rest of block c's statistics
+        ops.slab(c)    -> fp64 tensor [stride]: per-atom sums (ksvd.py:118), counts and tuple moments of block c
+
+    i.e. K/B all-reduces of one slab each instead of K all-reduces of n+1 numbers, all enqueued on the stream without
+    a host synchronisation (the collective is asynchronous with respect to the host).  Returns the atoms unused on
+    every rank (the counts travel inside the slabs)."""
+    ops.begin()
+    for c in range(ops.nb + 1):
+        ops.step(0, c)
+        if c >= 1:
+            ops.step(1, c)
+        if c < ops.nb:
+            allreduce_sum_(ops.slab(c), group)
+    return ops.finish()
+
+
 # ------------------------------------------------------------------------------------------------ online DL
 def odl_batch_sharded(ops, beta, non_neg=False, group=None):
     """One mini-batch of online DL over shards: local increments, one all-reduce of [dA | dB], replicated update.

@@ -364,7 +364,8 @@ class HipKsvdOps(object):
     def fused_step(self, a):
         """[pending update of atom a-1] + [accumulation for atom a] in one launch (a = K: only the last update)."""
         _lib.check(self.lib.lys_ksvd_fused_step(a, self.dd.K, _ptr(self.R), _ld(self.R), self.dd.n, self.k,
-                                                _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.idx), _ptr(self.coef),
+                                                _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.emeta), _ptr(self.ecoef),
+                                           _ptr(self.idx), _ptr(self.coef),
                                                 _ptr(self.sbuf), _ptr(self.dd.D), _ptr(self.Dnext), _stream()),
                    "lys_ksvd_fused_step")
 
@@ -393,15 +394,107 @@ class HipKsvdOps(object):
         return _torch().nonzero(counts == 0).flatten().cpu().numpy().tolist()
 
 
-def ksvd_cycle(R, dd, idx, coef, nnz, group=None, buffers=None):
+class HipBlockKsvdOps(object):
+    """Block Gauss-Seidel form of the sweep (csrc/ksvd_block.hip): B atoms per step, 2 K/B + 1 dependent launches, one
+    statistics slab per block -- the `ops` of dist.ksvd_cycle_blocks and the single-GPU sweep."""
+
+    def __init__(self, R, dd, idx, coef, nnz, buffers=None, block=None):
+        torch = _torch()
+        self.lib = lib = _lib.load()
+        self.R, self.dd, self.coef, self.idx = R, dd, coef, idx
+        self.k = int(idx.shape[1])
+        self.N = int(idx.shape[0])
+        self.B = int(block) if block else int(lib.lys_bksvd_block_size(dd.n))
+        self.nb = (dd.K + self.B - 1) // self.B
+        lay = (ctypes.c_int32 * 6)()
+        _lib.check(lib.lys_bksvd_layout(dd.n, self.B, lay), "lys_bksvd_layout")
+        self.stride, self.head = int(lay[0]), int(lay[5])
+        if buffers is None:
+            buffers = {}
+        key = ("blk", self.N, self.k, dd.K, dd.n, self.B)
+        if buffers.get("bkey") != key:
+            buffers["bkey"] = key
+            buffers["brow_ptr"] = torch.empty((dd.K + 1,), dtype=torch.int32, device=dd.device)
+            buffers["bentry"] = torch.empty((max(1, self.N * self.k),), dtype=torch.int32, device=dd.device)
+            buffers["bemeta"] = torch.empty((max(1, self.N * self.k),), dtype=torch.int32, device=dd.device)
+            buffers["becoef"] = torch.empty((max(1, self.N * self.k),), dtype=torch.float32, device=dd.device)
+            buffers["stats"] = torch.zeros((self.nb, self.stride), dtype=torch.float64, device=dd.device)
+            buffers["bDnext"] = torch.zeros_like(dd.D)
+        self.row_ptr, self.entry = buffers["brow_ptr"], buffers["bentry"]
+        self.emeta, self.ecoef = buffers["bemeta"], buffers["becoef"]
+        self.stats, self.Dnext = buffers["stats"], buffers["bDnext"]
+        self.nnz = nnz
+        self.ws = _workspace(max(int(lib.lys_csr_workspace_bytes(dd.K, self.k, self.N)), 4), dd.device, "csr")
+
+    @staticmethod
+    def supported(dd, k, N):
+        return dd.n <= 256 and k <= 64 and N * dd.ldd * 4 < (1 << 32) and N * k * 4 < (1 << 32)
+
+    def counts(self):
+        """Non-zeros per atom seen by the last cycle (after a multi-GPU run: summed over ranks)."""
+        torch = _torch()
+        n = self.dd.n
+        c = self.stats[:, :self.head].reshape(self.nb, self.B, n + 2)[:, :, n + 1].reshape(-1)[:self.dd.K]
+        return c.round().to(torch.int64)
+
+    def unused(self):
+        return _torch().nonzero(self.counts() == 0).flatten().cpu().numpy().tolist()
+
+    # -- single GPU: everything in one C call
+    def sweep_single_gpu(self):
+        dd = self.dd
+        _lib.check(self.lib.lys_bksvd_sweep(_ptr(self.R), _ld(self.R), dd.n, dd.K, self.k, self.N, _ptr(self.idx),
+                                            _ptr(self.coef), _ptr(self.nnz), self.B, _ptr(self.row_ptr),
+                                            _ptr(self.entry), _ptr(self.emeta), _ptr(self.ecoef), _ptr(self.ws),
+                                            self.ws.numel(), _ptr(self.stats), _ptr(dd.D), _ptr(self.Dnext),
+                                            _stream()), "lys_bksvd_sweep")
+        dd.invalidate()
+        return self.unused()
+
+    # -- the `ops` interface of dist.ksvd_cycle_blocks
+    def begin(self):
+        _lib.check(self.lib.lys_bksvd_index(_ptr(self.idx), _ptr(self.coef), _ptr(self.nnz), self.dd.K, self.k, self.N,
+                                            self.B, _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.emeta),
+                                            _ptr(self.ecoef), _ptr(self.ws), self.ws.numel(), _stream()),
+                   "lys_bksvd_index")
+        self.stats.zero_()
+
+    def step(self, mode, c):
+        """mode 0 = X(c): block c-1's atom updates (from its reduced slab) || block c's statistics over the signals that
+        do not use block c-1; mode 1 = Y(c): block c-1 applied + the rest of block c's statistics."""
+        dd = self.dd
+        _lib.check(self.lib.lys_bksvd_step(mode, c, self.B, _ptr(self.R), _ld(self.R), dd.n, dd.K, self.k,
+                                           _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.emeta), _ptr(self.ecoef),
+                                           _ptr(self.idx), _ptr(self.coef), _ptr(dd.D), _ptr(self.Dnext),
+                                           _ptr(self.stats), _stream()), "lys_bksvd_step")
+
+    def slab(self, c):
+        return self.stats[c]
+
+    def finish(self):
+        self.dd.D[:self.dd.K].copy_(self.Dnext[:self.dd.K])
+        self.dd.invalidate()
+        return self.unused()
+
+
+def ksvd_cycle(R, dd, idx, coef, nnz, group=None, buffers=None, block=None):
     """One dictionary-update cycle (atoms 0..K-1 in order) of approx K-SVD, in place on R, coef and dd.D.
 
     Returns the list of unused atoms of this cycle (lyssa/dict_learning/ksvd.py:111-115).
-    ``group``: torch.distributed process group => signals are sharded over its ranks and the n+1 sufficient
-    statistics of every atom are all-reduced between the two phases (dist.ksvd_cycle_sharded).
-    ``buffers``: a dict kept by the caller across cycles/iterations; index / statistics buffers are allocated once
-    in it so that the sweep's captured hipGraph is replayed instead of re-captured.
+    Default: the block Gauss-Seidel sweep (HipBlockKsvdOps; ``block`` = 4 or 8 overrides the block size).
+    ``group``: torch.distributed process group => signals are sharded over its ranks and ONE statistics slab per block
+    of atoms is all-reduced (dist.ksvd_cycle_blocks).  LYS_KSVD_LEGACY=1 (or an unsupported shape: n > 256, k > 64)
+    selects the one-launch-per-atom kernels of ksvd.hip with a per-atom exchange (dist.ksvd_cycle_sharded).
+    ``buffers``: a dict kept by the caller across cycles/iterations (index / statistics buffers allocated once).
     """
+    import os
+    k = int(idx.shape[1])
+    if os.environ.get("LYS_KSVD_LEGACY", "0") != "1" and HipBlockKsvdOps.supported(dd, k, int(idx.shape[0])):
+        ops = HipBlockKsvdOps(R, dd, idx, coef, nnz, buffers, block=block)
+        if group is None:
+            return ops.sweep_single_gpu()
+        from . import dist as _d
+        return _d.ksvd_cycle_blocks(ops, group)
     ops = HipKsvdOps(R, dd, idx, coef, nnz, buffers)
     if group is None:
         return ops.sweep_single_gpu()
