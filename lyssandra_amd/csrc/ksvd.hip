@@ -168,7 +168,9 @@ __global__ __launch_bounds__(64) void csr_count_or_fill_kernel(const int32_t* __
                                                                const int32_t* __restrict__ row_ptr,
                                                                int32_t* __restrict__ entry, int fill,
                                                                int32_t* __restrict__ emeta = nullptr,
-                                                               float* __restrict__ ecoef = nullptr, int logb = 0) {
+                                                               float* __restrict__ ecoef = nullptr, int logb = 0,
+                                                               int32_t* __restrict__ cg_cur = nullptr,
+                                                               int32_t* __restrict__ cg_entry = nullptr) {
     extern __shared__ int s_cnt[];
     const int lane = threadIdx.x;
     const int chunk = blockIdx.x;
@@ -196,19 +198,33 @@ __global__ __launch_bounds__(64) void csr_count_or_fill_kernel(const int32_t* __
             for (int u = 0; u < U; ++u) {
                 const bool live = cv[u] != 0.f && av[u] >= 0 && av[u] < K;
                 int meta = lane;
-                if (fill == 2) {
-                    // block sweep (ksvd_block.hip): entry = signal id + the entry's coefficient + its slot and three flags
-                    // about the signal's OTHER atoms: same block of 2^logb atoms (bit 8), previous block (9), next (10)
+                if (logb > 0) {
+                    // block sweep (ksvd_block.hip): entry = signal id + the entry's coefficient + its slot and flags
+                    // about the signal's atoms: another atom in the same block of 2^logb atoms (bit 8), in the previous
+                    // block (9), in the next (10); bit 11: this entry is the LEADER (smallest atom of its block in the
+                    // signal).  Leaders of coupled signals that do not touch the previous block are also listed in a second
+                    // index sorted by (block, in-block atom mask): their tuple moments are summed group by group.
                     const int a = live ? av[u] : -1;
                     const int blk = a >> logb;
+                    const int bsz = 1 << logb;
+                    unsigned msk = 0;
                     for (int j = 0; j < k; ++j) {  // wave-uniform loop over the signal's slots
                         const int aj = __builtin_amdgcn_readlane(a, j);
-                        if (aj >= 0 && j != lane) {
+                        if (aj >= 0) {
                             const int bj = aj >> logb;
-                            meta |= (bj == blk) ? 0x100 : 0;
+                            msk |= (bj == blk) ? (1u << (aj & (bsz - 1))) : 0u;
                             meta |= (bj == blk - 1) ? 0x200 : 0;
                             meta |= (bj == blk + 1) ? 0x400 : 0;
                         }
+                    }
+                    const bool coupled = (msk & (msk - 1)) != 0;
+                    const bool leader = live && ((a & (bsz - 1)) == __ffs(msk) - 1);
+                    meta |= coupled ? 0x100 : 0;
+                    meta |= leader ? 0x800 : 0;
+                    if (cg_cur && leader && coupled && !(meta & 0x200)) {
+                        const int key = (blk << bsz) | (int)msk;
+                        const int pos = atomicAdd(&cg_cur[key], 1);  // count pass: a counter; fill pass: the position
+                        if (fill) cg_entry[pos] = (int32_t)(sb + u);
                     }
                 }
                 if (live) {
@@ -308,10 +324,15 @@ int csr_scan(int32_t* counts, int rows, int T, int32_t* totals, int32_t* row_ptr
     return LYS_OK;
 }
 
-static void csr_plan(int64_t N, int& T, int64_t& S) {
-    int64_t t = (N + 255) / 256;
+// One wave walks a chunk of signals in order; the number of chunks T sets the parallelism of the build (the per-signal
+// work is a serial chain per wave), bounded by the K x T counter table (<= 64 MB).
+static void csr_plan(int64_t N, int K, int& T, int64_t& S) {
+    int64_t t = (N + 63) / 64;
+    int64_t cap = (16ll << 20) / (K > 0 ? K : 1);
+    if (cap > 8192) cap = 8192;
+    if (cap < 256) cap = 256;
     if (t < 1) t = 1;
-    if (t > 2048) t = 2048;
+    if (t > cap) t = cap;
     T = (int)t;
     S = (N + T - 1) / T;
 }
@@ -319,23 +340,33 @@ static void csr_plan(int64_t N, int& T, int64_t& S) {
 size_t csr_workspace_bytes(int K, int k, int64_t N) {
     int T;
     int64_t S;
-    csr_plan(N, T, S);
+    csr_plan(N, K, T, S);
     return ((size_t)K * (size_t)T + (size_t)K) * sizeof(int32_t);
 }
 
 // emeta == nullptr: entry = signal*k + slot (per-atom kernels, online DL).  Otherwise (block sweep, k <= 64): entry =
-// signal id, ecoef = the entry's coefficient, emeta = slot | flags (see csr_count_or_fill_kernel), blocks of 2^logb atoms.
+// signal id, ecoef = the entry's coefficient, emeta = slot | flags (see csr_count_or_fill_kernel), blocks of 2^logb atoms,
+// plus the coupled-leader index cg_ptr [nb * 2^B + 1] / cg_entry [<= N*k/2] keyed by (block << B) | in-block mask.
+size_t csr_block_workspace_bytes(int K, int k, int64_t N, int B) {
+    const size_t nkey = (size_t)((K + B - 1) / B) << B;
+    return csr_workspace_bytes(K, k, N) + (nkey + 1) * sizeof(int32_t);
+}
+
 int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int32_t* row_ptr,
-                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int32_t* emeta, float* ecoef, int logb) {
-    if (emeta && k > 64) {
-        set_error("csr_by_atom: block-sweep index needs k <= 64 (k = %d)", k);
+                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int32_t* emeta, float* ecoef, int logb,
+                int32_t* cg_ptr, int32_t* cg_entry) {
+    if (emeta && (k > 64 || !cg_ptr || !cg_entry || (logb != 2 && logb != 3))) {
+        set_error("csr_by_atom: block-sweep index needs k <= 64, B in {4, 8} and the coupled-leader buffers (k = %d)", k);
         return LYS_ENOSUP;
     }
     int T;
     int64_t S;
-    csr_plan(N, T, S);
-    if (ws_bytes < ((size_t)K * T + K) * sizeof(int32_t)) {
-        set_error("csr_by_atom: workspace %zu < %zu", ws_bytes, ((size_t)K * T + K) * sizeof(int32_t));
+    csr_plan(N, K, T, S);
+    const int B = emeta ? (1 << logb) : 1;
+    const size_t nkey = emeta ? ((size_t)((K + B - 1) / B) << B) : 0;
+    const size_t need = ((size_t)K * T + K) * sizeof(int32_t) + (emeta ? (nkey + 1) * sizeof(int32_t) : 0);
+    if (ws_bytes < need) {
+        set_error("csr_by_atom: workspace %zu < %zu", ws_bytes, need);
         return LYS_EWORKSPACE;
     }
     if ((int64_t)N * k > 0x7fffffffLL) {
@@ -348,16 +379,24 @@ int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K
     }
     int32_t* counts = static_cast<int32_t*>(ws);
     int32_t* totals = counts + (size_t)K * T;
+    int32_t* cg_cur = emeta ? totals + K : nullptr;
     const size_t lds = (size_t)K * sizeof(int);
+    if (emeta) LYS_CHECK_HIP(hipMemsetAsync(cg_cur, 0, (nkey + 1) * sizeof(int32_t), stream));
     hipLaunchKernelGGL(csr_count_or_fill_kernel, dim3(T), dim3(64), lds, stream, idx, coef, nnz, K, k, N, T, S, counts,
-                       row_ptr, entry, 0);
+                       row_ptr, entry, 0, (int32_t*)nullptr, (float*)nullptr, emeta ? logb : 0, cg_cur,
+                       (int32_t*)nullptr);
     LYS_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_scan_atoms_kernel, dim3(K), dim3(256), 0, stream, counts, T, totals);
     LYS_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, totals, K, row_ptr);
     LYS_LAUNCH_CHECK();
+    if (emeta) {
+        hipLaunchKernelGGL(csr_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, cg_cur, (int)nkey, cg_ptr);
+        LYS_LAUNCH_CHECK();
+        LYS_CHECK_HIP(hipMemcpyAsync(cg_cur, cg_ptr, (nkey + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    }
     hipLaunchKernelGGL(csr_count_or_fill_kernel, dim3(T), dim3(64), lds, stream, idx, coef, nnz, K, k, N, T, S, counts,
-                       row_ptr, entry, emeta ? 2 : 1, emeta, ecoef, logb);
+                       row_ptr, entry, emeta ? 2 : 1, emeta, ecoef, emeta ? logb : 0, cg_cur, cg_entry);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }

@@ -38,6 +38,8 @@
 //   G = 2^B - 1 - B, group index g = (2^t - 1 - t) + (pi - 1).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace lys {
@@ -271,8 +273,10 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
                         u[b][e] = (f < n) ? bb[lay.offQ + (int64_t)g * n + f] : 0.0;
                     }
             }
-            for (int l = 0; l < t; ++l) {  // Horner: u = P_l (u + c_l d_l^old), l ascending over the prefix set
-                if (!((pi >> l) & 1u)) continue;
+            // Horner: u = P_l (u + c_l d_l^old), l ascending over the prefix set.  The loop runs over the SET bits (a
+            // wave's four teams hold different prefix sets: a loop over all l < t would execute the body for the union)
+            for (unsigned rest = pi; rest; rest &= rest - 1) {
+                const int l = __ffs(rest) - 1;
                 const double cl = (sl >= 0) ? QC[(size_t)sl * (NF + B) + NF + l] : bb[lay.offC + (int64_t)g * B + l];
                 double dot = 0.0;
 #pragma unroll
@@ -358,11 +362,14 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                                                                 const int32_t* __restrict__ entry,
                                                                 const int32_t* __restrict__ emeta,
                                                                 const float* __restrict__ ecoef,
+                                                                const int32_t* __restrict__ cg_ptr,
+                                                                const int32_t* __restrict__ cg_entry,
                                                                 const int32_t* __restrict__ idx,
                                                                 float* __restrict__ coef, const float* __restrict__ D,
                                                                 float* __restrict__ Dnext, int ldd,
                                                                 double* __restrict__ bbuf, BkLayout lay) {
     constexpr int B = 1 << LOGB;
+    constexpr int G = (1 << B) - 1 - B;
     constexpr int U = (FB == 1) ? 8 : 4;  // signals in flight per team
     constexpr int NTH = 16 * TEAMS;
     extern __shared__ double sm[];  // narrow step only
@@ -537,9 +544,57 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
         }
     };
 
-    constexpr int F_COUPLED = 0x100, F_PREV = 0x200, F_NEXT = 0x400;  // see csr_count_or_fill_kernel (ksvd.hip)
+    // the same, X(c)'s group phase: moments of the populous groups are summed in the workgroup's LDS slots first
+    // (s_gslot[g] >= 0), so that the ~90 signals of a pair group do not serialise 90 fp64 atomics per address at the
+    // memory side; rare groups go straight to the slab
+    auto coupled_grouped = [&](const float4 (&r)[FB], const int (&a)[SL], const float (&x)[SL], int t1, float x1,
+                               unsigned m2, double* gq, const short* gslot) {
+        float xq = (q == t1) ? x1 : 0.f;
+        unsigned pi = 1u << t1;
+        while (m2) {
+            const int t = __ffs(m2) - 1;
+            m2 &= m2 - 1;
+            const float xj = value_of(a, x, c * B + t);
+            const int g = ((1 << t) - 1 - t) + (int)pi - 1;
+            const int sl = gslot[g];
+            if (sl >= 0) {
+                double* dst = gq + (size_t)sl * (FB * 64 + B + 1);
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    atomicAdd(dst + 64 * b + 4 * q + 0, (double)(xj * r[b].x));
+                    atomicAdd(dst + 64 * b + 4 * q + 1, (double)(xj * r[b].y));
+                    atomicAdd(dst + 64 * b + 4 * q + 2, (double)(xj * r[b].z));
+                    atomicAdd(dst + 64 * b + 4 * q + 3, (double)(xj * r[b].w));
+                }
+                if (q < B && ((pi >> q) & 1u)) atomicAdd(dst + FB * 64 + q, (double)xj * (double)xq);
+                if (q == 0) atomicAdd(dst + FB * 64 + B, 1.0);
+            } else {
+                double* Qg = bb + lay.offQ + (int64_t)g * n;
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    const int f = 64 * b + 4 * q;
+                    if (f < n) atomicAdd(Qg + f, (double)(xj * r[b].x));
+                    if (f + 1 < n) atomicAdd(Qg + f + 1, (double)(xj * r[b].y));
+                    if (f + 2 < n) atomicAdd(Qg + f + 2, (double)(xj * r[b].z));
+                    if (f + 3 < n) atomicAdd(Qg + f + 3, (double)(xj * r[b].w));
+                }
+                if (q < B && ((pi >> q) & 1u)) atomicAdd(bb + lay.offC + (int64_t)g * B + q, (double)xj * (double)xq);
+                if (q == 0) atomicAdd(bb + lay.offGC + g, 1.0);
+            }
+            if (q == 0) {
+                atomicAdd(&s_acc[t][FB * 64], (double)xj * (double)xj);
+                atomicAdd(&s_acc[t][FB * 64 + 1], 1.0);
+            }
+            xq = (q == t) ? xj : xq;
+            pi |= 1u << t;
+        }
+    };
+
+    constexpr int F_COUPLED = 0x100, F_PREV = 0x200, F_NEXT = 0x400, F_LEADER = 0x800;  // csr_count_or_fill_kernel
     // What a walk does with an entry (role):
-    //   ROLE_ACC      X(c), list c : PREV -> nothing (Y's job); COUPLED -> queue; else accumulate (fast)
+    //   ROLE_ACC      X(c), list c : PREV -> nothing (Y's job); non-leader entry of a coupled signal -> nothing; else
+    //                                accumulate x R_i (fast).  The tuple moments of the coupled signals follow in the
+    //                                group phase below, from the index sorted by (block, in-block mask).
     //   ROLE_COLLECT  Y(c), list c : PREV -> queue; else nothing (X did it)
     //   ROLE_APPLY    Y(c), list p : NEXT -> nothing (its list-c entry is PREV, queued above); COUPLED -> queue; else
     //                                apply the entry's atom (fast: coefficient and slot came with the index)
@@ -556,8 +611,8 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
             xe[u] = __builtin_bit_cast(float, bk_row_bcast_dyn(__builtin_bit_cast(int, ecf), j0 + u));
             bool skip, slow;
             if (role == ROLE_ACC) {
-                skip = (m & F_PREV) && p >= 0;
-                slow = !skip && (m & F_COUPLED);
+                skip = ((m & F_PREV) && p >= 0) || ((m & F_COUPLED) && !(m & F_LEADER));
+                slow = false;
             } else if (role == ROLE_COLLECT) {
                 slow = (m & F_PREV) != 0;
                 skip = !slow;
@@ -687,6 +742,110 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     if (mode == 0) {
         walk(ROLE_ACC, c, 1);
         BK_WSTAMP(3);
+        // ---- group phase: tuple moments of the coupled signals of block c (their leaders, sorted by in-block mask).
+        // Workgroup w takes the entries [w * GCH, (w + 1) * GCH) of the block's range, 2 per team (loaded together).
+        constexpr int GPT = 2;
+        constexpr int GCH = GPT * TEAMS;
+        constexpr int NS = 24;                   // LDS slots of (NF + B + 1) doubles each, in the dynamic LDS
+        constexpr int SW = FB * 64 + B + 1;
+        __shared__ short s_gslot[G > 0 ? G : 1];
+        __shared__ short s_sg[NS];
+        __shared__ int s_nslot;
+        const int kb = c << B;  // first key of the block
+        const int cgb = cg_ptr[kb], cge = cg_ptr[kb + (1 << B)];
+        const int lo = cgb + (int)blockIdx.x * GCH;
+        if (lo < cge) {  // uniform per workgroup
+            const int hi = (lo + GCH < cge) ? lo + GCH : cge;
+            double* gq = sm;
+            for (int i = tid; i < G; i += NTH) s_gslot[i] = -1;
+            for (int i = tid; i < NS * SW; i += NTH) gq[i] = 0.0;
+            if (tid == 0) s_nslot = 0;
+            __syncthreads();
+            if (tid < (1 << B)) {  // one thread per mask: groups of the masks with >= 4 signals in this range get slots
+                const int kk = kb + tid;
+                const int b0 = max(cg_ptr[kk], lo), b1 = min(cg_ptr[kk + 1], hi);
+                const unsigned M = (unsigned)tid;
+                if (b1 - b0 >= 4 && (M & (M - 1))) {
+                    const int nt = __popc(M) - 1;
+                    const int base = atomicAdd(&s_nslot, nt);
+                    if (base + nt <= NS) {
+                        unsigned rest = M & (M - 1), pi = M & (0u - M);
+                        int j = 0;
+                        while (rest) {
+                            const int t = __ffs(rest) - 1;
+                            rest &= rest - 1;
+                            const int g = ((1 << t) - 1 - t) + (int)pi - 1;
+                            s_gslot[g] = (short)(base + j);
+                            s_sg[base + j] = (short)g;
+                            pi |= 1u << t;
+                            ++j;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            {
+                float4 r[GPT][FB];
+                int a[GPT][SL];
+                float x[GPT][SL];
+                unsigned mk[GPT];
+#pragma unroll
+                for (int u = 0; u < GPT; ++u) {  // loads of both signals first (the entry index is clamped)
+                    const int e = lo + team * GPT + u;
+                    const unsigned sig = (unsigned)cg_entry[(e < hi) ? e : hi - 1];
+#pragma unroll
+                    for (int b = 0; b < FB; ++b) {
+                        const int f = 64 * b + 4 * q;
+                        r[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (FULL || f < n)
+                            r[u][b] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R) + (sig * rsz + 4u * f));
+                    }
+#pragma unroll
+                    for (int s = 0; s < SL; ++s) {
+                        const int j = q + 16 * s;
+                        const unsigned off = sig * ksz + 4u * (unsigned)((j < k) ? j : k - 1);
+                        a[u][s] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(idx) + off);
+                        x[u][s] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(coef) + off);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GPT; ++u) {
+                    unsigned m = 0;
+#pragma unroll
+                    for (int s = 0; s < SL; ++s) {
+                        const bool live = (q + 16 * s < k) && (x[u][s] != 0.f);
+                        a[u][s] = live ? a[u][s] : -1;
+                        m |= ((a[u][s] >> LOGB) == c) ? (1u << (a[u][s] & (B - 1))) : 0u;
+                    }
+                    mk[u] = bk_row16_or(m);
+                }
+#pragma unroll
+                for (int u = 0; u < GPT; ++u) {
+                    if (lo + team * GPT + u >= hi) break;  // uniform per team
+                    const unsigned m2 = mk[u] & (mk[u] - 1);
+                    if (m2) {
+                        const int t1 = __ffs(mk[u]) - 1;
+                        coupled_grouped(r[u], a[u], x[u], t1, value_of(a[u], x[u], c * B + t1), m2, gq, s_gslot);
+                    }
+                }
+            }
+            __syncthreads();
+            const int ns = min(s_nslot, NS);
+            for (int i = tid; i < ns * SW; i += NTH) {  // slots -> slab
+                const int sl = i / SW, e = i % SW, g = s_sg[sl];
+                const double v = gq[i];
+                if (v != 0.0) {
+                    if (e < FB * 64) {
+                        if (e < n) atomicAdd(bb + lay.offQ + (int64_t)g * n + e, v);
+                    } else if (e < FB * 64 + B) {
+                        atomicAdd(bb + lay.offC + (int64_t)g * B + (e - FB * 64), v);
+                    } else {
+                        atomicAdd(bb + lay.offGC + g, v);
+                    }
+                }
+            }
+        }
+        BK_WSTAMP(2);
     } else {
         if (have_c) walk(ROLE_COLLECT, c, 1);
         BK_WSTAMP(2);
@@ -717,7 +876,14 @@ struct BkIndex {
     const int32_t* entry;
     const int32_t* emeta;
     const float* ecoef;
+    const int32_t* cg_ptr;
+    const int32_t* cg_entry;
 };
+
+static size_t group_lds_bytes(int n, int B) {  // LDS slots of X(c)'s group phase (NS = 24 in the kernel)
+    const size_t nf = (size_t)((n + 63) / 64) * 64;
+    return (size_t)24 * (nf + B + 1) * sizeof(double);
+}
 
 static size_t narrow_lds_bytes(int n, int B) {
     const size_t nf = (size_t)((n + 63) / 64) * 64;
@@ -730,20 +896,20 @@ static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ld
                             const BkLayout& lay, hipStream_t stream) {
     // only X(c >= 1) runs the narrow step and needs its LDS (up to ~100 KB of the 160 KB of a gfx950 workgroup)
     const bool narrow = (mode == 0 && c >= 1);
-    const size_t lds = narrow ? narrow_lds_bytes(n, 1 << LOGB) : 0;
+    const size_t lds = (mode != 0) ? 0 : std::max(narrow ? narrow_lds_bytes(n, 1 << LOGB) : 0, group_lds_bytes(n, 1 << LOGB));
     static bool attr_set[64] = {};
     int dev = 0;
     LYS_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bksvd_step_kernel<FB, LOGB, SL, TEAMS, FULL>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)narrow_lds_bytes(64 * FB, 1 << LOGB)));
+                                          (int)std::max(narrow_lds_bytes(64 * FB, 1 << LOGB), group_lds_bytes(64 * FB, 1 << LOGB))));
         attr_set[dev] = true;
     }
     const int grid = (mode == 0 && c >= nb) ? 1 : BK_WBLOCKS + (narrow ? 1 : 0);
     hipLaunchKernelGGL((bksvd_step_kernel<FB, LOGB, SL, TEAMS, FULL>), dim3(grid), dim3(16 * TEAMS), lds, stream, mode,
-                       c, nb, K, R, ldr, n, k, ix.row_ptr, ix.entry, ix.emeta, ix.ecoef, idx, coef, D, Dnext,
-                       padded_features(n), bbuf, lay);
+                       c, nb, K, R, ldr, n, k, ix.row_ptr, ix.entry, ix.emeta, ix.ecoef, ix.cg_ptr, ix.cg_entry, idx, coef, D,
+                       Dnext, padded_features(n), bbuf, lay);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -765,8 +931,9 @@ static int launch_step(int sl, int mode, int c, int nb, int K, float* R, int64_t
 // One half step: mode 0 = X(c), c in [0, nb]; mode 1 = Y(c), c in [1, nb] (see the header of this file).
 // row_ptr / entry / emeta / ecoef: lys_bksvd_index.
 int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr,
-               const int32_t* entry, const int32_t* emeta, const float* ecoef, const int32_t* idx, float* coef,
-               const float* D, float* Dnext, double* bbuf, hipStream_t stream) {
+               const int32_t* entry, const int32_t* emeta, const float* ecoef, const int32_t* cg_ptr,
+               const int32_t* cg_entry, const int32_t* idx, float* coef, const float* D, float* Dnext, double* bbuf,
+               hipStream_t stream) {
     if (n > 256 || k > 64 || (B != 4 && B != 8) || (B == 8 && n > 128)) {
         set_error("bksvd_step: unsupported shape n=%d k=%d B=%d", n, k, B);
         return LYS_ENOSUP;
@@ -776,7 +943,7 @@ int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int 
         set_error("bksvd_step: mode %d, block %d of %d", mode, c, nb);
         return LYS_EINVAL;
     }
-    const BkIndex ix{row_ptr, entry, emeta, ecoef};
+    const BkIndex ix{row_ptr, entry, emeta, ecoef, cg_ptr, cg_entry};
     const BkLayout lay = bk_layout(n, B);
     const int sl = (k <= 16) ? 1 : (k <= 32) ? 2 : 4;
     const int fb = (n <= 64) ? 1 : (n <= 128) ? 2 : 4;
@@ -798,13 +965,14 @@ size_t bksvd_stats_doubles(int n, int K, int B) {
 }
 
 int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int32_t* row_ptr,
-                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int32_t* emeta, float* ecoef,
-                int logb);  // ksvd.hip
+                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int32_t* emeta, float* ecoef, int logb,
+                int32_t* cg_ptr, int32_t* cg_entry);  // ksvd.hip
 
 // One full cycle on one GPU: index, 2 K/B + 1 launches, D <- D_next.  bbuf is zeroed here.
 int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
-                const int32_t* nnz, int B, int32_t* row_ptr, int32_t* entry, int32_t* emeta, float* ecoef, void* ws,
-                size_t ws_bytes, double* bbuf, float* D, float* Dnext, hipStream_t stream) {
+                const int32_t* nnz, int B, int32_t* row_ptr, int32_t* entry, int32_t* emeta, float* ecoef,
+                int32_t* cg_ptr, int32_t* cg_entry, void* ws, size_t ws_bytes, double* bbuf, float* D, float* Dnext,
+                hipStream_t stream) {
     if (k > 64 || (unsigned long long)N * (unsigned long long)ldr * 4ull >= (1ull << 32) ||
         (unsigned long long)N * (unsigned long long)k * 4ull >= (1ull << 32)) {
         set_error("bksvd_sweep: k = %d, N = %lld outside the block sweep's range", k, (long long)N);
@@ -814,15 +982,16 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
         set_error("bksvd_sweep: block size %d", B);
         return LYS_EINVAL;
     }
-    int rc = csr_by_atom(idx, coef, nnz, K, k, N, row_ptr, entry, ws, ws_bytes, stream, emeta, ecoef, B == 8 ? 3 : 2);
+    int rc = csr_by_atom(idx, coef, nnz, K, k, N, row_ptr, entry, ws, ws_bytes, stream, emeta, ecoef, B == 8 ? 3 : 2,
+                         cg_ptr, cg_entry);
     if (rc) return rc;
     LYS_CHECK_HIP(hipMemsetAsync(bbuf, 0, bksvd_stats_doubles(n, K, B) * sizeof(double), stream));
     const int nb = (K + B - 1) / B;
     for (int c = 0; c <= nb; ++c) {
-        rc = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, entry, emeta, ecoef, idx, coef, D, Dnext, bbuf, stream);
+        rc = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, entry, emeta, ecoef, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
         if (rc) return rc;
         if (c >= 1) {
-            rc = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, entry, emeta, ecoef, idx, coef, D, Dnext, bbuf, stream);
+            rc = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, entry, emeta, ecoef, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
             if (rc) return rc;
         }
     }

@@ -418,13 +418,17 @@ class HipBlockKsvdOps(object):
             buffers["bentry"] = torch.empty((max(1, self.N * self.k),), dtype=torch.int32, device=dd.device)
             buffers["bemeta"] = torch.empty((max(1, self.N * self.k),), dtype=torch.int32, device=dd.device)
             buffers["becoef"] = torch.empty((max(1, self.N * self.k),), dtype=torch.float32, device=dd.device)
+            buffers["bcg_ptr"] = torch.empty((self.nb * (1 << self.B) + 1,), dtype=torch.int32, device=dd.device)
+            buffers["bcg_entry"] = torch.empty((self.N * self.k // 2 + 1,), dtype=torch.int32, device=dd.device)
             buffers["stats"] = torch.zeros((self.nb, self.stride), dtype=torch.float64, device=dd.device)
             buffers["bDnext"] = torch.zeros_like(dd.D)
         self.row_ptr, self.entry = buffers["brow_ptr"], buffers["bentry"]
         self.emeta, self.ecoef = buffers["bemeta"], buffers["becoef"]
+        self.cg_ptr, self.cg_entry = buffers["bcg_ptr"], buffers["bcg_entry"]
         self.stats, self.Dnext = buffers["stats"], buffers["bDnext"]
         self.nnz = nnz
-        self.ws = _workspace(max(int(lib.lys_csr_workspace_bytes(dd.K, self.k, self.N)), 4), dd.device, "csr")
+        self.ws = _workspace(max(int(lib.lys_bksvd_index_workspace_bytes(dd.K, self.k, self.N, self.B)), 4), dd.device,
+                             "csr")
 
     @staticmethod
     def supported(dd, k, N):
@@ -445,9 +449,9 @@ class HipBlockKsvdOps(object):
         dd = self.dd
         _lib.check(self.lib.lys_bksvd_sweep(_ptr(self.R), _ld(self.R), dd.n, dd.K, self.k, self.N, _ptr(self.idx),
                                             _ptr(self.coef), _ptr(self.nnz), self.B, _ptr(self.row_ptr),
-                                            _ptr(self.entry), _ptr(self.emeta), _ptr(self.ecoef), _ptr(self.ws),
-                                            self.ws.numel(), _ptr(self.stats), _ptr(dd.D), _ptr(self.Dnext),
-                                            _stream()), "lys_bksvd_sweep")
+                                            _ptr(self.entry), _ptr(self.emeta), _ptr(self.ecoef), _ptr(self.cg_ptr),
+                                            _ptr(self.cg_entry), _ptr(self.ws), self.ws.numel(), _ptr(self.stats),
+                                            _ptr(dd.D), _ptr(self.Dnext), _stream()), "lys_bksvd_sweep")
         dd.invalidate()
         return self.unused()
 
@@ -455,8 +459,8 @@ class HipBlockKsvdOps(object):
     def begin(self):
         _lib.check(self.lib.lys_bksvd_index(_ptr(self.idx), _ptr(self.coef), _ptr(self.nnz), self.dd.K, self.k, self.N,
                                             self.B, _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.emeta),
-                                            _ptr(self.ecoef), _ptr(self.ws), self.ws.numel(), _stream()),
-                   "lys_bksvd_index")
+                                            _ptr(self.ecoef), _ptr(self.cg_ptr), _ptr(self.cg_entry), _ptr(self.ws),
+                                            self.ws.numel(), _stream()), "lys_bksvd_index")
         self.stats.zero_()
 
     def step(self, mode, c):
@@ -465,8 +469,8 @@ class HipBlockKsvdOps(object):
         dd = self.dd
         _lib.check(self.lib.lys_bksvd_step(mode, c, self.B, _ptr(self.R), _ld(self.R), dd.n, dd.K, self.k,
                                            _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.emeta), _ptr(self.ecoef),
-                                           _ptr(self.idx), _ptr(self.coef), _ptr(dd.D), _ptr(self.Dnext),
-                                           _ptr(self.stats), _stream()), "lys_bksvd_step")
+                                           _ptr(self.cg_ptr), _ptr(self.cg_entry), _ptr(self.idx), _ptr(self.coef),
+                                           _ptr(dd.D), _ptr(self.Dnext), _ptr(self.stats), _stream()), "lys_bksvd_step")
 
     def slab(self, c):
         return self.stats[c]

@@ -55,6 +55,112 @@ class NumpyKsvdOps(object):
         self.D[:, used] = self.Dnext[:, used]
 
 
+class NumpyBlockKsvdOps(object):
+    """float64 numpy stand-in for engine.HipBlockKsvdOps: the block Gauss-Seidel sweep of csrc/ksvd_block.hip (B atoms
+    per step, exact in-block coupling through tuple moments) with the same `ops` interface and the same slab layout
+    [S (B x (n+2)) | Q (G x n) | C (G x B) | GC (G)], G = 2^B - 1 - B, g = (2^t - 1 - t) + (pi - 1)."""
+
+    def __init__(self, Y, D, Z, B):
+        self.D, self.Z, self.B = D, Z, B
+        self.R = Y - D @ Z
+        self.n, self.K = D.shape
+        self.nb = (self.K + B - 1) // B
+        self.G = (1 << B) - 1 - B
+        n, G = self.n, self.G
+        self.offQ = B * (n + 2)
+        self.offC = self.offQ + G * n
+        self.offGC = self.offC + G * B
+        self.stride = self.offGC + G
+        self.stats = torch.zeros((self.nb, self.stride), dtype=torch.float64)
+        self.Dnext = D.copy()
+
+    def begin(self):
+        self.stats.zero_()
+        self.support = self.Z != 0            # omega of this cycle (ksvd.py:111)
+
+    def slab(self, c):
+        return self.stats[c]
+
+    def _in_block(self, i, c):
+        lo, hi = c * self.B, min(self.K, (c + 1) * self.B)
+        return [a for a in range(lo, hi) if self.support[a, i]]
+
+    def _accumulate(self, c, with_prev):
+        n, B = self.n, self.B
+        s = self.stats[c].numpy()
+        for i in range(self.Z.shape[1]):
+            atoms = self._in_block(i, c)
+            if not atoms:
+                continue
+            uses_prev = c >= 1 and bool(self._in_block(i, c - 1))
+            if uses_prev != with_prev:
+                continue
+            r = self.R[:, i]
+            pi = 0
+            for j, a in enumerate(atoms):
+                t, x = a - c * B, self.Z[a, i]
+                if j == 0:
+                    s[t * (n + 2):t * (n + 2) + n] += x * r
+                else:
+                    g = ((1 << t) - 1 - t) + pi - 1
+                    s[self.offQ + g * n:self.offQ + (g + 1) * n] += x * r
+                    for b in atoms[:j]:
+                        s[self.offC + g * B + (b - c * B)] += x * self.Z[b, i]
+                    s[self.offGC + g] += 1
+                s[t * (n + 2) + n] += x * x
+                s[t * (n + 2) + n + 1] += 1
+                pi |= 1 << t
+
+    def _narrow(self, c):
+        n, B = self.n, self.B
+        s = self.stats[c].numpy()
+        for t in range(B):
+            a = c * B + t
+            if a >= self.K:
+                break
+            if s[t * (n + 2) + n + 1] == 0:
+                continue                       # unused atom keeps its column
+            v = s[t * (n + 2):t * (n + 2) + n] + self.D[:, a] * s[t * (n + 2) + n]
+            for pi in range(1, 1 << t):
+                g = ((1 << t) - 1 - t) + pi - 1
+                if s[self.offGC + g] == 0:
+                    continue
+                u = s[self.offQ + g * n:self.offQ + (g + 1) * n].copy()
+                for l in range(t):
+                    if (pi >> l) & 1:
+                        u += s[self.offC + g * B + l] * self.D[:, c * B + l]
+                        dn = self.Dnext[:, c * B + l]
+                        u -= dn * np.dot(dn, u)
+                v += u
+            self.Dnext[:, a] = v / (np.sqrt(np.dot(v, v)) + EPS)
+
+    def _apply(self, p):
+        for i in range(self.Z.shape[1]):
+            for a in self._in_block(i, p):     # ascending: the sequential order of ksvd.py:105-123
+                xo = self.Z[a, i]
+                v = self.R[:, i] + self.D[:, a] * xo
+                xn = float(np.dot(v, self.Dnext[:, a]))
+                self.R[:, i] = v - self.Dnext[:, a] * xn
+                self.Z[a, i] = xn
+
+    def step(self, mode, c):
+        if mode == 0:
+            if c >= 1:
+                self._narrow(c - 1)
+            if c < self.nb:
+                self._accumulate(c, with_prev=False)
+        else:
+            self._apply(c - 1)
+            if c < self.nb:
+                self._accumulate(c, with_prev=True)
+
+    def finish(self):
+        n = self.n
+        cnt = self.stats[:, :self.B * (n + 2)].reshape(self.nb, self.B, n + 2)[:, :, n + 1].reshape(-1)[:self.K]
+        self.D[:] = self.Dnext
+        return [int(a) for a in (cnt == 0).nonzero().flatten().tolist()]
+
+
 class NumpyOdlOps(object):
     def __init__(self, D, A, B, Xb, Zb):
         self.D, self.A, self.B, self.Xb, self.Zb = D, A, B, Xb, Zb
@@ -101,6 +207,13 @@ def _worker(rank, world, port, out):
         assert unused == list(unused_ref) == [K - 1]
         assert np.max(np.abs(Dl - Dref)) < 1e-12
         assert np.max(np.abs(Zl - Zref[:, span[0]:span[1]])) < 1e-12
+        # ---- the block sweep (one slab all-reduce per block of B atoms) == sequential reference semantics
+        for B in (4, 8):
+            Dl, Zl = D0.copy(), Z[:, span[0]:span[1]].copy()
+            unused = ld.ksvd_cycle_blocks(NumpyBlockKsvdOps(Xl, Dl, Zl, B))
+            assert unused == [K - 1]
+            assert np.max(np.abs(Dl - Dref)) < 1e-11, (B, np.max(np.abs(Dl - Dref)))
+            assert np.max(np.abs(Zl - Zref[:, span[0]:span[1]])) < 1e-11
         # ---- online DL: one all-reduce of [dA | dB] per batch == full-batch statistics
         Do, Ao, Bo = D0.copy(), np.zeros((K, K)), np.zeros((n, K))
         Dg, Ag, Bg = D0.copy(), np.zeros((K, K)), np.zeros((n, K))
@@ -143,6 +256,29 @@ def test_sharded_protocols_gloo_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: 1, 1: 1}
+
+
+@pytest.mark.parametrize("B", [4, 8])
+def test_block_sweep_algebra_matches_sequential_oracle(B):
+    """The block Gauss-Seidel sweep (csrc/ksvd_block.hip) is the reference's sequential sweep, not an approximation:
+    float64 numpy restatement of the X/Y step protocol vs oracle approx_ksvd (ksvd.py:98-126), on codes dense enough
+    that most signals use 2-4 atoms of a block (K = 21 atoms, k = 6), two cycles, K not a multiple of B, one unused atom."""
+    from lyssandra_amd import dist as ld
+    from oracle import lyssa_oracle as orc
+    rs = np.random.RandomState(11 + B)
+    n, K, k, N = 12, 21, 6, 150
+    D0 = orc.norm_cols(rs.randn(n, K))
+    X = rs.randn(n, N)
+    Z = orc.bomp_encode(X, D0, k)
+    Z[5, :] = 0.0
+    Dl, Zl = D0.copy(), Z.copy()
+    ops = NumpyBlockKsvdOps(X, Dl, Zl, B)
+    u1 = ld.ksvd_cycle_blocks(ops)
+    u2 = ld.ksvd_cycle_blocks(ops)
+    Dref, Zref, uref = orc.approx_ksvd(X, D0.copy(), Z.copy(), n_cycles=2)
+    assert u1 + u2 == list(uref) == [5, 5]
+    assert np.max(np.abs(Dl - Dref)) < 1e-11 and np.max(np.abs(Zl - Zref)) < 1e-11
+    assert np.max(np.abs(ops.R - (X - Dl @ Zl))) < 1e-11
 
 
 def test_single_process_is_a_noop_group():
