@@ -12,10 +12,14 @@ its own S patches against the replicated dictionary, no data-path collective (we
 value = N*S*K_steps / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     -- dominant kernel (greedy/Cholesky stage) priced against the fp32 MFMA/VALU peak with HIP-event
-                  durations taken inside the timed region; also the GEMM stage and the whole step
-  cpu_baseline -- the float64 numpy port of the reference path (oracle/) timed on this host's cores on a bounded
-                  sample of the same workload (rank 0, N=1 only)
+  roofline       -- dominant kernel (greedy/Cholesky stage) priced against the fp32 MFMA/VALU peak with HIP-event
+                    durations taken inside the timed region (and the rocprofv3 average of the same kernel from
+                    profiles/kernel_durations.json beside it); also the GEMM stage and the whole step
+  cpu_baseline   -- the float64 numpy port of the reference path (oracle/) timed on this host's cores on a bounded
+                    sample of the same workload (rank 0, N=1 only); the all-cores figures sit beside it as flat keys
+  ksvd_iteration -- auxiliary (not part of `value`): one approx-K-SVD alternation of configs[1] per stage; for N > 1
+                    the sweep runs sharded with its per-block statistics all-reduce and `exchange` is its cost
+  odl_batch      -- auxiliary, N > 1 only: one online-DL mini-batch (statistics, [upper(ZZ') | XZ'] all-reduce, update)
 """
 import argparse
 import ctypes
@@ -40,8 +44,8 @@ def flops_per_signal(n, K, k):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)     # 200 x 4.9 ms: a timed region of about one second
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--patches-per-gpu", dest="signals", type=int, default=1 << 20, help="patches per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ksvd", action="store_true", help="skip the auxiliary approx-K-SVD iteration timing")
@@ -143,6 +147,15 @@ def main():
                 traffic = json.load(open(tpath)).get("bomp_wave_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
+        # rocprofv3 --kernel-trace averages of the same kernels on the same command (tools/profile.sh writes the file,
+        # it is committed under profiles/): the HIP-event figure above must agree with it
+        rocprof = {}
+        dpath = os.path.join(ROOT, "profiles", "kernel_durations.json")
+        if os.path.exists(dpath):
+            try:
+                rocprof = json.load(open(dpath))
+            except Exception:
+                rocprof = {}
         result = {
             "metric": "patches/sec Batch-OMP (1024 atoms, k=10, 64-dim)",
             "value": value,
@@ -172,16 +185,27 @@ def main():
                 "flop_per_patch": f_omp,
                 "patches_per_launch": sig_per_launch,
                 "avg_launch_ms": omp_avg_ms,
+                "rocprof_avg_launch_ms": rocprof.get("bomp_wave_kernel_avg_ms"),
+                "rocprof_source": rocprof.get("source"),
                 "launches_timed": launches.value,
                 "gemm_stage": {"kernel": "alpha0_n64_kernel (alpha0 = X D, v_mfma_f32_32x32x2_f32, software-pipelined buffer stores)",
                                "achieved": gemm_tf, "frac": gemm_tf / PEAK_FP32_TFLOPS, "flop_per_patch": f_gemm,
-                               "avg_launch_ms": gemm_avg_ms},
+                               "avg_launch_ms": gemm_avg_ms,
+                               "rocprof_avg_launch_ms": rocprof.get("alpha0_n64_kernel_avg_ms")},
                 "whole_step": {"achieved": step_tf, "frac": step_tf / PEAK_FP32_TFLOPS,
                                "flop_per_patch": f_gemm + f_omp},
             },
         }
-        if world == 1 and not args.no_ksvd:
-            result["ksvd_iteration"] = ksvd_iteration(Xs, dd, k)
+    # auxiliary legs (every rank takes part in the collectives; rank 0 reports)
+    if not args.no_ksvd:
+        kit = ksvd_iteration(Xs, dd, k, group=(dist.group.WORLD if distributed else None))
+        if rank == 0:
+            result["ksvd_iteration"] = kit
+        if distributed:
+            ob = odl_batch(Xs, dd, k, dist.group.WORLD)
+            if rank == 0:
+                result["odl_batch"] = ob
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(Xs, Dt, k, args.cpu_sample, args.cpu_pool_workers)
         print(json.dumps(result), flush=True)
@@ -191,20 +215,30 @@ def main():
     return result
 
 
-def ksvd_iteration(Xs, dd0, k, iters=3):
-    """Auxiliary, NOT part of `value`: one alternation of configs[1] (approx K-SVD on the same 2^20 patches, 1024 atoms,
+def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
+    """Auxiliary, NOT part of `value`: one alternation of configs[1] (approx K-SVD on 2^20 patches per GPU, 1024 atoms,
     k=10) = encode + residual + atom sweep + error, timed per stage after one untimed iteration.  The sweep is HBM-bound
-    byte work: algorithmic traffic 3*4n bytes per (atom, signal) non-zero."""
+    byte work; SURVEY 8(d) prices it at 8 n bytes per (atom, signal) non-zero (residual row read + written once).
+    With a process group the signals are this rank's shard, the sweep all-reduces one statistics slab per block of
+    atoms (dist.ksvd_cycle_blocks) and `exchange` = sharded sweep - the same sweep without collectives."""
     import torch
+    from lyssandra_amd import dist as ld
     from lyssandra_amd import engine
     n, K = dd0.n, dd0.K
+    ws, rk = ld.world(group)
     dd = engine.DeviceDictionary(n, K, dd0.device)
-    dd.set((Xs[:K] / Xs[:K].norm(dim=1, keepdim=True)).t().contiguous())   # D0 = first K patches, normalised
+    D0 = (Xs[:K] / Xs[:K].norm(dim=1, keepdim=True)).contiguous()   # D0 = rank 0's first K patches, normalised
+    if ws > 1:
+        torch.distributed.broadcast(D0, src=0, group=group)
+    dd.set(D0.t().contiguous())
     out, R, buffers = None, None, {}
     acc = {"encode": 0.0, "residual": 0.0, "sweep": 0.0, "error": 0.0}
+    t_local = 0.0
 
     def timed(fn):
         torch.cuda.synchronize()
+        if ws > 1:
+            torch.distributed.barrier(group=group)
         t0 = time.perf_counter()
         r = fn()
         torch.cuda.synchronize()
@@ -216,23 +250,88 @@ def ksvd_iteration(Xs, dd0, k, iters=3):
         out, t_e = timed(lambda: engine.bomp_encode(Xs, dd, k, out=out))
         idx, coef, nnz = out
         (R, _), t_r = timed(lambda: engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False, out=R))
-        _, t_s = timed(lambda: engine.ksvd_cycle(R, dd, idx, coef, nnz, buffers=buffers))
+        t_l = 0.0
+        if ws > 1:   # the same sweep without collectives, on copies (its result is rank-local and discarded)
+            R2, c2, D2 = R.clone(), coef.clone(), dd.D.clone()
+            _, t_l = timed(lambda: engine.ksvd_cycle(R2, dd, idx, c2, nnz, buffers=buffers))
+            dd.D.copy_(D2)
+            dd.invalidate()
+        _, t_s = timed(lambda: engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group, buffers=buffers))
         err, t_x = timed(lambda: engine.approx_error(Xs, dd, idx, coef, nnz))
         if it > 0:
             acc["encode"] += t_e
             acc["residual"] += t_r
             acc["sweep"] += t_s
             acc["error"] += t_x
+            t_local += t_l
             nnz_tot = int(nnz.sum().item())
+    if ws > 1:
+        t = torch.tensor([err], dtype=torch.float64)
+        ld.allreduce_sum_(t, group)
+        err = float(t.item())
     ms = {kk: v / iters for kk, v in acc.items()}
-    sweep_gbs = 3 * 4 * n * nnz_tot / (ms["sweep"] * 1e-3) / 1e9
-    return {"workload": "approx K-SVD alternation, %d patches, K=%d, k=%d (configs[1]); mean of %d iterations"
-                        % (Xs.shape[0], K, k, iters),
-            "ms": ms, "ms_total": sum(ms.values()),
-            "sweep_roofline": {"bound": "hbm", "achieved": sweep_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": sweep_gbs / PEAK_HBM_GBS,
-                               "note": "2K dependent launches per sweep: latency-bound (DESIGN.md 3.4)"},
-            "final_error": err}
+    if ws > 1:
+        ms["sweep_without_exchange"] = t_local / iters
+        ms["exchange"] = ms["sweep"] - ms["sweep_without_exchange"]
+    sweep_gbs = 8 * n * nnz_tot / (ms["sweep"] * 1e-3) / 1e9
+    B = int(engine._lib.load().lys_bksvd_block_size(n))
+    nb = (K + B - 1) // B
+    res = {"workload": "approx K-SVD alternation, %d patches per GPU on %d GPU(s), K=%d, k=%d (configs[1]); mean of %d "
+                       "iterations" % (Xs.shape[0], ws, K, k, iters),
+           "ms": ms, "ms_total": ms["encode"] + ms["residual"] + ms["sweep"] + ms["error"],
+           "sweep_roofline": {"bound": "hbm", "kernel": "bksvd_step_kernel (block Gauss-Seidel sweep, %d launches of %d "
+                                                        "atoms)" % (2 * nb + 1, B),
+                              "achieved": sweep_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": sweep_gbs / PEAK_HBM_GBS,
+                              "bytes_model": "SURVEY 8(d): 8*n bytes per (atom, signal) non-zero = %.3g GB per sweep per GPU"
+                                             % (8 * n * nnz_tot / 1e9),
+                              "traffic_model_gbs": 12 * n * nnz_tot / (ms["sweep"] * 1e-3) / 1e9,
+                              "traffic_model": "12*n bytes per non-zero: the row is read for the statistics, read and "
+                                               "written for the update"},
+           "final_error": err}
+    if ws > 1:
+        stride = engine.HipBlockKsvdOps(R, dd, idx, coef, nnz, buffers).stride
+        res["exchange"] = {"collectives_per_sweep": nb, "bytes_per_collective": stride * 8,
+                           "bytes_per_sweep": nb * stride * 8}
+    return res
+
+
+def odl_batch(Xs, dd0, k, group, iters=3):
+    """Auxiliary, N > 1: one online-DL mini-batch on this rank's shard (online_dict_learn.py:84-98): local Z Z' / X Z',
+    ONE all-reduce of [block-upper(ZZ') | XZ'], replicated dictionary update."""
+    import torch
+    from lyssandra_amd import dist as ld
+    from lyssandra_amd import engine
+    n, K = dd0.n, dd0.K
+    dd = engine.DeviceDictionary(n, K, dd0.device)
+    dd.D.copy_(dd0.D)
+    idx, coef, nnz = engine.bomp_encode(Xs, dd, k)
+    state = engine.OdlState(dd)
+    state._batch = (Xs, idx, coef, nnz)
+    acc = {"increments": 0.0, "exchange": 0.0, "update": 0.0}
+    for it in range(iters + 1):
+        torch.cuda.synchronize()
+        torch.distributed.barrier(group=group)
+        t0 = time.perf_counter()
+        dA, dB = state.increments()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ld.allreduce_symmetric_(dA, extra=dB, group=group)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        state.update(0.9)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        if it > 0:
+            acc["increments"] += (t1 - t0) * 1e3
+            acc["exchange"] += (t2 - t1) * 1e3
+            acc["update"] += (t3 - t2) * 1e3
+    Kp = state.A.shape[0]
+    nblk = (Kp + 1023) // 1024
+    packed = sum((min((i + 1) * 1024, Kp) - i * 1024) * (Kp - i * 1024) for i in range(nblk)) + state.B.numel()
+    return {"workload": "online-DL mini-batch of %d patches per GPU, K=%d, k=%d" % (Xs.shape[0], K, k),
+            "ms": {kk: v / iters for kk, v in acc.items()},
+            "exchange_bytes": packed * 4, "dense_bytes": (state.A.numel() + state.B.numel()) * 4}
 
 
 def _cpu_worker(job):
@@ -276,24 +375,26 @@ def cpu_baseline(Xs, Dt, k, sample, pool_workers=-1):
                 t0 = time.perf_counter()
                 done = sum(pool.map(_cpu_worker, jobs))
                 dtp = time.perf_counter() - t0
-            out["all_cores"] = {"value": done / dtp, "unit": "patches/s", "cores": len(jobs),
-                                "sample": "%d patches over %d spawned processes (one column batch each), %.1f s"
-                                          % (done, len(jobs), dtp)}
+            out["all_cores_value"] = done / dtp
+            out["all_cores_cores"] = len(jobs)
+            out["all_cores_sample"] = ("%d patches over %d spawned processes (one column batch each, the reference's "
+                                       "run_parallel strategy), %.1f s" % (done, len(jobs), dtp))
         except Exception as e:  # the baseline must never take the bench line down
-            out["all_cores"] = {"error": repr(e)}
+            out["all_cores_error"] = repr(e)
     # informative: the plain-C restatement (oracle/bomp_oracle.c, OpenMP over signals) -- what a tuned CPU port does
     try:
         from oracle import c_oracle
-        n_c = min(Xs.shape[0], 200000)
+        n_c = min(Xs.shape[0], 1 << 20)          # a few seconds of work on all cores
         Xc = Xs[:n_c].t().contiguous().double().cpu().numpy()
         c_oracle.bomp_encode_sparse(Xc[:, :256], D, k)
         t0 = time.perf_counter()
         c_oracle.bomp_encode_sparse(Xc, D, k)
         dtc = time.perf_counter() - t0
-        out["c_port_all_cores"] = {"value": n_c / dtc, "unit": "patches/s", "cores": os.cpu_count(),
-                                   "sample": "%d patches, float64 C restatement with OpenMP, %.1f s" % (n_c, dtc)}
+        out["c_port_value"] = n_c / dtc
+        out["c_port_cores"] = os.cpu_count()
+        out["c_port_sample"] = "%d patches, float64 C restatement with OpenMP on all cores, %.1f s" % (n_c, dtc)
     except Exception as e:
-        out["c_port_all_cores"] = {"error": repr(e)}
+        out["c_port_error"] = repr(e)
     return out
 
 

@@ -77,6 +77,12 @@ def online_dict_learn(X, n_atoms, sparse_coder=None, batch_size=None, A=None, B=
             for i, batch in zip(range(n_iter), batch_idx):
                 Xb, (idx, coef, nnz) = encode(batch)
                 error_curr += engine.approx_error(Xb, dd, idx, coef, nnz)
+            if group is not None:  # every rank must take the same patience / early-return decisions
+                import torch
+                from .. import dist as _d
+                t = torch.tensor([error_curr], dtype=torch.float64)
+                _d.allreduce_sum_(t, group)
+                error_curr = float(t.item())
             if verbose:
                 print("end of epoch %d: error %.6g (diff %.6g)" % (e, error_curr, error_curr - error_prev))
                 error_prev = error_curr

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ksvd"
+BENCH="python $PWD/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-ksvd"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 # PMC passes: counters in their own runs (never combined with sys/hip trace domains)
@@ -15,6 +15,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > /
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o pmc -- $BENCH > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/pmc_mfma -o pmc -- $BENCH > /dev/null 2> $OUT/pmc_mfma.err
 cd - > /dev/null
-python $PWD/tools/summarize_profile.py $OUT > $PWD/gpurun_out/prof_${TAG}_summary.txt 2>&1
+python $PWD/tools/summarize_profile.py $OUT $PWD/gpurun_out/kernel_durations_${TAG}.json > $PWD/gpurun_out/prof_${TAG}_summary.txt 2>&1
 find $OUT -name "*.db" -delete   # summaries only: keep the merge under the gpurun_out size cap
 tail -60 $PWD/gpurun_out/prof_${TAG}_summary.txt

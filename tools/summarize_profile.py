@@ -5,6 +5,8 @@ import sqlite3
 import sys
 
 root = sys.argv[1]
+json_out = sys.argv[2] if len(sys.argv) > 2 else None   # e.g. profiles/kernel_durations.json (read by bench.py)
+durations = {}
 
 
 def short(name):
@@ -23,6 +25,10 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         for name, calls, tot, avg, pct in cur.execute(
                 "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 16"):
             print("%-86s %7d %14d %12.0f %7.2f" % (short(name), calls, tot, avg, pct))
+            for key in ("bomp_wave_kernel", "alpha0_n64_kernel", "bksvd_step_kernel"):
+                if key in name and key + "_avg_ms" not in durations:
+                    durations[key + "_avg_ms"] = avg / 1e3   # top_kernels.average is in us
+                    durations[key + "_calls"] = calls
         print("\nregister / LDS use per kernel (from the dispatch records):")
         for name, v, a, s, lds, wg, gx in cur.execute(
                 "select name,vgpr_count,accum_vgpr_count,sgpr_count,lds_size,workgroup_x,max(grid_x) from kernels group by name order by sum(duration) desc limit 10"):
@@ -38,3 +44,8 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
             r = rows[name]
             vals = ", ".join("%s=%.5g" % (c, v) for c, v in sorted(r.items()) if c not in ("n", "dur"))
             print("%-60s dispatches=%d avg_ns=%.0f  %s" % (short(name)[-60:], r["n"], r["dur"], vals))
+
+if json_out:
+    import json
+    durations["source"] = "rocprofv3 --kernel-trace --stats of `python bench.py` (tools/profile.sh), averages over all launches"
+    json.dump(durations, open(json_out, "w"), indent=1)
