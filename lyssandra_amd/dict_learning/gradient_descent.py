@@ -6,6 +6,7 @@ dictionary-learning test drives (lyssa/dict_learning/tests/test_dictionary_learn
 D (ZZ') - XZ' (the online-DL statistics kernels), D <- norm_cols(clip(D - eta*grad + 2 mu D (D'D - I))) in one MFMA GEMM.
 """
 import ctypes
+from ._base import learner_shell, reference_patience, starting_dictionary
 
 import numpy as np
 
@@ -25,20 +26,15 @@ def projected_grad_desc(X, n_atoms=None, sparse_coder=None, batch_size=None, D_i
         raise ValueError('Must specify learning rate.')
     torch = engine.require_gpu()
     lib = _lib.load()
-    sparse_coder.verbose = False
     X = np.asarray(X)
-    n_features, n_samples = X.shape
-    if D_init is None:
-        from .utils import init_dictionary
-        D, _ = init_dictionary(X, n_atoms, method='data', return_unused_data=True)
-    else:
-        D = D_init
+    setattr(sparse_coder, "verbose", False)
+    D = starting_dictionary(X, n_atoms, D_init)
     Xs = engine.signals_to_device(X)
     dd = engine.DeviceDictionary.from_host(D)
     device_coder = isinstance(sparse_coder, sparse_encoder) and sparse_coder.algorithm in ('bomp', 'omp', 'thresh')
     state = engine.OdlState(dd)                 # reuses its dA / dB buffers
     scratch = torch.empty((dd.Kp * dd.Kp + 2 * dd.Kp * dd.ldd,), dtype=torch.float32, device=dd.device)
-    batch_idx = gen_batches(n_samples, batch_size=batch_size)
+    batch_idx = gen_batches(X.shape[1], batch_size=batch_size)
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)  # noqa: E731
     use_mu = mu is not None and mu > 0
 
@@ -48,9 +44,7 @@ def projected_grad_desc(X, n_atoms=None, sparse_coder=None, batch_size=None, D_i
             return Xb, sparse_coder.encode_device(Xb, dd)
         return Xb, engine.sparsify_host(sparse_coder(X[:, batch], dd.to_host()))
 
-    max_patience = 10
-    error_prev = 0
-    patience = 0
+    stop = reference_patience(verbose)
     n_epochs = 1 if n_epochs is None else n_epochs
     for e in range(n_epochs):
         for batch in batch_idx:
@@ -62,49 +56,27 @@ def projected_grad_desc(X, n_atoms=None, sparse_coder=None, batch_size=None, D_i
                                           float(mu) if use_mu else 0.0, int(bool(non_neg)), P(scratch),
                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "lys_pgd_update")
             dd.invalidate()
-        if e < n_epochs - 1:
-            error_curr = 0
-            for batch in batch_idx:
-                Xb, (idx, coef, nnz) = encode(batch)
-                error_curr += engine.approx_error(Xb, dd, idx, coef, nnz)
-            if verbose:
-                print("end of epoch %d: error %.6g (diff %.6g)" % (e, error_curr, error_curr - error_prev))
-                error_prev = error_curr
-            if (e > 0) and (error_curr > 0.9 * error_prev or error_curr > error_prev):
-                patience += 1
-            if patience >= max_patience:
-                break
+        if e == n_epochs - 1:
+            break
+        error = 0
+        for batch in batch_idx:
+            Xb, (idx, coef, nnz) = encode(batch)
+            error += engine.approx_error(Xb, dd, idx, coef, nnz)
+        if verbose:
+            print("end of epoch %d: error %.6g (diff %.6g)" % (e, error, stop.change(error)))
+        stop.observe(e, error)
+        if stop.exhausted:
+            break
     return dd.to_host()
 
 
-class dictionary_learner():
-    """lyssa/dict_learning/gradient_descent.py:128-160."""
+class dictionary_learner(learner_shell):
+    """lyssa/dict_learning/gradient_descent.py:128-160: keyword holder around ``projected_grad_desc``."""
+    _forward = ("sparse_coder", "batch_size", "mu", "D_init", "eta", "n_epochs", "verbose", "n_jobs", "non_neg", "mmap")
 
     def __init__(self, n_atoms=None, sparse_coder=None, batch_size=None, eta=None, mu=None, D_init=None,
                  n_epochs=1, verbose=False, memory="low", mmap=False, non_neg=False, n_jobs=1):
-        self.n_atoms = n_atoms
-        self.sparse_coder = sparse_coder
-        self.batch_size = batch_size
-        self.eta = eta
-        self.mu = mu
-        self.n_epochs = n_epochs
-        self.D_init = D_init
-        self.memory = memory
-        self.verbose = verbose
-        self.n_jobs = n_jobs
-        self.mmap = mmap
-        self.non_neg = non_neg
+        self._hold(locals())
 
-    def __call__(self, X):
-        self.fit(X)
-        return self.encode(X)
-
-    def fit(self, X):
-        self.D = projected_grad_desc(X, n_atoms=self.n_atoms, sparse_coder=self.sparse_coder,
-                                     batch_size=self.batch_size, mu=self.mu, D_init=self.D_init,
-                                     eta=self.eta, n_epochs=self.n_epochs, verbose=self.verbose, n_jobs=self.n_jobs,
-                                     non_neg=self.non_neg, mmap=self.mmap)
-
-    def encode(self, X):
-        Z = self.sparse_coder(X, self.D)
-        return Z
+    def _learn(self, X):
+        self.D = projected_grad_desc(X, n_atoms=self.n_atoms, **self._learner_kwargs())

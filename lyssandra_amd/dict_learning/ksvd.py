@@ -12,6 +12,7 @@ import numpy as np
 from .. import engine
 from ..sparse_coding import sparse_encoder
 from ..utils.math import normalize
+from ._base import learner_shell, reference_patience
 
 
 def _is_device_coder(sc):
@@ -82,6 +83,10 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
     are all-reduced, `init_dict='data'` and the unused-atom replacement work on GLOBAL signal indices (every rank
     must hold the same numpy RNG state).  The returned codes are the local shard's.
     """
+    if max_iter is None:
+        # the reference's default (ksvd_coder(max_iter=None)): under Python 2 `0 < None` is False, the loop never runs and
+        # the initial dictionary is returned with all-zero codes -- reproduced explicitly instead of a py3 TypeError
+        max_iter = 0
     if non_neg and not approx:
         raise NotImplementedError("nn_ksvd (non_neg=True with approx=False) is outside the accelerated path")
     if not approx and group is not None:
@@ -89,7 +94,7 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
     if eta is not None and group is not None:
         raise NotImplementedError("eta (force_mi) is not available in group (sharded) mode")
     X = np.asarray(X)
-    n_features, n_samples = X.shape
+    n_samples = X.shape[1]
     unused_data = []
     if group is not None:
         from .. import dist as _dist
@@ -110,16 +115,13 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
         sparse_coder.mmap = True
     if verbose:
         print("dictionary initialized")
-    max_patience = 10
-    error_curr = 0
-    error_prev = 0
+    stop = reference_patience(verbose)
     it = 0
-    patience = 0
     idx = coef = nnz = None
     out = None            # code triplet, residual and index buffers are allocated once and reused every iteration
     R = None
     buffers = {}
-    while it < max_iter and patience < max_patience:
+    while it < max_iter and not stop.exhausted:
         it_start = time.time()
         # ---- sparse coding
         if device_coder:
@@ -137,14 +139,13 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
             else:  # ksvd.py:189-190: exact rank-1 update
                 unused_atoms += engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=buffers)
         # ---- replace unused atoms (host RNG, ksvd.py:199-207)
-        for j in range(len(unused_atoms)):
-            if len(unused_data) == 0:
+        for atom in unused_atoms:
+            if not unused_data:
                 break
-            _idx = np.random.choice(unused_data, size=1)
-            i_ = _idx[0]
-            col = X[:, i_] if group is None else _dist.fetch_global_column(X, shard_span, int(i_), group)
-            dd.set_atom(unused_atoms[j], normalize(np.asarray(col, dtype=np.float64)))
-            unused_data.remove(i_)
+            pick = np.random.choice(unused_data, size=1)[0]        # one draw per replaced atom, global RNG
+            col = X[:, pick] if group is None else _dist.fetch_global_column(X, shard_span, int(pick), group)
+            dd.set_atom(atom, normalize(np.asarray(col, dtype=np.float64)))
+            unused_data.remove(pick)
         # ---- force mutual incoherence, not in the last iteration (ksvd.py:209-213)
         if eta is not None and it < max_iter - 1:
             from .utils import force_mi
@@ -152,15 +153,13 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
             Dh, unused_data = force_mi(Dh, X, (idx, coef, nnz), unused_data, eta)
             dd.set(Dh)
         # ---- error with the updated codes (ksvd.py:220)
-        error_curr = engine.approx_error(Xs, dd, idx, coef, nnz)
+        error = engine.approx_error(Xs, dd, idx, coef, nnz)
         if group is not None:
-            error_curr = _allreduce_scalar(error_curr, dd.device, group)
+            error = _allreduce_scalar(error, dd.device, group)
         if verbose:
             print("iteration %d: sparse coding %.3fs, total %.3fs, unused atoms %d, error %.6g (diff %.6g)"
-                  % (it, t_sparse, time.time() - it_start, len(unused_atoms), error_curr, error_curr - error_prev))
-            error_prev = error_curr
-        if (it > 0) and (error_curr > 0.9 * error_prev or error_curr > error_prev):
-            patience += 1
+                  % (it, t_sparse, time.time() - it_start, len(unused_atoms), error, stop.change(error)))
+        stop.observe(it, error)
         it += 1
     D_out = dd.to_host()
     if idx is None:
@@ -180,39 +179,16 @@ def _allreduce_scalar(v, device, group):
     return float(t.item())
 
 
-class ksvd_coder(object):
-    """lyssa/dict_learning/ksvd.py:234-271 -- kwargs holder around ``ksvd_dict_learn``."""
+class ksvd_coder(learner_shell):
+    """lyssa/dict_learning/ksvd.py:234-271: keyword holder around ``ksvd_dict_learn``; the dictionary ends up in ``.D``.
+    ``n_nonzero_coefs`` is accepted and ignored like in the reference (the sparsity lives in ``sparse_coder.params``)."""
+    _forward = ("init_dict", "sparse_coder", "max_iter", "non_neg", "approx", "eta", "n_cycles", "n_jobs", "mmap",
+                "verbose")
 
     def __init__(self, n_atoms=None, n_nonzero_coefs=None, sparse_coder=None, init_dict="data",
                  max_iter=None, non_neg=False, approx=True, eta=None, n_cycles=1, n_jobs=1,
                  mmap=False, verbose=True):
-        self.n_atoms = n_atoms
-        self.sparse_coder = sparse_coder
-        self.max_iter = max_iter
-        self.non_neg = non_neg
-        self.approx = approx
-        self.eta = eta
-        self.n_jobs = n_jobs
-        self.init_dict = init_dict
-        self.n_cycles = n_cycles
-        self.verbose = verbose
-        self.mmap = mmap
-        self.D = None
+        self._hold(locals())
 
-    def _fit(self, X):
-        D, _ = ksvd_dict_learn(X, self.n_atoms, init_dict=self.init_dict,
-                               sparse_coder=self.sparse_coder, max_iter=self.max_iter,
-                               non_neg=self.non_neg, approx=self.approx, eta=self.eta, n_cycles=self.n_cycles,
-                               n_jobs=self.n_jobs, mmap=self.mmap, verbose=self.verbose, return_codes=False)
-        self.D = D
-
-    def __call__(self, X):
-        self._fit(X)
-        Z = self.sparse_coder(X, self.D)
-        return Z
-
-    def fit(self, X):
-        self._fit(X)
-
-    def encode(self, X):
-        return self.sparse_coder(X, self.D)
+    def _learn(self, X):
+        self.D, _ = ksvd_dict_learn(X, self.n_atoms, return_codes=False, **self._learner_kwargs())

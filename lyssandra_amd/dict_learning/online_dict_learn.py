@@ -5,6 +5,7 @@ per-batch arithmetic on the device: sparse coding, A += ZZ', B += XZ' from the s
 dictionary update D <- norm_cols(D + (B - DA) diag(1/(A_kk+eps))) with DA computed once per batch.
 """
 import numpy as np
+from ._base import learner_shell, reference_patience, starting_dictionary
 
 from .. import engine
 from ..sparse_coding import sparse_encoder
@@ -24,29 +25,18 @@ def online_dict_learn(X, n_atoms, sparse_coder=None, batch_size=None, A=None, B=
     the patience quirk (:101-118).  ``D_init`` is updated in place like the reference (D = D_init, :46).
     ``group``: torch.distributed group when every rank holds a shard of each mini-batch (A|B all-reduced).
     """
-    sparse_coder.verbose = False
     X = np.asarray(X)
-    n_features, n_samples = X.shape
-    if D_init is None:
-        from .utils import init_dictionary
-        D, unused_data = init_dictionary(X, n_atoms, method='data', return_unused_data=True)
-    else:
-        D = D_init
+    setattr(sparse_coder, "verbose", False)                        # :41
+    D = starting_dictionary(X, n_atoms, D_init)
     Xs = engine.signals_to_device(X)
     dd = engine.DeviceDictionary.from_host(D)
     device_coder = _is_device_coder(sparse_coder)
-
-    batch_idx = gen_batches(n_samples, batch_size=batch_size)
-    n_batches = len(batch_idx)
-    n_iter = n_batches
-    if A is None and B is None:
-        state = engine.OdlState(dd)
-    else:
-        state = engine.OdlState(dd, A=A, B=B)
-    if beta is None:
-        beta = np.linspace(0, 1, num=n_iter)
-    else:
-        beta = np.zeros(n_iter) + beta
+    batch_idx = gen_batches(X.shape[1], batch_size=batch_size)
+    n_iter = len(batch_idx)
+    warm = not (A is None and B is None)                           # :59-63: both or none
+    state = engine.OdlState(dd, A=A, B=B) if warm else engine.OdlState(dd)
+    # forgetting factors of one epoch: a ramp 0 .. 1 (restarted every epoch, so its first batch wipes A and B), or constant
+    beta = np.linspace(0, 1, num=n_iter) if beta is None else np.full(n_iter, beta, dtype=np.float64)
 
     def encode(batch):
         Xb = Xs[batch.start:batch.stop]
@@ -62,64 +52,40 @@ def online_dict_learn(X, n_atoms, sparse_coder=None, batch_size=None, A=None, B=
             return D, state.A_host(), state.B_host()
         return Dh, state.A_host(), state.B_host()
 
-    max_patience = 10
-    error_curr = 0
-    error_prev = 0
-    patience = 0
+    stop = reference_patience(verbose)
     for e in range(n_epochs):
         for i, batch in zip(range(n_iter), batch_idx):
             Xb, (idx, coef, nnz) = encode(batch)
             state.batch_update(Xb, idx, coef, nnz, beta[i], non_neg=non_neg, group=group)
-        if e < n_epochs - 1:
-            if patience >= max_patience:
-                return finish()
-            error_curr = 0
-            for i, batch in zip(range(n_iter), batch_idx):
-                Xb, (idx, coef, nnz) = encode(batch)
-                error_curr += engine.approx_error(Xb, dd, idx, coef, nnz)
-            if group is not None:  # every rank must take the same patience / early-return decisions
-                import torch
-                from .. import dist as _d
-                t = torch.tensor([error_curr], dtype=torch.float64)
-                _d.allreduce_sum_(t, group)
-                error_curr = float(t.item())
-            if verbose:
-                print("end of epoch %d: error %.6g (diff %.6g)" % (e, error_curr, error_curr - error_prev))
-                error_prev = error_curr
-            if (e > 0) and (error_curr > 0.9 * error_prev or error_curr > error_prev):
-                patience += 1
+        if e == n_epochs - 1:
+            break                                                  # no error pass after the last epoch (:101)
+        if stop.exhausted:
+            return finish()
+        error = 0
+        for i, batch in zip(range(n_iter), batch_idx):
+            Xb, (idx, coef, nnz) = encode(batch)
+            error += engine.approx_error(Xb, dd, idx, coef, nnz)
+        if group is not None:  # every rank must take the same patience / early-return decisions
+            import torch
+            from .. import dist as _d
+            t = torch.tensor([error], dtype=torch.float64)
+            _d.allreduce_sum_(t, group)
+            error = float(t.item())
+        if verbose:
+            print("end of epoch %d: error %.6g (diff %.6g)" % (e, error, stop.change(error)))
+        stop.observe(e, error)
     return finish()
 
 
-class online_dictionary_coder():
-    """lyssa/dict_learning/online_dict_learn.py:127-160 -- keeps .D, .A, .B; A and B warm-start the next fit."""
+class online_dictionary_coder(learner_shell):
+    """lyssa/dict_learning/online_dict_learn.py:127-160: keeps ``.D``, ``.A``, ``.B``; the statistics A and B warm-start
+    the next ``fit`` while ``D_init`` is NOT refreshed (the reference's behaviour, pinned by the warm-start golden)."""
+    _forward = ("sparse_coder", "batch_size", "D_init", "beta", "n_epochs", "verbose", "n_jobs", "non_neg", "mmap")
 
     def __init__(self, n_atoms=None, sparse_coder=None, batch_size=None, beta=None, D_init=None,
                  n_epochs=1, verbose=False, memory="low", mmap=False, non_neg=False, n_jobs=1):
-        self.n_atoms = n_atoms
-        self.sparse_coder = sparse_coder
-        self.batch_size = batch_size
-        self.beta = beta
-        self.n_epochs = n_epochs
-        self.A = None
-        self.B = None
-        self.D_init = D_init
-        self.memory = memory
-        self.verbose = verbose
-        self.n_jobs = n_jobs
-        self.mmap = mmap
-        self.non_neg = non_neg
+        self._hold(locals())
+        self.A = self.B = None
 
-    def __call__(self, X):
-        self.fit(X)
-        return self.encode(X)
-
-    def fit(self, X):
-        self.D, self.A, self.B = online_dict_learn(X, self.n_atoms, sparse_coder=self.sparse_coder,
-                                                   batch_size=self.batch_size, A=self.A, B=self.B, D_init=self.D_init,
-                                                   beta=self.beta, n_epochs=self.n_epochs, verbose=self.verbose,
-                                                   n_jobs=self.n_jobs, non_neg=self.non_neg, mmap=self.mmap)
-
-    def encode(self, X):
-        Z = self.sparse_coder(X, self.D)
-        return Z
+    def _learn(self, X):
+        self.D, self.A, self.B = online_dict_learn(X, self.n_atoms, A=self.A, B=self.B, **self._learner_kwargs())

@@ -93,35 +93,34 @@ def force_mi(D, X, Z, unused_data, eta, max_tries=100):
     returned.
     """
     D = np.asarray(D)
-    n_atoms = D.shape[1]
-    G = np.abs(np.dot(D.T, D))
-    np.fill_diagonal(G, 0)
-    row_norm = _code_row_norms(Z, n_atoms)
-    for atom_idx1 in range(n_atoms):
-        atom_idx2 = int(np.argmax(G[atom_idx1, :]))
-        mcoh = G[atom_idx1, atom_idx2]
-        if mcoh < eta:
+    K = D.shape[1]
+    coherence = np.abs(D.T @ D)            # computed once, never refreshed (:89)
+    coherence[np.diag_indices(K)] = 0.0
+    usage = _code_row_norms(Z, K)
+
+    def column(i):
+        return _normalize(np.asarray(X[:, i], dtype=np.float64))
+
+    for first in range(K):
+        partner = int(coherence[first].argmax())
+        worst = coherence[first, partner]
+        if worst < eta:
             continue
-        c_atom = atom_idx1 if row_norm[atom_idx1] > row_norm[atom_idx2] else atom_idx2
-        cnt = 0
-        available_data = unused_data[:]
-        min_idx = None
-        min_coh = mcoh
-        while mcoh > eta:
-            if cnt > max_tries:
+        victim = first if usage[first] > usage[partner] else partner      # as written at :100-103
+        pool = list(unused_data)
+        best, best_coh, now = None, worst, worst
+        # up to max_tries + 1 draws from the GLOBAL numpy RNG, one `np.random.choice(pool, size=1)` each (:117-133)
+        for _ in range(max_tries + 1):
+            if not now > eta:
                 break
-            if len(available_data) == 0:
+            if not pool:
                 return D, unused_data
-            idx = np.random.choice(available_data, size=1)[0]
-            new_atom = _normalize(np.asarray(X[:, idx], dtype=np.float64))
-            available_data.remove(idx)
-            mcoh = np.max(np.abs(np.dot(D.T, new_atom)))
-            if mcoh < min_coh:
-                min_coh = mcoh
-                min_idx = idx
-            cnt += 1
-        if min_idx is None:
-            continue
-        D[:, c_atom] = _normalize(np.asarray(X[:, min_idx], dtype=np.float64))
-        unused_data.remove(min_idx)
+            pick = np.random.choice(pool, size=1)[0]
+            pool.remove(pick)
+            now = np.abs(D.T @ column(pick)).max()
+            if now < best_coh:
+                best, best_coh = pick, now
+        if best is not None:
+            D[:, victim] = column(best)
+            unused_data.remove(best)
     return D, unused_data

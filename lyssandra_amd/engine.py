@@ -123,8 +123,10 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device, tag):
+    """Scratch buffer cached per (device, tag, HIP stream): two encoders running on different streams (or threads with
+    their own current stream) never share an alpha0 tile; work on ONE stream is ordered, so reuse there is safe."""
     torch = _torch()
-    key = (str(device), tag)
+    key = (str(device), tag, int(torch.cuda.current_stream(device).cuda_stream))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
@@ -226,8 +228,12 @@ def densify(idx, coef, nnz, K, out=None):
         if out is None:
             # host result, uninitialised, page-locked when possible (D2H at PCIe speed, ~55 GB/s, instead of the staged
             # pageable copy at ~8 GB/s; PyTorch's caching host allocator recycles the block once the array is dropped)
+            # (page-locked results stay in PyTorch's host cache for the life of the process: LYS_PINNED_RESULTS=0 returns
+            # ordinary pageable arrays instead, through the staged copy)
+            import os
+            pin = os.environ.get("LYS_PINNED_RESULTS", "1") != "0"
             try:
-                Zh = torch.empty((K, N), dtype=torch.float64, pin_memory=True)
+                Zh = torch.empty((K, N), dtype=torch.float64, pin_memory=pin)
             except RuntimeError:
                 Zh = torch.empty((K, N), dtype=torch.float64)
             Zh.copy_(Zd)

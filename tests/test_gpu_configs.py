@@ -155,3 +155,23 @@ def test_bomp_config3_per_gpu_shard_properties(eng):
     a, b = 5_000_003, 5_000_003 + 300_001
     i2, c2, z2 = eng.bomp_encode(Xs[a:b], dd, k)
     assert torch.equal(i2, idx[a:b]) and torch.equal(c2, coef[a:b]) and torch.equal(z2, nnz[a:b])
+
+
+def test_ksvd_coder_reference_defaults(eng):
+    """`ksvd_coder(n_atoms=.., sparse_coder=..)` with the reference's default max_iter=None (ksvd.py:236): under Python 2
+    `0 < None` is False, so `fit` returns the data-initialised dictionary untouched; the drop-in does the same instead of
+    raising a TypeError, and `encode` then works against it."""
+    from lyssandra_amd.dict_learning.ksvd import ksvd_coder
+    from lyssandra_amd.dict_learning.utils import init_dictionary
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    rs = np.random.RandomState(0)
+    X = rs.randn(16, 300)
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 3}, verbose=False)
+    np.random.seed(5)
+    coder = ksvd_coder(n_atoms=20, sparse_coder=se, verbose=False)
+    coder.fit(X)
+    np.random.seed(5)
+    D0 = init_dictionary(X, 20, method='data')
+    assert coder.D.shape == (16, 20) and np.allclose(coder.D, D0, atol=1e-6)
+    Z = coder.encode(X)
+    assert Z.shape == (20, 300) and ((Z != 0).sum(0) == 3).all()
