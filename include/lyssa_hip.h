@@ -100,6 +100,25 @@ int lys_bomp_from_alpha0(const float* alpha0, const float* G, int K, int k, int6
  * (unused slots -1/0, unordered), nnz[N]; steps[N] (optional) = steps taken, negative when more than kcap
  * coefficients were non-zero (only the first kcap are returned).  G = true Gram matrix (its diagonal is used).
  */
+/*
+ * Error-constrained 'omp': `_omp` with `tol` and no `n_nonzero_coefs`, lyssa/sparse_coding.py:27-31 -- atoms are
+ * selected while ||r|| >= tol (also checked before the first selection), stop on re-selection / singular pivot as in
+ * :40-50.  kcap (<= 64) = slots per signal in idx/coef; a signal that still has ||r|| >= tol after kcap atoms is
+ * returned with nnz = kcap.  ||r||^2 is tracked as ||x||^2 - sum t_j^2 in fp32: meaningful for tol >~ 1e-3 ||x||.
+ */
+size_t lys_omp_tol_workspace_bytes(int n, int K, int kcap, int64_t N);
+int lys_omp_encode_tol(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K, int kcap,
+                       float tol, int64_t N, int32_t* idx, float* coef, int32_t* nnz,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * Dataset-level preprocessing of a signal-major matrix, lyssa/feature_extract/preproc.py: per-feature sums / sums of
+ * squares over all signals in fp64 (`X.mean(axis=1)`, `X.std(axis=1)`, :55-62), the in-place per-feature affine map
+ * X[i][f] = (X[i][f] - shift[f]) * scale[f], and C = X' X (n x n, fp64, fp32 MFMA partial sums) for `zca_transform`
+ * (:18-31; the n x n eigen-decomposition stays on the host like the reference's scipy `eigh`).
+ */
+int lys_feature_stats(const float* X, int64_t ldx, int n, int64_t N, double* sum_dev, double* sumsq_dev, void* stream);
+int lys_feature_affine(float* X, int64_t ldx, int n, int64_t N, const float* shift, const float* scale, void* stream);
+int lys_covariance(const float* X, int64_t ldx, int n, int64_t N, double* C_dev, void* stream);
 size_t lys_lasso_workspace_bytes(int n, int K, int64_t N);
 int lys_lasso_encode(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K,
                      float lambda, int kcap, int max_steps, float tol, int64_t N,

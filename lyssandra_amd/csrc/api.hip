@@ -41,6 +41,11 @@ size_t bomp_generic_scratch_bytes(int Kp, int k);
 int bomp_from_alpha0(const float*, const float*, int, int, int64_t, int32_t*, float*, int32_t*, float*, hipStream_t,
                      int unit_diag = 1);
 int thresh_from_alpha0(const float*, int, int, int, int64_t, int32_t*, float*, int32_t*, hipStream_t);
+int omp_tol_from_alpha0(const float*, const float*, int, int, int64_t, const float*, int64_t, int, float, float*, int32_t*,
+                        float*, int32_t*, float*, hipStream_t);
+int feature_stats(const float*, int64_t, int, int64_t, double*, double*, hipStream_t);
+int feature_affine(float*, int64_t, int, int64_t, const float*, const float*, hipStream_t);
+int covariance(const float*, int64_t, int, int64_t, double*, hipStream_t);
 int bomp_debug_variant(const float*, const float*, int64_t, int, int32_t*, float*, int32_t*, int, int, hipStream_t);
 int residual(const float*, int64_t, const float*, int, int, int, int64_t, const int32_t*, const float*, const int32_t*,
              float*, int64_t, double*, hipStream_t);
@@ -346,6 +351,55 @@ int lys_omp_encode(const float* X, int64_t ldx, const float* D_packed, const flo
 int lys_thresh_encode(const float* X, int64_t ldx, const float* D_packed, int n, int K, int k, int64_t N, int32_t* idx,
                       float* coef, int32_t* nnz, void* workspace, size_t workspace_bytes, void* stream) {
     return encode_tiles(2, X, ldx, D_packed, nullptr, n, K, k, N, idx, coef, nnz, workspace, workspace_bytes, stream);
+}
+
+// ---- error-constrained 'omp' (sparse_coding.py:27-31 with tol and no n_nonzero_coefs): tiles of <= 65536 signals
+static int64_t omp_tol_tile(int64_t N) { return (N < 65536) ? ((N < 1) ? 1 : N) : 65536; }
+
+size_t lys_omp_tol_workspace_bytes(int n, int K, int kcap, int64_t N) {
+    (void)n;
+    const int Kp = padded_atoms(K);
+    return bomp_generic_scratch_bytes(Kp, kcap) + (size_t)omp_tol_tile(N) * ((size_t)Kp + 1) * sizeof(float);
+}
+
+int lys_omp_encode_tol(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K, int kcap,
+                       float tol, int64_t N, int32_t* idx, float* coef, int32_t* nnz, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    LYS_REQUIRE(X && D_packed && G && idx && coef && nnz && workspace, "omp_encode_tol: null pointer");
+    LYS_REQUIRE(n > 0 && K > 0 && N >= 0 && ldx >= n && kcap >= 1 && kcap <= 64 && tol >= 0.f,
+                "omp_encode_tol: bad arguments (kcap must be in [1, 64])");
+    LYS_REQUIRE(workspace_bytes >= lys_omp_tol_workspace_bytes(n, K, kcap, N), "omp_encode_tol: workspace too small");
+    if (N == 0) return LYS_OK;
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    const int64_t tile = omp_tol_tile(N);
+    float* gen = static_cast<float*>(workspace);
+    float* alpha0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + bomp_generic_scratch_bytes(Kp, kcap));
+    float* xn2 = alpha0 + (size_t)tile * Kp;
+    for (int64_t s0 = 0; s0 < N; s0 += tile) {
+        const int64_t cnt = (N - s0 < tile) ? N - s0 : tile;
+        int rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, alpha0, Kp, cnt, n, STREAM(stream));
+        if (rc) return rc;
+        rc = omp_tol_from_alpha0(alpha0, G, Kp, kcap, cnt, X + s0 * ldx, ldx, n, tol, xn2, idx + s0 * kcap,
+                                 coef + s0 * kcap, nnz + s0, gen, STREAM(stream));
+        if (rc) return rc;
+    }
+    return LYS_OK;
+}
+
+// ---- dataset-level preprocessing (feature_extract/preproc.py:18-31,55-62,77-78)
+int lys_feature_stats(const float* X, int64_t ldx, int n, int64_t N, double* sum_dev, double* sumsq_dev, void* stream) {
+    LYS_REQUIRE(X && sum_dev && sumsq_dev && n > 0 && N >= 0 && ldx >= n, "feature_stats: bad arguments");
+    return feature_stats(X, ldx, n, N, sum_dev, sumsq_dev, STREAM(stream));
+}
+
+int lys_feature_affine(float* X, int64_t ldx, int n, int64_t N, const float* shift, const float* scale, void* stream) {
+    LYS_REQUIRE(X && shift && scale && n > 0 && N >= 0 && ldx >= n, "feature_affine: bad arguments");
+    return feature_affine(X, ldx, n, N, shift, scale, STREAM(stream));
+}
+
+int lys_covariance(const float* X, int64_t ldx, int n, int64_t N, double* C_dev, void* stream) {
+    LYS_REQUIRE(X && C_dev && n > 0 && n <= 1024 && N >= 0 && ldx >= n, "covariance: bad arguments (n <= 1024)");
+    return covariance(X, ldx, n, N, C_dev, STREAM(stream));
 }
 
 size_t lys_lasso_workspace_bytes(int n, int K, int64_t N) {

@@ -447,16 +447,70 @@ __global__ __launch_bounds__(256) void thresh_wave_kernel(const float* __restric
     if (lane == 0) nnz_out[sig] = k;
 }
 
+// K > 1024: one workgroup of 256 threads per signal, thread t keeps the keys of atoms t, t+256, .. in registers (R =
+// Kp/256 <= 32, i.e. K <= 8192); k rounds of a workgroup-wide maximum over the packed (ordered key, ~atom) pair, so
+// that equal correlations resolve to the lowest atom index like `argsort()[::-1][:k]` never does deterministically
+// but the single-wave kernel above does.  (sparse_coding.py:416-425 has no limit on K.)
+template <int R>
+__global__ __launch_bounds__(256) void thresh_block_kernel(const float* __restrict__ alpha0, int Kp, int64_t N, int K,
+                                                            int k, int32_t* __restrict__ idx_out,
+                                                            float* __restrict__ coef_out, int32_t* __restrict__ nnz_out) {
+    __shared__ unsigned long long s_best[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t sig = blockIdx.x;
+    unsigned key[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int a = tid + 256 * r;
+        key[r] = (a < K) ? ordered_key(alpha0[sig * Kp + a]) : 0u;  // padded atoms never win
+    }
+    for (int j = 0; j < k; ++j) {
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned long long pk = ((unsigned long long)key[r] << 32) | (unsigned)(0x7fffffff - (tid + 256 * r));
+            best = (pk > best) ? pk : best;
+        }
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = (o > best) ? o : best;
+        }
+        if (lane == 0) s_best[wid] = best;
+        __syncthreads();
+        best = s_best[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) best = (s_best[w] > best) ? s_best[w] : best;
+        const int kk = 0x7fffffff - (int)(unsigned)(best & 0xffffffffull);
+        const unsigned m = (unsigned)(best >> 32);
+#pragma unroll
+        for (int r = 0; r < R; ++r) key[r] = (tid + 256 * r == kk) ? 0u : key[r];
+        if (tid == 0) {
+            idx_out[sig * k + j] = kk;
+            coef_out[sig * k + j] = key_to_float(m);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) nnz_out[sig] = k;
+}
+
 int thresh_from_alpha0(const float* alpha0, int K, int Kp, int k, int64_t N, int32_t* idx, float* coef, int32_t* nnz,
                        hipStream_t stream) {
     if (N <= 0) return LYS_OK;
-    if (Kp > 1024) {
-        set_error("thresh: K = %d > 1024 is not implemented", K);
-        return LYS_ENOSUP;
-    }
     if (k < 1 || k > K) {
         set_error("thresh: n_nonzero_coefs must be in [1, K], got %d", k);
         return LYS_EINVAL;
+    }
+    if (Kp > 1024) {
+        const dim3 g((unsigned)N), b(256);
+        if (Kp <= 2048) hipLaunchKernelGGL(thresh_block_kernel<8>, g, b, 0, stream, alpha0, Kp, N, K, k, idx, coef, nnz);
+        else if (Kp <= 4096) hipLaunchKernelGGL(thresh_block_kernel<16>, g, b, 0, stream, alpha0, Kp, N, K, k, idx, coef, nnz);
+        else if (Kp <= 8192) hipLaunchKernelGGL(thresh_block_kernel<32>, g, b, 0, stream, alpha0, Kp, N, K, k, idx, coef, nnz);
+        else {
+            set_error("thresh: K = %d > 8192 is not implemented", K);
+            return LYS_ENOSUP;
+        }
+        LYS_LAUNCH_CHECK();
+        return LYS_OK;
     }
     const dim3 grid((unsigned)((N + 3) / 4)), block(256);
     switch (Kp / 64) {
@@ -664,9 +718,15 @@ __global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restri
                                                             float* __restrict__ scratch,  // [grid][(k+1)*Kp]
                                                             int32_t* __restrict__ idx_out,
                                                             float* __restrict__ coef_out,
-                                                            int32_t* __restrict__ nnz_out, int unit_diag) {
+                                                            int32_t* __restrict__ nnz_out, int unit_diag,
+                                                            const float* __restrict__ xnorm2 = nullptr,
+                                                            float tol2 = 0.f) {
+    // xnorm2 != nullptr: error-constrained mode (`_omp` with tol and no n_nonzero_coefs, sparse_coding.py:27-31): select
+    // while ||r|| >= tol, with ||r||^2 = ||x||^2 - sum_j t_j^2 (t = the forward-substituted coefficients; exact for the
+    // least-squares fit on the support, fp32 cancellation limits it to tol >~ 1e-3 ||x||)
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
+    __shared__ float s_res2;
     __shared__ float s_w[64];
     __shared__ float s_L[64 * 64];
     __shared__ float s_t[64], s_rinv[64], s_z[64];
@@ -680,7 +740,10 @@ __global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restri
 
     for (int64_t sig = blockIdx.x; sig < N; sig += gridDim.x) {
         for (int x = tid; x < Kp; x += 256) a[x] = alpha0[sig * Kp + x];
-        if (tid == 0) s_stop = 0;
+        if (tid == 0) {
+            s_stop = 0;
+            s_res2 = xnorm2 ? xnorm2[sig] : 0.f;
+        }
         __syncthreads();
         int nsel = 0;
         for (int j = 0; j < k; ++j) {
@@ -711,6 +774,7 @@ __global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restri
                     }
                 }
                 bool stop = !(mm == mm) || kk == 0x7fffffff;
+                if (xnorm2 && !(s_res2 >= tol2)) stop = true;  // ||r|| < tol (also before the first selection)
                 if (j == 0) s_m0 = mm;
                 else if (mm < NOISE_REL * s_m0) stop = true;  // fp32 noise floor, see NOISE_REL
                 for (int i = 0; i < j && !stop; ++i) stop = (s_dx[i] == kk);
@@ -735,6 +799,7 @@ __global__ __launch_bounds__(256) void bomp_generic_kernel(const float* __restri
                     const float inv = 1.f / rho;
                     s_rinv[j] = inv;
                     s_t[j] = s_akk * inv;
+                    s_res2 = fmaf(-s_t[j], s_t[j], s_res2);
                     s_dx[j] = kk;
                     for (int i = 0; i < j; ++i) s_L[j * 64 + i] = s_w[i];
                 }
@@ -911,7 +976,37 @@ int bomp_from_alpha0(const float* alpha0, const float* G, int Kp, int k, int64_t
     }
     const int grid = (int)((N < (int64_t)num_cus() * 4) ? N : (int64_t)num_cus() * 4);
     hipLaunchKernelGGL(bomp_generic_kernel, dim3(grid), dim3(256), 0, stream, alpha0, G, Kp, N, k, generic_scratch,
-                       idx, coef, nnz, unit_diag);
+                       idx, coef, nnz, unit_diag, (const float*)nullptr, 0.f);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// ||x||^2 of every signal-major row (one wave per row)
+__global__ __launch_bounds__(256) void row_norm2_kernel(const float* __restrict__ X, int64_t ldx, int n, int64_t N,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= N) return;
+    float ss = 0.f;
+    for (int f = lane; f < n; f += 64) ss = fmaf(X[s * ldx + f], X[s * ldx + f], ss);
+    ss = wave_sum_f(ss);
+    if (lane == 0) out[s] = ss;
+}
+
+// error-constrained 'omp' on one alpha0 tile: generic kernel, true Gram diagonal, stop when ||r|| < tol
+int omp_tol_from_alpha0(const float* alpha0, const float* G, int Kp, int kcap, int64_t N, const float* X, int64_t ldx,
+                        int n, float tol, float* xnorm2, int32_t* idx, float* coef, int32_t* nnz, float* generic_scratch,
+                        hipStream_t stream) {
+    if (N <= 0) return LYS_OK;
+    if (kcap < 1 || kcap > 64) {
+        set_error("omp(tol): at most 64 atoms per signal, got kcap = %d", kcap);
+        return LYS_ENOSUP;
+    }
+    hipLaunchKernelGGL(row_norm2_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, X, ldx, n, N, xnorm2);
+    LYS_LAUNCH_CHECK();
+    const int grid = (int)((N < (int64_t)num_cus() * 4) ? N : (int64_t)num_cus() * 4);
+    hipLaunchKernelGGL(bomp_generic_kernel, dim3(grid), dim3(256), 0, stream, alpha0, G, Kp, N, kcap, generic_scratch,
+                       idx, coef, nnz, 0, (const float*)xnorm2, tol * tol);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }

@@ -131,6 +131,125 @@ int preproc_signals(float* X, int64_t ldx, int n, int64_t N, float scale, int ce
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dataset-level preprocessing (lyssa/feature_extract/preproc.py:18-31,55-62,77-78): per-FEATURE mean / std over all
+// signals ('global_centering', 'global_standarization') and ZCA 'whitening'.  All HBM-rate streaming passes over the
+// signal-major matrix; the n x n eigen-decomposition of ZCA stays on the host (scipy eigh, like the reference).
+// ---------------------------------------------------------------------------------------------
+// sum and sum of squares of every feature, fp64 (one wave walks rows, lane = feature % 64; per-workgroup LDS reduce)
+__global__ __launch_bounds__(256) void feature_stats_kernel(const float* __restrict__ X, int64_t ldx, int n, int64_t N,
+                                                            double* __restrict__ sum, double* __restrict__ sumsq) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int f0 = 0; f0 < n; f0 += 64) {
+        const int f = f0 + lane;
+        double s = 0.0, q = 0.0;
+        if (f < n) {
+            for (int64_t i = (int64_t)blockIdx.x * 4 + wid; i < N; i += (int64_t)gridDim.x * 4) {
+                const double v = (double)X[i * ldx + f];
+                s += v;
+                q = fma(v, v, q);
+            }
+            atomicAdd(sum + f, s);
+            atomicAdd(sumsq + f, q);
+        }
+    }
+}
+
+// X[i][f] = (X[i][f] - shift[f]) * scale[f]
+__global__ __launch_bounds__(256) void feature_affine_kernel(float* __restrict__ X, int64_t ldx, int n, int64_t N,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ scale) {
+    const int64_t tot = N * (int64_t)n;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < tot; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / n;
+        const int f = (int)(t - i * n);
+        X[i * ldx + f] = (X[i * ldx + f] - shift[f]) * scale[f];
+    }
+}
+
+// C += X' X restricted to the 64 x 64 block (bi, bj) of features, over this workgroup's slab of signals: the slab is
+// staged 64 rows at a time in LDS, the four waves own the four 32 x 32 MFMA tiles of the block
+// (v_mfma_f32_32x32x2_f32: A[f][i] and B[i][g] both read from the same staged rows), fp64 atomics at the end.
+__global__ __launch_bounds__(256) void covariance_kernel(const float* __restrict__ X, int64_t ldx, int n, int64_t N,
+                                                         int64_t rows_per_wg, double* __restrict__ C) {
+    __shared__ float s_a[64][65], s_b[64][65];
+    const int nb = (n + 63) / 64;
+    int bi = 0, bj = blockIdx.y;  // blockIdx.y enumerates the upper-triangular blocks bi <= bj
+    while (bj >= nb - bi) {
+        bj -= nb - bi;
+        ++bi;
+    }
+    bj += bi;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ti = wid >> 1, tj = wid & 1;  // this wave's 32 x 32 tile inside the block
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < N) ? r0 + rows_per_wg : N;
+    using f16v = __attribute__((ext_vector_type(16))) float;
+    f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t c0 = r0; c0 < r1; c0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int i = e >> 6, f = e & 63;
+            const int64_t row = c0 + i;
+            const int fa = bi * 64 + f, fb = bj * 64 + f;
+            s_a[i][f] = (row < r1 && fa < n) ? X[row * ldx + fa] : 0.f;
+            s_b[i][f] = (row < r1 && fb < n) ? X[row * ldx + fb] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int i = 0; i < 64; i += 2) {
+            const int kk = i + (lane >> 5);
+            const float av = s_a[kk][32 * ti + (lane & 31)];
+            const float bv = s_b[kk][32 * tj + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3), col = lane & 31;
+        const int f = bi * 64 + 32 * ti + row, g = bj * 64 + 32 * tj + col;
+        if (f < n && g < n) {
+            atomicAdd(C + (int64_t)f * n + g, (double)acc[r]);
+            if (bi != bj) atomicAdd(C + (int64_t)g * n + f, (double)acc[r]);
+        }
+    }
+}
+
+int feature_stats(const float* X, int64_t ldx, int n, int64_t N, double* sum, double* sumsq, hipStream_t stream) {
+    LYS_CHECK_HIP(hipMemsetAsync(sum, 0, (size_t)n * sizeof(double), stream));
+    LYS_CHECK_HIP(hipMemsetAsync(sumsq, 0, (size_t)n * sizeof(double), stream));
+    if (N <= 0) return LYS_OK;
+    int64_t blocks = (N + 3) / 4;
+    const int64_t cap = (int64_t)num_cus() * 4;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(feature_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, ldx, n, N, sum, sumsq);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+int feature_affine(float* X, int64_t ldx, int n, int64_t N, const float* shift, const float* scale, hipStream_t stream) {
+    if (N <= 0) return LYS_OK;
+    int64_t blocks = (N * n + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(feature_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, ldx, n, N, shift, scale);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+int covariance(const float* X, int64_t ldx, int n, int64_t N, double* C, hipStream_t stream) {
+    LYS_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)n * n * sizeof(double), stream));
+    if (N <= 0) return LYS_OK;
+    const int nb = (n + 63) / 64;
+    int64_t wgs = (int64_t)num_cus() * 2;
+    int64_t rows = (N + wgs - 1) / wgs;
+    rows = ((rows + 63) / 64) * 64;
+    wgs = (N + rows - 1) / rows;
+    hipLaunchKernelGGL(covariance_kernel, dim3((unsigned)wgs, nb * (nb + 1) / 2), dim3(256), 0, stream, X, ldx, n, N, rows, C);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Consumer right after the encode: ScSPM spatial-pyramid max pooling of |z|
 // (lyssa/feature_extract/spatial_pyramid.py:57-97 with pooling.py:4-7) straight from the sparse triplet:
 // out[cell][atom] = max over the patches of the cell of |coef|.  |x| >= 0, so the float max is an unsigned max on

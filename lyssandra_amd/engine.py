@@ -176,6 +176,33 @@ def bomp_encode(Xs, dd, k, out=None, algorithm='bomp'):
     return idx, coef, nnz
 
 
+def omp_tol_encode(Xs, dd, tol, kcap=None, out=None):
+    """Error-constrained OMP (`_omp` with ``tol`` and no ``n_nonzero_coefs``, sparse_coding.py:27-31): atoms are added
+    while ||r|| >= tol.  ``kcap`` (<= 64, default min(n, K, 64)) slots per signal; a signal that runs out of slots comes
+    back with nnz == kcap.  Returns (idx, coef, nnz)."""
+    torch = _torch()
+    lib = _lib.load()
+    N = int(Xs.shape[0])
+    kcap = int(kcap) if kcap is not None else min(dd.n, dd.K, 64)
+    if not 1 <= kcap <= 64:
+        raise ValueError("kcap must be in [1, 64]")
+    assert Xs.dtype == torch.float32
+    if N > 0 and Xs.shape[1] > 1 and Xs.stride(1) != 1:
+        Xs = Xs.contiguous()
+    if out is None:
+        idx = torch.empty((N, kcap), dtype=torch.int32, device=dd.device)
+        coef = torch.empty((N, kcap), dtype=torch.float32, device=dd.device)
+        nnz = torch.empty((N,), dtype=torch.int32, device=dd.device)
+    else:
+        idx, coef, nnz = out
+    if N > 0:
+        ws = _workspace(lib.lys_omp_tol_workspace_bytes(dd.n, dd.K, kcap, N), dd.device, "bomp")
+        _lib.check(lib.lys_omp_encode_tol(_ptr(Xs), _ld(Xs), _ptr(dd.D), _ptr(dd.gram()), dd.n, dd.K, kcap, float(tol), N,
+                                          _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(ws), ws.numel(), _stream()),
+                   "lys_omp_encode_tol")
+    return idx, coef, nnz
+
+
 def lasso_encode(Xs, dd, lam, kcap=None, max_steps=None, tol=1e-6, out=None, return_steps=False):
     """min_a 0.5||x - D a||^2 + lam ||a||_1 for every row of ``Xs`` (sparse_coding.py:487-509, spams.lasso mode 2).
 

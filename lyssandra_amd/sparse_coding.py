@@ -93,6 +93,16 @@ class sparse_encoder(object):
                     warnings.warn("lasso: %d of %d signals used the whole step budget (%d) without reaching tol; "
                                   "raise params['max_steps'] or lambda" % (n_bad, steps.numel(), budget))
             return idx, coef, nnz
+        if self.algorithm == 'omp' and self.params.get('n_nonzero_coefs') is None and self.params.get('tol') is not None:
+            # error-constrained OMP (sparse_coding.py:27-31): atoms until ||r|| < tol; at most params['kcap'] (<= 64) of them
+            kcap = self.params.get('kcap')
+            idx, coef, nnz = engine.omp_tol_encode(Xs, dd, self.params.get('tol'), kcap=kcap, out=out)
+            cap = int(idx.shape[1])
+            if cap < min(dd.n, dd.K) and nnz.numel() and int(nnz.max().item()) >= cap:
+                import warnings
+                warnings.warn("omp(tol): some signals used all %d coefficient slots; the reference would keep adding "
+                              "atoms (params['kcap'] <= 64 sets the limit)" % cap)
+            return idx, coef, nnz
         return engine.bomp_encode(Xs, dd, self._k(dd.K), out=out, algorithm=self.algorithm)
 
     # -- helpers ---------------------------------------------------------------------------------------
@@ -102,8 +112,6 @@ class sparse_encoder(object):
             # thresholding(): nonzero_percentage overrides n_nonzero_coefs (sparse_coding.py:419-420)
             k = int(np.floor(self.params.get('nonzero_percentage') * n_atoms))
         if k is None:
-            if self.algorithm == 'omp' and self.params.get('tol') is not None:
-                raise NotImplementedError("error-constrained 'omp' (tol without n_nonzero_coefs) is not accelerated")
             # the reference dies with a TypeError in np.zeros((None, None)) (sparse_coding.py:317)
             raise ValueError("params['n_nonzero_coefs'] is required for algorithm=%r" % (self.algorithm,))
         return int(k)
@@ -118,13 +126,25 @@ class sparse_encoder(object):
         raise ValueError("Sparse optimizer not found.")  # sparse_coding.py:705-706
 
     def _dictionary(self, D):
+        """Packed device copy of D + its Gram matrix, re-used while the CONTENT of D is unchanged (a 64-bit hash of the
+        host array; a learner that edits D in place between calls therefore still gets a fresh upload)."""
         D = np.asarray(D) if not _is_tensor(D) else D
         n, K = int(D.shape[0]), int(D.shape[1])
         dd = self._dd
         if dd is None or dd.n != n or dd.K != K:
             dd = engine.DeviceDictionary(n, K, self.device)
             self._dd = dd
-        dd.set(D)
+            self._dd_tag = None
+        tag = None
+        if not _is_tensor(D):
+            try:
+                import xxhash
+                tag = (D.dtype.str, xxhash.xxh3_64_intdigest(np.ascontiguousarray(D)))
+            except Exception:  # pragma: no cover
+                tag = None
+        if tag is None or tag != getattr(self, "_dd_tag", None):
+            dd.set(D)
+            self._dd_tag = tag
         return dd
 
 

@@ -183,12 +183,13 @@ def densify(idx, coef, nnz, K):
 
 
 # --------------------------------------------------------------------------- 'omp' and 'thresh' 
-def omp_signal(x, D, Gram, alpha, n_nonzero_coefs, want_gap=False):
+def omp_signal(x, D, Gram, alpha, n_nonzero_coefs, want_gap=False, tol=None):
     """lyssa/sparse_coding.py:19-57 (`_omp`, fixed sparsity): residual-domain OMP.  argmax|alpha| :39, stop on
     re-selection :40-41, z[Dx] = inv(G[Dx,Dx]) (D'x)[Dx] :44-52 (TRUE Gram diagonal, unlike batch_omp),
     r = x - D[:,Dx] z :53, alpha = D'r :54; loop while i < k and ||r|| > 1e-10 :27-31.
     ``want_gap`` also returns the minimum relative top-1/top-2 gap of |alpha| along the greedy path (tie classifier of
-    the parity tests, same definition as batch_omp_signal)."""
+    the parity tests, same definition as batch_omp_signal).  ``n_nonzero_coefs=None`` with ``tol``: the error-constrained
+    form, loop while ||r|| >= tol :30-31."""
     K = D.shape[1]
     Dx = []
     z = np.zeros(K)
@@ -196,7 +197,12 @@ def omp_signal(x, D, Gram, alpha, n_nonzero_coefs, want_gap=False):
     i = 0
     a0 = np.dot(D.T, x)
     min_gap = np.inf
-    while i < n_nonzero_coefs and norm(r) > 1e-10:
+    def cont():
+        if n_nonzero_coefs is not None:
+            return i < n_nonzero_coefs and norm(r) > 1e-10
+        return norm(r) >= tol
+
+    while cont():
         kk = int(np.argmax(np.abs(alpha)))
         if kk in Dx:
             break
@@ -218,17 +224,18 @@ def omp_signal(x, D, Gram, alpha, n_nonzero_coefs, want_gap=False):
     return z
 
 
-def omp_encode(X, D, k, want_gap=False):
-    """sparse_encoder 'omp' branch: lyssa/sparse_coding.py:620-627 + `omp` :60-66.  ``want_gap`` -> (Z, gap [N])."""
+def omp_encode(X, D, k, want_gap=False, tol=None):
+    """sparse_encoder 'omp' branch: lyssa/sparse_coding.py:620-627 + `omp` :60-66.  ``want_gap`` -> (Z, gap [N]);
+    ``k=None`` with ``tol``: error-constrained."""
     Gram = fast_dot(D.T, D)
     Alpha = fast_dot(D.T, X)
     Z = np.zeros((D.shape[1], X.shape[1]))
     gap = np.zeros(X.shape[1])
     for i in range(X.shape[1]):
         if want_gap:
-            Z[:, i], gap[i] = omp_signal(X[:, i], D, Gram, Alpha[:, i], k, want_gap=True)
+            Z[:, i], gap[i] = omp_signal(X[:, i], D, Gram, Alpha[:, i], k, want_gap=True, tol=tol)
         else:
-            Z[:, i] = omp_signal(X[:, i], D, Gram, Alpha[:, i], k)
+            Z[:, i] = omp_signal(X[:, i], D, Gram, Alpha[:, i], k, tol=tol)
     return (Z, gap) if want_gap else Z
 
 
@@ -578,7 +585,7 @@ def grid_patches(img, patch_size, step_size):
 
 
 def preproc(name, X):
-    """lyssa/feature_extract/preproc.py:46-80, the per-datapoint operations."""
+    """lyssa/feature_extract/preproc.py:46-80 (per-datapoint and dataset-level operations)."""
     X = np.array(X, dtype=np.float64)
     if name == 'scaling':
         return X / 255.
@@ -588,6 +595,15 @@ def preproc(name, X):
         return norm_cols(X - X.mean(axis=0)[np.newaxis, :])
     if name == 'normalization':
         return norm_cols(X)
+    if name == 'global_centering':           # :55-57, per FEATURE over all datapoints
+        return X - X.mean(axis=1)[:, np.newaxis]
+    if name == 'global_standarization':      # :58-62
+        X = X - X.mean(axis=1)[:, np.newaxis]
+        return X / X.std(axis=1)[:, np.newaxis]
+    if name == 'whitening':                  # :77-78 -> zca_transform(X.T).T, :18-31 (bias = 0.1)
+        Xr = X.T - X.T.mean(axis=0)
+        eigs, eigv = np.linalg.eigh(np.dot(Xr.T, Xr) / Xr.shape[0] + 0.1 * np.identity(Xr.shape[1]))
+        return np.dot(Xr, np.dot(eigv * np.sqrt(1.0 / eigs), eigv.T)).T
     raise ValueError(name)
 
 

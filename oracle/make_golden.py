@@ -18,6 +18,9 @@ Fixtures:
       call, final D, A, B
   F11 force_mi (mutual-incoherence step of ksvd_dict_learn, eta=0.9) on a dictionary with three coherent atom pairs
   F10 exact K-SVD (`ksvd`, randomized_svd seeded): F5's data (first 1200 signals), D / codes / error after 2 iterations
+  F12 (round 2; `python oracle/make_golden.py F12` regenerates it alone) dataset-level preproc ('global_centering',
+      'global_standarization', 'whitening' = zca_transform), error-constrained 'omp' (tol, no n_nonzero_coefs) and
+      'thresh' with 2048 atoms
 """
 import contextlib
 import io
@@ -63,6 +66,38 @@ def dense_to_triplet(Z, k):
         coef[i, :len(nz)] = Z[nz, i]
         nnz[i] = len(nz)
     return idx, coef, nnz
+
+
+def make_f12():
+    """Round-2 widenings, from the reference itself."""
+    load_reference()
+    from lyssa.sparse_coding import sparse_encoder
+    from lyssa.feature_extract.preproc import preproc as ref_preproc
+    os.makedirs(OUT, exist_ok=True)
+    rs = np.random.RandomState(1212)
+    out = {}
+    # patches-like data: 36 features, 700 datapoints, non-negative with unequal feature scales
+    Xp = f32(np.abs(rs.randn(36, 700)) * np.linspace(0.5, 3.0, 36)[:, None] + rs.rand(36, 1))
+    out["pre_X"] = Xp.astype(np.float32)
+    for name in ("global_centering", "global_standarization", "whitening"):
+        out["pre_" + name] = quiet(ref_preproc(name), Xp.copy())
+    # error-constrained OMP: unit-norm and non-unit-norm dictionaries
+    D = make_dict(rs, 24, 60)
+    Dn = f32(D * rs.uniform(0.7, 1.4, size=60)[None, :])
+    X = f32(rs.randn(24, 90))
+    out["omp_X"], out["omp_D"], out["omp_Dn"] = X.astype(np.float32), D.astype(np.float32), Dn.astype(np.float32)
+    for tag, DD in (("unit", D), ("nonunit", Dn)):
+        for tol in (2.0, 3.5):
+            se = sparse_encoder(algorithm='omp', params={'tol': tol}, n_jobs=1, verbose=False)
+            out["omp_%s_tol%g_Z" % (tag, tol)] = quiet(se.encode, X, DD)
+    # thresh beyond 1024 atoms
+    Dt = make_dict(rs, 32, 2048)
+    Xt = f32(rs.randn(32, 64))
+    out["th_X"], out["th_D"] = Xt.astype(np.float32), Dt.astype(np.float32)
+    se = sparse_encoder(algorithm='thresh', params={'n_nonzero_coefs': 9}, n_jobs=1, verbose=False)
+    out["th_k9_Z"] = quiet(se.encode, Xt, Dt)
+    np.savez_compressed(os.path.join(OUT, "F12.npz"), **out)
+    print("F12: omp(tol) nnz", [(k, int((v != 0).sum(0).max())) for k, v in out.items() if k.startswith("omp_") and k.endswith("_Z")])
 
 
 def main():
@@ -353,4 +388,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["F12"]:
+        make_f12()
+    else:
+        main()
+        make_f12()

@@ -315,3 +315,23 @@ def test_c_oracle_approx_ksvd_matches_reference_and_numpy_oracle():
     assert np.max(np.abs(Dc - Do)) <= 1e-12
     assert np.max(np.abs(orc.densify(idx, cc, nnz, K) - Zo)) <= 1e-11
     assert abs(err - orc.approx_error(Do, Zo, Xm)) <= 1e-9 * err
+
+
+def test_round2_widenings_match_reference():
+    """F12 (generated by the reference itself): dataset-level preproc (feature_extract/preproc.py:18-31,55-62,77-78),
+    error-constrained 'omp' (sparse_coding.py:27-31) and 'thresh' with 2048 atoms (:416-425) against the oracle."""
+    g = load_golden("F12")
+    Xp = g["pre_X"].astype(np.float64)
+    for name in ("global_centering", "global_standarization", "whitening"):
+        ref = g["pre_" + name]
+        assert np.max(np.abs(orc.preproc(name, Xp) - ref)) <= 1e-10 * max(1.0, np.abs(ref).max()), name
+    X = g["omp_X"].astype(np.float64)
+    for tag, D in (("unit", g["omp_D"].astype(np.float64)), ("nonunit", g["omp_Dn"].astype(np.float64))):
+        for tol in (2.0, 3.5):
+            Z = orc.omp_encode(X, D, None, tol=tol)
+            Zr = g["omp_%s_tol%g_Z" % (tag, tol)]
+            assert np.array_equal(Z != 0, Zr != 0) and np.max(np.abs(Z - Zr)) <= 1e-10
+            r = np.linalg.norm(X - D @ Z, axis=0)
+            assert (r < tol).all()                                   # every signal stopped because ||r|| < tol
+    Zt = orc.thresh_encode(g["th_X"].astype(np.float64), g["th_D"].astype(np.float64), n_nonzero_coefs=9)
+    assert np.array_equal(Zt != 0, g["th_k9_Z"] != 0) and np.max(np.abs(Zt - g["th_k9_Z"])) <= 1e-12
