@@ -704,7 +704,17 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     // walk of one block's entry range with a role; the batch count is uniform per workgroup (every team has the same
     // chunk size, teams past the end of the list idle) because the queued entries of a batch are drained by ALL teams
     // between two workgroup barriers
-    auto walk = [&](int role, int blk_id, int w) {
+    auto drain = [&]() {  // all teams take queued slow-path entries between two workgroup barriers
+        __syncthreads();
+        const int nq = s_qn;
+        for (int i = team; i < nq; i += TEAMS)  // uniform per team
+            run_slow((unsigned)s_q[i][0], s_q[i][1], __builtin_bit_cast(float, s_q[i][2]), s_q[i][3] != 0);
+        __syncthreads();
+        if (tid == 0) s_qn = 0;
+    };
+    // `defer`: leave the queued entries for a later drain (Y(c) drains the entries of both its walks in ONE round: a
+    // drain is a dependent load round trip) unless the queue could overflow in the next batch
+    auto walk = [&](int role, int blk_id, int w, bool defer) {
         which = w;
         const int lbeg = s_rp[w][0];
         const int a_hi = (blk_id * B + B < K) ? B : K - blk_id * B;
@@ -728,19 +738,21 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                     if (left > j0) run_fast(role, ent, emt, ecf, j0, e0 + j0);
             }
             if (bo == 0 && role != ROLE_COLLECT) BK_WSTAMP(6);
-            __syncthreads();
-            if (bo == 0 && role != ROLE_COLLECT) BK_WSTAMP(7);
-            const int nq = s_qn;
-            for (int i = team; i < nq; i += TEAMS)  // uniform per team
-                run_slow((unsigned)s_q[i][0], s_q[i][1], __builtin_bit_cast(float, s_q[i][2]), s_q[i][3] != 0);
-            if (bo == 0 && role == ROLE_ACC) BK_WSTAMP(2);
-            __syncthreads();
-            if (tid == 0) s_qn = 0;
+            if (role == ROLE_ACC) continue;  // X(c) queues nothing
+            const bool last = bo + 16 >= chunk;
+            if (!(defer && last)) {
+                drain();
+            } else {
+                __syncthreads();
+                const bool full = s_qn > NTH - 16 * TEAMS;  // uniform: read after the barrier
+                __syncthreads();
+                if (full) drain();
+            }
         }
     };
 
     if (mode == 0) {
-        walk(ROLE_ACC, c, 1);
+        walk(ROLE_ACC, c, 1, false);
         BK_WSTAMP(3);
         // ---- group phase: tuple moments of the coupled signals of block c (their leaders, sorted by in-block mask).
         // Workgroup w takes the entries [w * GCH, (w + 1) * GCH) of the block's range, 2 per team (loaded together).
@@ -847,9 +859,10 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
         }
         BK_WSTAMP(2);
     } else {
-        if (have_c) walk(ROLE_COLLECT, c, 1);
+        if (have_c) walk(ROLE_COLLECT, c, 1, true);
         BK_WSTAMP(2);
-        if (have_p) walk(ROLE_APPLY, p, 0);
+        if (have_p) walk(ROLE_APPLY, p, 0, true);
+        drain();
         BK_WSTAMP(3);
     }
     if (have_c) {  // uniform per launch
