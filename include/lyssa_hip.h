@@ -101,6 +101,18 @@ int lys_bomp_from_alpha0(const float* alpha0, const float* G, int K, int k, int6
  * coefficients were non-zero (only the first kcap are returned).  G = true Gram matrix (its diagonal is used).
  */
 /*
+ * The same l1 problem through a LARS-lasso homotopy (the algorithm family of spams.lasso(mode=2),
+ * lyssa/sparse_coding.py:487-509): about one breakpoint per non-zero, |A| Gram rows per breakpoint, then the
+ * coordinate-descent kernel of lys_lasso_encode warm-started from the path's end point as a polish (it owns the
+ * stopping rule `tol`).  breakpoints[N] (optional) = breakpoints taken, steps[N] = polish steps (negative: support
+ * truncated to kcap).  At most 128 active atoms on the path (a dependent atom or a full active set ends the path early,
+ * the polish takes over).  Workspace: lys_lasso_workspace_bytes.
+ */
+int lys_lasso_lars_encode(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K,
+                          float lambda, int kcap, int max_breakpoints, int max_steps, float tol, int64_t N,
+                          int32_t* idx, float* coef, int32_t* nnz, int32_t* steps, int32_t* breakpoints,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/*
  * Error-constrained 'omp': `_omp` with `tol` and no `n_nonzero_coefs`, lyssa/sparse_coding.py:27-31 -- atoms are
  * selected while ||r|| >= tol (also checked before the first selection), stop on re-selection / singular pivot as in
  * :40-50.  kcap (<= 64) = slots per signal in idx/coef; a signal that still has ||r|| >= tol after kcap atoms is

@@ -30,6 +30,7 @@ SIGNATURES = {
     "lys_bomp_encode": (_I, [_P, _L, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P, _Z, _P]),
     "lys_omp_encode": (_I, [_P, _L, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P, _Z, _P]),
     "lys_thresh_encode": (_I, [_P, _L, _P, _I, _I, _I, _L, _P, _P, _P, _P, _Z, _P]),
+    "lys_lasso_lars_encode": (_I, [_P, _L, _P, _P, _I, _I, _F, _I, _I, _I, _F, _L, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lys_omp_tol_workspace_bytes": (_Z, [_I, _I, _I, _L]),
     "lys_omp_encode_tol": (_I, [_P, _L, _P, _P, _I, _I, _I, _F, _L, _P, _P, _P, _P, _Z, _P]),
     "lys_feature_stats": (_I, [_P, _L, _I, _L, _P, _P, _P]),

@@ -63,7 +63,9 @@ int ksvd_exact_sweep(float*, int64_t, int, int, int, const int32_t*, const int32
                      int64_t, hipStream_t);
 size_t ksvd_exact_work_doubles(int);
 int lasso_from_alpha0(const float*, const float*, int, int, float, float, int, int, int64_t, int32_t*, float*, int32_t*,
-                      int32_t*, hipStream_t);
+                      int32_t*, hipStream_t, int warm = 0);
+int lasso_lars_from_alpha0(const float*, const float*, int, int, float, int, int, int64_t, int32_t*, float*, int32_t*,
+                           int32_t*, hipStream_t);
 int ksvd_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
                hipStream_t);
 int ksvd_sweep_fused(float*, int64_t, int, int, int, const int32_t*, const int32_t*, const int32_t*, float*, double*,
@@ -408,6 +410,37 @@ size_t lys_lasso_workspace_bytes(int n, int K, int64_t N) {
     const int64_t t = tile_signals(Kp);
     const int64_t rows = (N <= t) ? ((N < 1) ? 1 : N) : t;
     return (size_t)rows * (size_t)Kp * sizeof(float);
+}
+
+// LARS homotopy followed by the coordinate-descent polish (warm start): same problem, same outputs as lys_lasso_encode
+int lys_lasso_lars_encode(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K, float lambda,
+                          int kcap, int max_breakpoints, int max_steps, float tol, int64_t N, int32_t* idx, float* coef,
+                          int32_t* nnz, int32_t* steps, int32_t* breakpoints, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    LYS_REQUIRE(X && D_packed && G && idx && coef && nnz && workspace, "lasso_lars_encode: null pointer");
+    LYS_REQUIRE(n > 0 && K > 0 && N >= 0 && ldx >= n && kcap >= 1 && max_steps >= 0 && max_breakpoints >= 0 &&
+                    lambda >= 0.f && tol >= 0.f, "lasso_lars_encode: bad arguments n=%d K=%d kcap=%d lambda=%g", n, K,
+                kcap, (double)lambda);
+    if (N == 0) return LYS_OK;
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    int64_t rows = (int64_t)(workspace_bytes / ((size_t)Kp * sizeof(float)));
+    LYS_REQUIRE(rows >= 1, "lasso_lars_encode: workspace too small (%zu bytes)", workspace_bytes);
+    const int64_t pref = tile_signals(Kp);
+    if (rows > pref) rows = pref;
+    float* a0 = static_cast<float*>(workspace);
+    hipStream_t st = STREAM(stream);
+    for (int64_t s0 = 0; s0 < N; s0 += rows) {
+        const int64_t cnt = (N - s0 < rows) ? N - s0 : rows;
+        int rc;
+        if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, st))) return rc;
+        if ((rc = lasso_lars_from_alpha0(a0, G, Kp, K, lambda, max_breakpoints, kcap, cnt, idx + s0 * kcap,
+                                         coef + s0 * kcap, nnz + s0, breakpoints ? breakpoints + s0 : nullptr, st)))
+            return rc;
+        if ((rc = lasso_from_alpha0(a0, G, Kp, K, lambda, tol, max_steps, kcap, cnt, idx + s0 * kcap, coef + s0 * kcap,
+                                    nnz + s0, steps ? steps + s0 : nullptr, st, 1)))
+            return rc;
+    }
+    return LYS_OK;
 }
 
 int lys_lasso_encode(const float* X, int64_t ldx, const float* D_packed, const float* G, int n, int K, float lambda,

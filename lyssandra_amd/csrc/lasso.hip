@@ -67,7 +67,9 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_cd_kernel(const fl
                                                                          int kcap, int64_t N, int32_t* __restrict__ idx,
                                                                          float* __restrict__ coef,
                                                                          int32_t* __restrict__ nnz,
-                                                                         int32_t* __restrict__ steps_out) {
+                                                                         int32_t* __restrict__ steps_out, int warm) {
+    // warm != 0: (idx, coef, nnz) hold a starting point (the LARS kernel's solution): a and the correlations are
+    // rebuilt from it exactly like in the refresh phase below, then coordinate descent polishes it to the stopping rule
     using L = LLay<R>;
     __shared__ float s_score[LASSO_MAX_WAVES], s_delta[LASSO_MAX_WAVES];
     __shared__ int s_e[LASSO_MAX_WAVES], s_cnt[LASSO_MAX_WAVES];
@@ -94,6 +96,22 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_cd_kernel(const fl
     }
     const float tol_abs = tol_rel * amax;
     int steps = 0, total = 0;
+    if (warm) {
+        const int m = nnz[sig] < kcap ? nnz[sig] : kcap;
+        for (int e = 0; e < m; ++e) {
+            const int j = idx[sig * kcap + e];
+            const float aj = coef[sig * kcap + e];
+            if (j < 0 || j >= K || aj == 0.f) continue;  // uniform
+            float g[R];
+            load_vec<R>(G + (int64_t)j * Kp, t, T, g);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (L::elem(r, t, T) == j) a[r] = aj;
+                c[r] = fmaf(-aj, g[r], c[r]);
+            }
+        }
+        __syncthreads();  // the list is overwritten by the first compaction
+    }
     // Rounds of [coordinate descent to the stopping rule] + [compaction of the non-zeros] + [refresh of c from scratch].
     // c -= delta * G[j,:] accumulates fp32 rounding over hundreds of steps; recomputing c = D'x - G a from the compacted
     // code (one Gram row per non-zero) and resuming removes that drift.  The kernel returns when a round that started
@@ -201,9 +219,282 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_cd_kernel(const fl
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LARS-lasso homotopy (the algorithm family of spams.lasso(mode=2), lyssa/sparse_coding.py:487-509), on the Gram
+// matrix, one workgroup per signal in the register layout of the kernel above.  With c = D'x - G a and the active set
+// A (signs s), the solution path is piecewise linear in the common correlation level C = |c_A|:
+//     d_A = G_AA^-1 s_A,   u = G[:,A] d_A  (u_A = s_A),   a_A += gamma d_A,   c -= gamma u,   C -= gamma
+// with gamma the smallest of: C - lambda (done), an inactive atom reaching the level (joins), an active coefficient
+// reaching zero (leaves).  Coordinate descent needs hundreds of Gram rows when the support approaches n; the path has
+// about one breakpoint per non-zero and reads |A| rows per breakpoint.  The Cholesky factor of G_AA (<= LARS_MAX
+// atoms) lives in LDS, the two triangular solves per breakpoint run on wave 0.  fp32 drift along the path is
+// removed afterwards by the coordinate-descent kernel, warm-started from this solution: it owns the stopping rule.
+// ---------------------------------------------------------------------------------------------
+constexpr int LARS_MAX = 128;  // active atoms (a lasso minimiser has at most min(n, K) non-zeros)
+
+struct LBest {
+    float g;  // step length
+    int e;    // atom (join) or active position (leave)
+    int kind; // 0 none, 1 join with sign +, 2 join with sign -, 3 leave
+};
+__device__ __forceinline__ LBest lmin(const LBest& a, const LBest& b) {
+    return (b.g < a.g || (b.g == a.g && b.e < a.e)) ? b : a;
+}
+__device__ __forceinline__ LBest wave_lmin(LBest x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        LBest o;
+        o.g = __shfl_xor(x.g, off, 64);
+        o.e = __shfl_xor(x.e, off, 64);
+        o.kind = __shfl_xor(x.kind, off, 64);
+        x = lmin(x, o);
+    }
+    return x;
+}
+
+template <int R>
+__global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_lars_kernel(const float* __restrict__ alpha0,
+                                                                           const float* __restrict__ G, int Kp, int K,
+                                                                           float lambda, int max_break, int kcap,
+                                                                           int64_t N, int32_t* __restrict__ idx,
+                                                                           float* __restrict__ coef,
+                                                                           int32_t* __restrict__ nnz,
+                                                                           int32_t* __restrict__ breaks_out) {
+    using L = LLay<R>;
+    extern __shared__ float lsm[];  // Lc[cap][cap]
+    __shared__ float s_a[LARS_MAX], s_d[LARS_MAX], s_s[LARS_MAX], s_y[LARS_MAX], s_g[LARS_MAX];
+    __shared__ int s_act[LARS_MAX];
+    __shared__ float s_rg[LASSO_MAX_WAVES];
+    __shared__ int s_re[LASSO_MAX_WAVES], s_rk[LASSO_MAX_WAVES];
+    __shared__ int s_m, s_fail;
+    const int64_t sig = blockIdx.x;
+    if (sig >= N) return;
+    const int t = threadIdx.x, T = blockDim.x, W = T >> 6, wid = t >> 6, lane = t & 63;
+    const int cap = kcap < LARS_MAX ? kcap : LARS_MAX;
+    float* Lc = lsm;
+    float c[R];
+    unsigned inact = 0;  // bit r: element r of this thread is a valid, currently inactive atom
+    load_vec<R>(alpha0 + sig * Kp, t, T, c);
+#pragma unroll
+    for (int r = 0; r < R; ++r) inact |= (L::elem(r, t, T) < K) ? (1u << r) : 0u;
+    if (t == 0) {
+        s_m = 0;
+        s_fail = 0;
+    }
+    __syncthreads();
+    // workgroup argmin helper
+    auto block_lmin = [&](LBest b) -> LBest {
+        b = wave_lmin(b);
+        if (W > 1) {
+            if (lane == 0) {
+                s_rg[wid] = b.g;
+                s_re[wid] = b.e;
+                s_rk[wid] = b.kind;
+            }
+            __syncthreads();
+            b = LBest{s_rg[0], s_re[0], s_rk[0]};
+            for (int w = 1; w < W; ++w) b = lmin(b, LBest{s_rg[w], s_re[w], s_rk[w]});
+            __syncthreads();
+        }
+        return b;
+    };
+    // append atom j (sign sg) to the Cholesky factor of G_AA: w = L^-1 G[A,j], rho = sqrt(G_jj - w'w)   (wave 0)
+    auto chol_append = [&](int j, float sg) {
+        if (wid == 0) {
+            const int m = s_m;
+            for (int i = lane; i < m; i += 64) s_g[i] = G[(int64_t)s_act[i] * Kp + j];
+            __builtin_amdgcn_wave_barrier();
+            float ww = 0.f;
+            for (int i = 0; i < m; ++i) {  // forward substitution, row i: lanes share the dot product
+                float part = 0.f;
+                for (int q = lane; q < i; q += 64) part = fmaf(Lc[i * cap + q], s_y[q], part);
+                part = wave_sum_f(part);
+                const float wi = (s_g[i] - part) / Lc[i * cap + i];
+                if (lane == 0) s_y[i] = wi;
+                __builtin_amdgcn_wave_barrier();
+                ww = fmaf(wi, wi, ww);
+            }
+            const float gjj = G[(int64_t)j * Kp + j];
+            const float vs = gjj - ww;
+            if (lane == 0) {
+                if (!(vs > 1e-6f * gjj) || m >= cap) {
+                    s_fail = 1;  // dependent atom / no room: stop the path here (the polish takes over)
+                } else {
+                    for (int q = 0; q < m; ++q) Lc[m * cap + q] = s_y[q];
+                    Lc[m * cap + m] = sqrtf(vs);
+                    s_act[m] = j;
+                    s_s[m] = sg;
+                    s_a[m] = 0.f;
+                    s_m = m + 1;
+                }
+            }
+        }
+        __syncthreads();
+    };
+    // d = G_AA^-1 s through the factor (wave 0): L y = s, L' d = y
+    auto solve_direction = [&]() {
+        if (wid == 0) {
+            const int m = s_m;
+            for (int i = 0; i < m; ++i) {
+                float part = 0.f;
+                for (int q = lane; q < i; q += 64) part = fmaf(Lc[i * cap + q], s_y[q], part);
+                part = wave_sum_f(part);
+                if (lane == 0) s_y[i] = (s_s[i] - part) / Lc[i * cap + i];
+                __builtin_amdgcn_wave_barrier();
+            }
+            for (int i = m - 1; i >= 0; --i) {
+                float part = 0.f;
+                for (int q = i + 1 + lane; q < m; q += 64) part = fmaf(Lc[q * cap + i], s_d[q], part);
+                part = wave_sum_f(part);
+                if (lane == 0) s_d[i] = (s_y[i] - part) / Lc[i * cap + i];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+    };
+
+    // ---- first atom: the largest |c|
+    float Clev;
+    {
+        LBest b{3.0e38f, 0x7fffffff, 0};
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((inact >> r) & 1u) b = lmin(b, LBest{-fabsf(c[r]), L::elem(r, t, T), c[r] >= 0.f ? 1 : 2});
+        b = block_lmin(b);
+        Clev = -b.g;
+        if (Clev > lambda && b.kind != 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (L::elem(r, t, T) == b.e) inact &= ~(1u << r);
+            chol_append(b.e, b.kind == 1 ? 1.f : -1.f);
+        }
+    }
+    int breaks = 0;
+    int just_left = -1;  // the atom that left at the previous breakpoint may not re-join at once (its |c| equals the level
+                         // up to rounding, which would otherwise produce a zero-length step and a cycle)
+    while (Clev > lambda && s_m > 0 && !s_fail && breaks < max_break) {
+        solve_direction();
+        const int m = s_m;
+        // u = G[:,A] d_A, one Gram row per active atom
+        float u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = 0.f;
+        for (int i = 0; i < m; ++i) {
+            float g[R];
+            load_vec<R>(G + (int64_t)s_act[i] * Kp, t, T, g);
+            const float di = s_d[i];
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = fmaf(di, g[r], u[r]);
+        }
+        // step length
+        LBest b{Clev - lambda, 0x7ffffffe, 0};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!((inact >> r) & 1u) || L::elem(r, t, T) == just_left) continue;
+            const float dp = 1.f - u[r], dm = 1.f + u[r];
+            const float gp = (dp > 1e-7f) ? (Clev - c[r]) / dp : 3.0e38f;   // c_j - g u_j = +(C - g)
+            const float gm = (dm > 1e-7f) ? (Clev + c[r]) / dm : 3.0e38f;   // c_j - g u_j = -(C - g)
+            if (gp > 0.f) b = lmin(b, LBest{gp, L::elem(r, t, T), 1});
+            if (gm > 0.f) b = lmin(b, LBest{gm, L::elem(r, t, T), 2});
+        }
+        for (int i = t; i < m; i += T) {  // an active coefficient reaches zero
+            const float gz = (s_d[i] != 0.f) ? -s_a[i] / s_d[i] : 3.0e38f;
+            if (gz > 0.f) b = lmin(b, LBest{gz, i, 3});
+        }
+        b = block_lmin(b);
+        const float gam = b.g > 0.f ? b.g : 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) c[r] = fmaf(-gam, u[r], c[r]);
+        for (int i = t; i < m; i += T) s_a[i] = fmaf(gam, s_d[i], s_a[i]);
+        Clev -= gam;
+        ++breaks;
+        __syncthreads();
+        if (b.kind == 0) break;  // reached lambda
+        just_left = -1;
+        if (b.kind == 3) {
+            // the atom at active position b.e leaves: rebuild the factor for the remaining atoms (rare; O(m^2) loads)
+            const int m0 = s_m, pos = b.e;
+            __shared__ int s_keep[LARS_MAX];
+            __shared__ float s_keep_a[LARS_MAX], s_keep_s[LARS_MAX];
+            const int gone = s_act[pos];
+            just_left = gone;
+            for (int i = t; i < m0; i += T) {
+                s_keep[i] = s_act[i];
+                s_keep_a[i] = s_a[i];
+                s_keep_s[i] = s_s[i];
+            }
+            __syncthreads();
+            if (t == 0) s_m = pos;  // positions before `pos` keep their rows
+            __syncthreads();
+            for (int i = pos + 1; i < m0 && !s_fail; ++i) {
+                chol_append(s_keep[i], s_keep_s[i]);
+                if (t == 0 && !s_fail) s_a[s_m - 1] = s_keep_a[i];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (L::elem(r, t, T) == gone) inact |= (1u << r);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (L::elem(r, t, T) == b.e) inact &= ~(1u << r);
+            chol_append(b.e, b.kind == 1 ? 1.f : -1.f);
+        }
+    }
+    __syncthreads();
+    const int m = s_m;
+    for (int p = t; p < kcap; p += T) {
+        const bool in = p < m && s_a[p] != 0.f;
+        idx[sig * kcap + p] = in ? s_act[p] : -1;
+        coef[sig * kcap + p] = in ? s_a[p] : 0.f;
+    }
+    if (t == 0) {
+        nnz[sig] = m < kcap ? m : kcap;
+        if (breaks_out) breaks_out[sig] = breaks;
+    }
+}
+
+int lasso_lars_from_alpha0(const float* alpha0, const float* G, int Kp, int K, float lambda, int max_break, int kcap,
+                           int64_t N, int32_t* idx, float* coef, int32_t* nnz, int32_t* breaks, hipStream_t stream) {
+    if (N <= 0) return LYS_OK;
+    if (N > 0x7fffffffLL) {
+        set_error("lasso(lars): too many signals in one tile");
+        return LYS_ENOSUP;
+    }
+    const int cap = kcap < LARS_MAX ? kcap : LARS_MAX;
+    const size_t lds = (size_t)cap * cap * sizeof(float);
+    const dim3 grid((unsigned)N);
+    static bool attr_set[64][5] = {};
+    int dev = 0;
+    LYS_CHECK_HIP(hipGetDevice(&dev));
+#define LYS_LARS(RR, TT, SLOT)                                                                                          \
+    do {                                                                                                                \
+        if (dev >= 0 && dev < 64 && !attr_set[dev][SLOT]) {                                                             \
+            LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lasso_lars_kernel<RR>),                     \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,                               \
+                                              (int)(LARS_MAX * LARS_MAX * sizeof(float))));                             \
+            attr_set[dev][SLOT] = true;                                                                                 \
+        }                                                                                                               \
+        hipLaunchKernelGGL(lasso_lars_kernel<RR>, grid, dim3(TT), lds, stream, alpha0, G, Kp, K, lambda, max_break,    \
+                           kcap, N, idx, coef, nnz, breaks);                                                            \
+    } while (0)
+    if (Kp == 64) LYS_LARS(1, 64, 0);
+    else if (Kp == 128) LYS_LARS(2, 64, 1);
+    else if (Kp == 256) LYS_LARS(4, 64, 2);
+    else if (Kp == 512) LYS_LARS(8, 64, 3);
+    else if (Kp % 1024 == 0 && Kp / 16 <= 64 * LASSO_MAX_WAVES) LYS_LARS(16, Kp / 16, 4);
+    else {
+        set_error("lasso(lars): padded atom count %d not supported (max %d)", Kp, 1024 * LASSO_MAX_WAVES);
+        return LYS_ENOSUP;
+    }
+#undef LYS_LARS
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 int lasso_from_alpha0(const float* alpha0, const float* G, int Kp, int K, float lambda, float tol, int max_steps,
                       int kcap, int64_t N, int32_t* idx, float* coef, int32_t* nnz, int32_t* steps,
-                      hipStream_t stream) {
+                      hipStream_t stream, int warm) {
     if (N <= 0) return LYS_OK;
     if (N > 0x7fffffffLL) {
         set_error("lasso: too many signals in one tile");
@@ -212,7 +503,7 @@ int lasso_from_alpha0(const float* alpha0, const float* G, int Kp, int K, float 
     const dim3 grid((unsigned)N);
 #define LYS_LASSO(RR, TT)                                                                                              \
     hipLaunchKernelGGL(lasso_cd_kernel<RR>, grid, dim3(TT), 0, stream, alpha0, G, Kp, K, lambda, tol, max_steps, kcap, \
-                       N, idx, coef, nnz, steps)
+                       N, idx, coef, nnz, steps, warm)
     if (Kp == 64) LYS_LASSO(1, 64);
     else if (Kp == 128) LYS_LASSO(2, 64);
     else if (Kp == 256) LYS_LASSO(4, 64);

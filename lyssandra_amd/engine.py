@@ -203,7 +203,8 @@ def omp_tol_encode(Xs, dd, tol, kcap=None, out=None):
     return idx, coef, nnz
 
 
-def lasso_encode(Xs, dd, lam, kcap=None, max_steps=None, tol=1e-6, out=None, return_steps=False):
+def lasso_encode(Xs, dd, lam, kcap=None, max_steps=None, tol=1e-6, out=None, return_steps=False, solver='cd',
+                 return_breakpoints=False):
     """min_a 0.5||x - D a||^2 + lam ||a||_1 for every row of ``Xs`` (sparse_coding.py:487-509, spams.lasso mode 2).
 
     Greedy coordinate descent on the Gram matrix in liblyssa_hip.so.  Returns the triplet (idx, coef, nnz) with
@@ -225,14 +226,27 @@ def lasso_encode(Xs, dd, lam, kcap=None, max_steps=None, tol=1e-6, out=None, ret
     else:
         idx, coef, nnz = out
     steps = torch.zeros((N,), dtype=torch.int32, device=dd.device)
+    breaks = torch.zeros((N,), dtype=torch.int32, device=dd.device) if solver == 'lars' else None
     if N > 0:
         ws = _workspace(lib.lys_lasso_workspace_bytes(dd.n, dd.K, N), dd.device, "bomp")
-        _lib.check(lib.lys_lasso_encode(_ptr(Xs), _ld(Xs), _ptr(dd.D), _ptr(dd.gram()), dd.n, dd.K, float(lam), kcap,
-                                        max_steps, float(tol), N, _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(steps),
-                                        _ptr(ws), ws.numel(), _stream()), "lys_lasso_encode")
+        if solver == 'lars':
+            # LARS-lasso homotopy (what spams.lasso runs) + coordinate-descent polish from its end point
+            _lib.check(lib.lys_lasso_lars_encode(_ptr(Xs), _ld(Xs), _ptr(dd.D), _ptr(dd.gram()), dd.n, dd.K, float(lam),
+                                                 kcap, 4 * kcap + 8, max_steps, float(tol), N, _ptr(idx), _ptr(coef),
+                                                 _ptr(nnz), _ptr(steps), _ptr(breaks), _ptr(ws), ws.numel(), _stream()),
+                       "lys_lasso_lars_encode")
+        elif solver == 'cd':
+            _lib.check(lib.lys_lasso_encode(_ptr(Xs), _ld(Xs), _ptr(dd.D), _ptr(dd.gram()), dd.n, dd.K, float(lam), kcap,
+                                            max_steps, float(tol), N, _ptr(idx), _ptr(coef), _ptr(nnz), _ptr(steps),
+                                            _ptr(ws), ws.numel(), _stream()), "lys_lasso_encode")
+        else:
+            raise ValueError("lasso solver must be 'cd' or 'lars'")
+    res = (idx, coef, nnz)
     if return_steps:
-        return idx, coef, nnz, steps
-    return idx, coef, nnz
+        res = res + (steps,)
+    if return_breakpoints:
+        res = res + (breaks,)
+    return res
 
 
 def densify(idx, coef, nnz, K, out=None):

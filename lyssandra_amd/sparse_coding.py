@@ -78,9 +78,11 @@ class sparse_encoder(object):
             lam = self.params.get('lambda')
             if lam is None:
                 raise ValueError("params['lambda'] is required for algorithm='lasso'")
+            # params['solver']: 'lars' (LARS-lasso homotopy like SPAMS + coordinate-descent polish, the default) or 'cd'
             idx, coef, nnz, steps = engine.lasso_encode(Xs, dd, lam, kcap=self.params.get('kcap'),
                                                         max_steps=self.params.get('max_steps'),
-                                                        tol=self.params.get('tol', 1e-6), out=out, return_steps=True)
+                                                        tol=self.params.get('tol', 1e-6), out=out, return_steps=True,
+                                                        solver=self.params.get('solver', 'lars'))
             if steps.numel():
                 if int(steps.min().item()) < 0:
                     raise RuntimeError("lasso: more than kcap=%d non-zero coefficients for some signal; raise "

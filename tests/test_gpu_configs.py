@@ -84,9 +84,12 @@ def test_online_dl_config4_shape(eng):
     Ao, Bo = np.zeros((K, K)), np.zeros((n, K))
     for b, beta_i in enumerate([0.0, 0.9]):
         xb = Xs[b * bs:(b + 1) * bs]
-        idx, coef, nnz, steps = eng.lasso_encode(xb, dd, lam, return_steps=True)
+        # the inner solver config 4 names: LARS homotopy (+ coordinate-descent polish from its end point)
+        idx, coef, nnz, steps, br = eng.lasso_encode(xb, dd, lam, return_steps=True, solver='lars',
+                                                     return_breakpoints=True)
         st = steps.cpu().numpy()
         assert st.min() >= 0 and st.max() < 50 * n, (st.min(), st.max())       # converged, no truncated support
+        assert int(br.max()) <= 2 * n + 8
         hi, hc, hn = idx.cpu().numpy(), coef.double().cpu().numpy(), nnz.cpu().numpy()
         assert hn.max() <= n and hn.mean() > 2
         X = xb.t().contiguous().double().cpu().numpy()
@@ -110,8 +113,8 @@ def test_online_dl_config4_shape(eng):
         ea = np.max(np.abs(Ag - Ao)) / np.abs(Ao).max()
         eb = np.max(np.abs(Bg - Bo)) / np.abs(Bo).max()
         ed = _atom_err(dd.to_host(), Do)
-        print("batch %d: nnz mean %.1f max %d, steps max %d, KKT %.2e, A err %.2e, B err %.2e, atom err %.2e"
-              % (b, hn.mean(), hn.max(), st.max(), kkt, ea, eb, ed))
+        print("batch %d: nnz mean %.1f max %d, LARS breakpoints max %d, polish steps max %d, KKT %.2e, A err %.2e, "
+              "B err %.2e, atom err %.2e" % (b, hn.mean(), hn.max(), int(br.max()), st.max(), kkt, ea, eb, ed))
         assert ea < 1e-5 and eb < 1e-5 and ed < 1e-5
         dd.set(Do)                                                   # next batch starts from the oracle's dictionary
 
@@ -244,3 +247,59 @@ def test_error_constrained_omp_and_large_K_thresh(eng):
     ok = orc.thresh_gap(Db.T @ Xb, 40) >= 1e-5
     assert ok.mean() > 0.9 and ((Zb != 0) == (Zo != 0)).all(axis=0)[ok].all()
     assert np.max(np.abs(Zb - Zo)[:, ok]) < 1e-5 * np.abs(Zo).max()
+
+
+@pytest.mark.parametrize("n,K,N,lam,unit", [(64, 256, 60, 0.15, True), (64, 1024, 40, 0.02, True), (32, 512, 40, 0.01, True),
+                                            (20, 40, 50, 0.1, True), (128, 2048, 24, 0.15, False),
+                                            (128, 8192, 8, 0.05, True)])
+def test_lasso_lars_homotopy(eng, n, K, N, lam, unit):
+    """`sparse_encoder('lasso')` through the LARS-lasso homotopy kernel (the algorithm family of spams.lasso(mode=2),
+    sparse_coding.py:487-509; SPAMS itself is absent, parity with it is unpinned): KKT conditions in float64, agreement
+    with sklearn's float64 `lars_path(method='lasso')`, about one breakpoint per non-zero -- including the dense regimes
+    (non-zeros ~ n) where coordinate descent does not converge in thousands of steps."""
+    from sklearn.linear_model import lars_path
+    from oracle import lyssa_oracle as orc
+    rs = np.random.RandomState(n + K)
+    D = rs.randn(n, K)
+    D /= np.linalg.norm(D, axis=0)
+    if not unit:
+        D *= rs.uniform(0.7, 1.4, size=K)[None, :]
+    X = rs.randn(n, N)
+    X /= np.linalg.norm(X, axis=0)
+    D = D.astype(np.float32).astype(np.float64)
+    X = X.astype(np.float32).astype(np.float64)
+    Xs = eng.signals_to_device(X)
+    dd = eng.DeviceDictionary.from_host(D)
+    idx, coef, nnz, steps, br = eng.lasso_encode(Xs, dd, lam, return_steps=True, solver='lars', return_breakpoints=True)
+    Z = orc.densify(idx.cpu().numpy(), coef.double().cpu().numpy(), nnz.cpu().numpy(), K)
+    kkt = orc.lasso_kkt_violation(X, D, Z, lam)
+    worst, worst_obj = 0.0, 0.0
+
+    def objective(x, a):
+        return 0.5 * np.sum((x - D @ a) ** 2) + lam * np.abs(a).sum()
+
+    for i in range(N):
+        _, _, coefs = lars_path(D, X[:, i], method='lasso', alpha_min=lam / n)
+        ref = coefs[:, -1]
+        worst = max(worst, np.max(np.abs(Z[:, i] - ref)) / max(np.abs(ref).max(), 1e-30))
+        worst_obj = max(worst_obj, (objective(X[:, i], Z[:, i]) - objective(X[:, i], ref)) / objective(X[:, i], ref))
+    nz = (Z != 0).sum(0)
+    dense = nz.max() >= 0.75 * min(n, K)
+    print("n=%d K=%d lam=%g: nnz mean %.1f max %d, breakpoints max %d, polish steps max %d, KKT %.2e, vs lars_path: "
+          "coefficients %.2e, objective excess %.2e" % (n, K, lam, nz.mean(), nz.max(), int(br.max()),
+                                                        int(steps.abs().max()), kkt, worst, worst_obj))
+    assert kkt < 1e-5
+    # the objective is matched to fp32 accuracy everywhere; the coefficients to 1e-4 unless the support approaches n,
+    # where the active Gram block is ill-conditioned and a 1e-6 KKT residual (the fp32 floor) moves them by cond * 1e-6
+    assert worst_obj < 1e-6
+    assert worst < (2e-2 if dense else 1e-4)
+    assert int(steps.min()) >= 0                                     # no truncated support
+    assert int(br.max()) <= 2 * min(n, K) + 8                        # ~ one breakpoint per non-zero (+ a few drops)
+    assert nz.max() <= min(n, K)
+    # the drop-in uses it by default and agrees with the coordinate-descent solver where that one converges
+    if lam >= 0.15:
+        from lyssandra_amd.sparse_coding import sparse_encoder
+        Zl = sparse_encoder(algorithm='lasso', params={'lambda': lam}, verbose=False).encode(X, D)
+        Zc = sparse_encoder(algorithm='lasso', params={'lambda': lam, 'solver': 'cd'}, verbose=False).encode(X, D)
+        assert np.max(np.abs(Zl - Z)) == 0.0
+        assert np.max(np.abs(Zc - Zl)) < 1e-4 * np.abs(Zl).max()
