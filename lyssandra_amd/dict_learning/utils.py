@@ -15,17 +15,17 @@ def init_dictionary(X, n_atoms, method='data', return_unused_data=False, normali
     X = np.asarray(X)
     if method == "data":
         energy = np.einsum('ij,ij->j', X, X)
-        idxs = np.flatnonzero(energy > 1e-6).tolist()
-        if len(idxs) < n_atoms:
+        idxs = np.flatnonzero(energy > 1e-6)                 # candidates, ascending (kept as an array: N can be 10^6)
+        if idxs.size < n_atoms:
             raise ValueError("not enough datapoints to initialize the dictionary")
-        subset = np.random.choice(len(idxs), size=n_atoms, replace=False)
-        subset_idxs = np.array(idxs).astype(int)[subset]
-        D = np.array(X[:, subset_idxs], dtype=np.float64)
+        subset = np.random.choice(idxs.size, size=n_atoms, replace=False)      # the reference's draw (:60)
+        D = np.array(X[:, idxs[subset]], dtype=np.float64)
         if normalize:
             D = norm_cols(D)
         if return_unused_data:
-            s = set(subset_idxs.tolist())
-            return D, [x for x in idxs if x not in s]
+            keep = np.ones(idxs.size, dtype=bool)
+            keep[subset] = False
+            return D, idxs[keep].tolist()                      # remaining candidates, ascending, a Python list
         return D
     if method == "random":
         D = np.random.randn(X.shape[0], n_atoms)

@@ -18,8 +18,18 @@ _lib.load()
 torch.zeros(1, device="cuda")
 np.random.seed(1)
 kc = ksvd_coder(n_atoms=K, sparse_coder=se, max_iter=50, approx=True, verbose=False)
+import cProfile
+import pstats
+pr = cProfile.Profile() if "--profile" in sys.argv else None
 t0 = time.perf_counter()
+if pr:
+    pr.enable()
 kc.fit(X)
+torch.cuda.synchronize()
+if pr:
+    pr.disable()
 t = time.perf_counter() - t0
+if pr:
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
 print("ksvd_coder.fit: N=%d K=%d k=%d max_iter=50 -> %.2f s wall (host float64 input, 11 alternations), D %s"
       % (N, K, k, t, kc.D.shape))
