@@ -285,6 +285,7 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
                               "frac": sweep_gbs / PEAK_HBM_GBS,
                               "bytes_model": "SURVEY 8(d): 8*n bytes per (atom, signal) non-zero = %.3g GB per sweep per GPU"
                                              % (8 * n * nnz_tot / 1e9),
+                              "traffic": _sweep_traffic(),
                               "traffic_model_gbs": 12 * n * nnz_tot / (ms["sweep"] * 1e-3) / 1e9,
                               "traffic_model": "12*n bytes per non-zero: the row is read for the statistics, read and "
                                                "written for the update"},
@@ -294,6 +295,14 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
         res["exchange"] = {"collectives_per_sweep": nb, "bytes_per_collective": stride * 8,
                            "bytes_per_sweep": nb * stride * 8}
     return res
+
+
+def _sweep_traffic():
+    """HBM bytes of one sweep from the PMC passes recorded in profiles/traffic.json (None when absent)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["bksvd_step_kernel"]["bytes_per_sweep"]
+    except Exception:
+        return None
 
 
 def odl_batch(Xs, dd0, k, group, iters=3):
