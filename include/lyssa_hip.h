@@ -220,10 +220,10 @@ int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, f
  *                        (multi-GPU: all-reduce slab c = stats + c * stride, `stride` doubles, here -- the per-atom sum
  *                         of ksvd.py:118 for B atoms at once)
  *     D_packed <- D_next.
- *   row_ptr / entry / entry_meta / entry_coef [N*k each]: lys_bksvd_index of the current codes = the by-atom index
- *   (a block's entries are one contiguous range) with, per entry, the signal id, the coefficient, and slot | flags
- *   (bit 8: the signal uses another atom of the same block, 9: of the previous block, 10: of the next block), so that
- *   the common case moves only the residual row; cg_ptr [ceil(K/B) * 2^B + 1] / cg_entry [N*k/2 + 1]: the leaders of
+ *   row_ptr [K+1] / entry_records [N*k records of 16 bytes, 16-byte aligned]: lys_bksvd_index of the current codes = the
+ *   by-atom index (a block's entries are one contiguous range) with one record {int32 signal, int32 slot | flags, fp32
+ *   coefficient, 0} per entry (flag bit 8: the signal uses another atom of the same block, 9: of the previous block,
+ *   10: of the next block, 11: leader entry), so that the common case moves only the residual row; cg_ptr [ceil(K/B) * 2^B + 1] / cg_entry [N*k/2 + 1]: the leaders of
  *   the signals that use several atoms of one block (and none of the previous), sorted by (block << B) | in-block atom
  *   mask, for the tuple moments; workspace: lys_bksvd_index_workspace_bytes.  stats fp64
  *   [lys_bksvd_stats_bytes], zeroed by the caller once per cycle (lys_bksvd_sweep builds the index and zeroes it).
@@ -239,18 +239,17 @@ int lys_bksvd_layout(int n, int B, int32_t* out6);
 size_t lys_bksvd_stats_bytes(int n, int K, int B);
 size_t lys_bksvd_index_workspace_bytes(int K, int k, int64_t N, int B);
 int lys_bksvd_index(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int B,
-                    int32_t* row_ptr, int32_t* entry, int32_t* entry_meta, float* entry_coef,
-                    int32_t* cg_ptr, int32_t* cg_entry, void* workspace, size_t workspace_bytes, void* stream);
+                    int32_t* row_ptr, void* entry_records, int32_t* cg_ptr, int32_t* cg_entry,
+                    void* workspace, size_t workspace_bytes, void* stream);
 /* one half step: mode 0 = X(c), c in [0, nb]; mode 1 = Y(c), c in [1, nb] */
 int lys_bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int k,
-                   const int32_t* row_ptr, const int32_t* entry, const int32_t* entry_meta, const float* entry_coef,
-                   const int32_t* cg_ptr, const int32_t* cg_entry, const int32_t* idx, float* coef,
-                   const float* D_packed, float* D_next, double* stats, void* stream);
+                   const int32_t* row_ptr, const void* entry_records, const int32_t* cg_ptr, const int32_t* cg_entry,
+                   const int32_t* idx, float* coef, const float* D_packed, float* D_next, double* stats, void* stream);
 /* one whole cycle on one GPU: index (workspace: lys_bksvd_index_workspace_bytes) + all launches + D_packed <- D_next */
 int lys_bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
-                    const int32_t* nnz, int B, int32_t* row_ptr, int32_t* entry, int32_t* entry_meta,
-                    float* entry_coef, int32_t* cg_ptr, int32_t* cg_entry, void* workspace, size_t workspace_bytes,
-                    double* stats, float* D_packed, float* D_next, void* stream);
+                    const int32_t* nnz, int B, int32_t* row_ptr, void* entry_records, int32_t* cg_ptr,
+                    int32_t* cg_entry, void* workspace, size_t workspace_bytes, double* stats, float* D_packed,
+                    float* D_next, void* stream);
 
 /* ---- online dictionary learning (online_dict_learn.py:84-98) ---------------------------------- */
 /*

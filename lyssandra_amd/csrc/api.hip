@@ -51,8 +51,7 @@ int residual(const float*, int64_t, const float*, int, int, int, int64_t, const 
              float*, int64_t, double*, hipStream_t);
 size_t csr_workspace_bytes(int, int, int64_t);
 int csr_by_atom(const int32_t*, const float*, const int32_t*, int, int, int64_t, int32_t*, int32_t*, void*, size_t,
-                hipStream_t, int32_t* emeta = nullptr, float* ecoef = nullptr, int logb = 0, int32_t* cg_ptr = nullptr,
-                int32_t* cg_entry = nullptr);
+                hipStream_t, int logb = 0, int32_t* cg_ptr = nullptr, int32_t* cg_entry = nullptr);
 size_t csr_block_workspace_bytes(int K, int k, int64_t N, int B);
 int ksvd_atom_accumulate(int, const float*, int64_t, int, int, const int32_t*, const int32_t*, const float*, double*,
                          hipStream_t);
@@ -79,10 +78,10 @@ struct BkLayout {
     int B, G, stride, offQ, offC, offGC;
 };
 BkLayout bk_layout(int n, int B);
-int bksvd_step(int, int, int, float*, int64_t, int, int, int, const int32_t*, const int32_t*, const int32_t*, const float*,
-               const int32_t*, const int32_t*, const int32_t*, float*, const float*, float*, double*, hipStream_t);
-int bksvd_sweep(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const int32_t*, int, int32_t*, int32_t*,
-                int32_t*, float*, int32_t*, int32_t*, void*, size_t, double*, float*, float*, hipStream_t);
+int bksvd_step(int, int, int, float*, int64_t, int, int, int, const int32_t*, const void*, const int32_t*, const int32_t*,
+               const int32_t*, float*, const float*, float*, double*, hipStream_t);
+int bksvd_sweep(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const int32_t*, int, int32_t*, void*,
+                int32_t*, int32_t*, void*, size_t, double*, float*, float*, hipStream_t);
 int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const float*, const int32_t*, const int32_t*,
                    const int32_t*, float*, float*, hipStream_t);
 int axpby(float*, float, const float*, int64_t, hipStream_t);
@@ -540,33 +539,32 @@ size_t lys_bksvd_stats_bytes(int n, int K, int B) { return bksvd_stats_doubles(n
 size_t lys_bksvd_index_workspace_bytes(int K, int k, int64_t N, int B) { return csr_block_workspace_bytes(K, k, N, B); }
 
 int lys_bksvd_index(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int B,
-                    int32_t* row_ptr, int32_t* entry, int32_t* entry_meta, float* entry_coef, int32_t* cg_ptr,
-                    int32_t* cg_entry, void* workspace, size_t workspace_bytes, void* stream) {
-    LYS_REQUIRE(idx && coef && nnz && row_ptr && entry && entry_meta && entry_coef && cg_ptr && cg_entry && workspace &&
-                    (B == 4 || B == 8), "bksvd_index: bad arguments");
-    return csr_by_atom(idx, coef, nnz, K, k, N, row_ptr, entry, workspace, workspace_bytes, STREAM(stream), entry_meta,
-                       entry_coef, B == 8 ? 3 : 2, cg_ptr, cg_entry);
+                    int32_t* row_ptr, void* entry_records, int32_t* cg_ptr, int32_t* cg_entry, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    LYS_REQUIRE(idx && coef && nnz && row_ptr && entry_records && cg_ptr && cg_entry && workspace && (B == 4 || B == 8) &&
+                    (reinterpret_cast<uintptr_t>(entry_records) & 15) == 0, "bksvd_index: bad arguments");
+    return csr_by_atom(idx, coef, nnz, K, k, N, row_ptr, static_cast<int32_t*>(entry_records), workspace, workspace_bytes,
+                       STREAM(stream), B == 8 ? 3 : 2, cg_ptr, cg_entry);
 }
 
 int lys_bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr,
-                   const int32_t* entry, const int32_t* entry_meta, const float* entry_coef, const int32_t* cg_ptr,
-                   const int32_t* cg_entry, const int32_t* idx, float* coef, const float* D_packed, float* D_next,
-                   double* stats, void* stream) {
-    LYS_REQUIRE(R && row_ptr && entry && entry_meta && entry_coef && cg_ptr && cg_entry && idx && coef && D_packed &&
-                    D_next && stats && (ldr % 4) == 0 && (B == 4 || B == 8), "bksvd_step: bad arguments");
-    return bksvd_step(mode, c, B, R, ldr, n, K, k, row_ptr, entry, entry_meta, entry_coef, cg_ptr, cg_entry, idx, coef,
-                      D_packed, D_next, stats, STREAM(stream));
+                   const void* entry_records, const int32_t* cg_ptr, const int32_t* cg_entry, const int32_t* idx,
+                   float* coef, const float* D_packed, float* D_next, double* stats, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry_records && cg_ptr && cg_entry && idx && coef && D_packed && D_next && stats &&
+                    (ldr % 4) == 0 && (B == 4 || B == 8), "bksvd_step: bad arguments");
+    return bksvd_step(mode, c, B, R, ldr, n, K, k, row_ptr, entry_records, cg_ptr, cg_entry, idx, coef, D_packed, D_next,
+                      stats, STREAM(stream));
 }
 
 int lys_bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
-                    const int32_t* nnz, int B, int32_t* row_ptr, int32_t* entry, int32_t* entry_meta, float* entry_coef,
-                    int32_t* cg_ptr, int32_t* cg_entry, void* workspace, size_t workspace_bytes, double* stats,
-                    float* D_packed, float* D_next, void* stream) {
-    LYS_REQUIRE(R && idx && coef && nnz && row_ptr && entry && entry_meta && entry_coef && cg_ptr && cg_entry &&
-                    workspace && stats && D_packed && D_next && (ldr % 4) == 0 && (B == 4 || B == 8),
-                "bksvd_sweep: bad arguments");
-    return bksvd_sweep(R, ldr, n, K, k, N, idx, coef, nnz, B, row_ptr, entry, entry_meta, entry_coef, cg_ptr, cg_entry,
-                       workspace, workspace_bytes, stats, D_packed, D_next, STREAM(stream));
+                    const int32_t* nnz, int B, int32_t* row_ptr, void* entry_records, int32_t* cg_ptr, int32_t* cg_entry,
+                    void* workspace, size_t workspace_bytes, double* stats, float* D_packed, float* D_next,
+                    void* stream) {
+    LYS_REQUIRE(R && idx && coef && nnz && row_ptr && entry_records && cg_ptr && cg_entry && workspace && stats &&
+                    D_packed && D_next && (ldr % 4) == 0 && (B == 4 || B == 8) &&
+                    (reinterpret_cast<uintptr_t>(entry_records) & 15) == 0, "bksvd_sweep: bad arguments");
+    return bksvd_sweep(R, ldr, n, K, k, N, idx, coef, nnz, B, row_ptr, entry_records, cg_ptr, cg_entry, workspace,
+                       workspace_bytes, stats, D_packed, D_next, STREAM(stream));
 }
 
 size_t lys_ksvd_exact_workspace_bytes(int n) { return ksvd_exact_work_doubles(n) * sizeof(double); }

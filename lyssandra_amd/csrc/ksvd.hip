@@ -174,7 +174,8 @@ __global__ __launch_bounds__(64) void csr_count_or_fill_kernel(const int32_t* __
     extern __shared__ int s_cnt[];
     const int lane = threadIdx.x;
     const int chunk = blockIdx.x;
-    for (int a = lane; a < K; a += 64) s_cnt[a] = fill ? row_ptr[a] + counts[(int64_t)a * T + chunk] : 0;
+    // counts is chunk-major [T][K]: a wave reads / writes its K counters as one contiguous run
+    for (int a = lane; a < K; a += 64) s_cnt[a] = fill ? row_ptr[a] + counts[(int64_t)chunk * K + a] : 0;
     __syncthreads();
     const int64_t s0 = (int64_t)chunk * S;
     const int64_t s1 = (s0 + S < N) ? s0 + S : N;
@@ -230,9 +231,7 @@ __global__ __launch_bounds__(64) void csr_count_or_fill_kernel(const int32_t* __
                 if (live) {
                     const int pos = atomicAdd(&s_cnt[av[u]], 1);
                     if (fill == 2) {
-                        entry[pos] = (int32_t)(sb + u);
-                        emeta[pos] = meta;
-                        ecoef[pos] = cv[u];
+                        reinterpret_cast<int4*>(entry)[pos] = make_int4((int)(sb + u), meta, __builtin_bit_cast(int, cv[u]), 0);
                     } else if (fill) {
                         entry[pos] = (int32_t)((sb + u) * k + lane);
                     }
@@ -254,35 +253,116 @@ __global__ __launch_bounds__(64) void csr_count_or_fill_kernel(const int32_t* __
     }
     if (!fill) {
         __syncthreads();
-        for (int a = lane; a < K; a += 64) counts[(int64_t)a * T + chunk] = s_cnt[a];
+        for (int a = lane; a < K; a += 64) counts[(int64_t)chunk * K + a] = s_cnt[a];
     }
 }
 
-// Exclusive scan of counts[a][0..T) inside every atom (one 256-thread block per atom, coalesced), atom totals out.
-__global__ __launch_bounds__(256) void csr_scan_atoms_kernel(int32_t* __restrict__ counts, int T,
-                                                             int32_t* __restrict__ totals) {
-    __shared__ int s_part[256];
-    const int a = blockIdx.x, t = threadIdx.x;
-    int32_t* c = counts + (int64_t)a * T;
-    const int per = (T + 255) / 256;
-    const int b = t * per, e = (b + per < T) ? b + per : T;
-    int sum = 0;
-    for (int i = b; i < e; ++i) sum += c[i];
-    s_part[t] = sum;
+// Block-sweep index, k <= 16: the same two passes with FOUR signals per wave instruction (one 16-lane DPP row per
+// signal, lane = slot).  The kernel above spends its time in VALU instructions that use 10 of 64 lanes; the order of the
+// signals inside an atom, which it preserves, does not matter to the block sweep (ksvd_block.hip walks contiguous
+// chunks and sums with atomics).  Flags / coupled-leader index: see csr_count_or_fill_kernel.
+template <int L>
+__device__ __forceinline__ int csr_row_bcast(int x) {  // lane L of every 16-lane row, in all lanes of that row
+    return __builtin_amdgcn_update_dpp(0, x, 0x150 + L, 0xf, 0xf, true);
+}
+template <int J>
+__device__ __forceinline__ void csr_flag_step(int a, int blk, int k, int logb, unsigned& msk, int& meta) {
+    if constexpr (J < 16) {
+        if (J < k) {  // uniform
+            const int aj = csr_row_bcast<J>(a);
+            const int bj = aj >> logb;
+            const bool on = aj >= 0;
+            msk |= (on && bj == blk) ? (1u << (aj & ((1 << logb) - 1))) : 0u;
+            meta |= (on && bj == blk - 1) ? 0x200 : 0;
+            meta |= (on && bj == blk + 1) ? 0x400 : 0;
+            csr_flag_step<J + 1>(a, blk, k, logb, msk, meta);
+        }
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(64) void bksvd_index_kernel(const int32_t* __restrict__ idx, const float* __restrict__ coef,
+                                                         int K, int k, int64_t N, int T, int64_t S,
+                                                         int32_t* __restrict__ counts,
+                                                         const int32_t* __restrict__ row_ptr,
+                                                         int4* __restrict__ erec, int logb,
+                                                         int32_t* __restrict__ cg_cur, int32_t* __restrict__ cg_entry) {
+    extern __shared__ int s_cnt[];
+    const int lane = threadIdx.x, row = lane >> 4, j = lane & 15;
+    const int chunk = blockIdx.x;
+    for (int a = lane; a < K; a += 64) s_cnt[a] = FILL ? row_ptr[a] + counts[(int64_t)chunk * K + a] : 0;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int v = (t >= off) ? s_part[t - off] : 0;
-        __syncthreads();
-        s_part[t] += v;
-        __syncthreads();
+    const int64_t s0 = (int64_t)chunk * S;
+    const int64_t s1 = (s0 + S < N) ? s0 + S : N;
+    const int bsz = 1 << logb;
+    constexpr int U = 4;  // quads of signals in flight
+    for (int64_t sb = s0; sb < s1; sb += 4 * U) {
+        int av[U];
+        float cv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t sig = sb + 4 * u + row;
+            const bool in = (sig < s1) && (j < k);
+            av[u] = in ? idx[sig * k + j] : -1;
+            cv[u] = in ? coef[sig * k + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t sig = sb + 4 * u + row;
+            const bool live = cv[u] != 0.f && av[u] >= 0 && av[u] < K;
+            const int a = live ? av[u] : -1;
+            const int blk = a >> logb;
+            unsigned msk = 0;
+            int meta = j;
+            csr_flag_step<0>(a, blk, k, logb, msk, meta);
+            const bool coupled = (msk & (msk - 1)) != 0;
+            const bool leader = live && ((a & (bsz - 1)) == __ffs(msk) - 1);
+            meta |= coupled ? 0x100 : 0;
+            meta |= leader ? 0x800 : 0;
+            if (leader && coupled && !(meta & 0x200)) {
+                const int key = (blk << bsz) | (int)msk;
+                const int pos = atomicAdd(&cg_cur[key], 1);  // count pass: a counter; fill pass: the position
+                if (FILL) cg_entry[pos] = (int32_t)sig;
+            }
+            if (live) {
+                const int pos = atomicAdd(&s_cnt[a], 1);
+                // one 16-byte record per entry {signal, slot | flags, coefficient bits, 0}: one scattered store here, one
+                // coalesced load in the sweep (three separate 4-byte stores made this pass twice as long)
+                if (FILL) erec[pos] = make_int4((int)sig, meta, __builtin_bit_cast(int, cv[u]), 0);
+            }
+        }
     }
-    int run = (t == 0) ? 0 : s_part[t - 1];
-    for (int i = b; i < e; ++i) {
-        const int v = c[i];
-        c[i] = run;
-        run += v;
+    if (!FILL) {
+        __syncthreads();
+        for (int a = lane; a < K; a += 64) counts[(int64_t)chunk * K + a] = s_cnt[a];
     }
-    if (t == 255) totals[a] = s_part[255];
+}
+
+// Exclusive scan over the chunks, in place, of the chunk-major table counts[T][K] for 64 consecutive atoms per workgroup
+// (1024 threads = 16 chunk segments x 64 atoms: every access is a coalesced 256-byte run), atom totals out.
+__global__ __launch_bounds__(1024) void csr_scan_chunks_kernel(int32_t* __restrict__ counts, int T, int K,
+                                                              int32_t* __restrict__ totals) {
+    __shared__ int s_seg[16][64];
+    const int a = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
+    const int per = (T + 15) / 16;
+    const int c0 = seg * per, c1 = (c0 + per < T) ? c0 + per : T;
+    int sum = 0;
+    if (a < K) {
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) sum += counts[(int64_t)c * K + a];
+    }
+    s_seg[seg][threadIdx.x & 63] = sum;
+    __syncthreads();
+    int run = 0;
+    for (int q = 0; q < seg; ++q) run += s_seg[q][threadIdx.x & 63];
+    if (a < K) {
+        for (int c = c0; c < c1; ++c) {
+            const int v = counts[(int64_t)c * K + a];
+            counts[(int64_t)c * K + a] = run;
+            run += v;
+        }
+        if (seg == 15) totals[a] = run;
+    }
 }
 
 // row_ptr = exclusive scan of the K atom totals (single block, K <= 16384)
@@ -310,20 +390,6 @@ __global__ __launch_bounds__(1024) void csr_scan_totals_kernel(const int32_t* __
     if (t == 1023) row_ptr[K] = s_part[1023];
 }
 
-// counts[rows][T] -> exclusive scan inside every row (in place), row totals, and row_ptr[rows+1]; shared with the
-// block index of ksvd_block.hip
-int csr_scan(int32_t* counts, int rows, int T, int32_t* totals, int32_t* row_ptr, hipStream_t stream) {
-    if (rows > 16384 * 1024) {
-        set_error("csr_scan: %d rows", rows);
-        return LYS_ENOSUP;
-    }
-    hipLaunchKernelGGL(csr_scan_atoms_kernel, dim3(rows), dim3(256), 0, stream, counts, T, totals);
-    LYS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(csr_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, totals, rows, row_ptr);
-    LYS_LAUNCH_CHECK();
-    return LYS_OK;
-}
-
 // One wave walks a chunk of signals in order; the number of chunks T sets the parallelism of the build (the per-signal
 // work is a serial chain per wave), bounded by the K x T counter table (<= 64 MB).
 static void csr_plan(int64_t N, int K, int& T, int64_t& S) {
@@ -344,17 +410,18 @@ size_t csr_workspace_bytes(int K, int k, int64_t N) {
     return ((size_t)K * (size_t)T + (size_t)K) * sizeof(int32_t);
 }
 
-// emeta == nullptr: entry = signal*k + slot (per-atom kernels, online DL).  Otherwise (block sweep, k <= 64): entry =
-// signal id, ecoef = the entry's coefficient, emeta = slot | flags (see csr_count_or_fill_kernel), blocks of 2^logb atoms,
-// plus the coupled-leader index cg_ptr [nb * 2^B + 1] / cg_entry [<= N*k/2] keyed by (block << B) | in-block mask.
+// logb == 0: entry = int32 signal*k + slot (per-atom kernels, online DL).  logb = 2 / 3 (block sweep, k <= 64): `entry`
+// is an array of 16-byte records {signal, slot | flags, coefficient bits, 0} (see csr_count_or_fill_kernel), blocks of
+// 2^logb atoms, plus the coupled-leader index cg_ptr [nb * 2^B + 1] / cg_entry [<= N*k/2] keyed by (block << B) | mask.
 size_t csr_block_workspace_bytes(int K, int k, int64_t N, int B) {
     const size_t nkey = (size_t)((K + B - 1) / B) << B;
     return csr_workspace_bytes(K, k, N) + (nkey + 1) * sizeof(int32_t);
 }
 
 int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int32_t* row_ptr,
-                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int32_t* emeta, float* ecoef, int logb,
-                int32_t* cg_ptr, int32_t* cg_entry) {
+                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int logb, int32_t* cg_ptr,
+                int32_t* cg_entry) {
+    const bool emeta = logb != 0;  // block-sweep mode
     if (emeta && (k > 64 || !cg_ptr || !cg_entry || (logb != 2 && logb != 3))) {
         set_error("csr_by_atom: block-sweep index needs k <= 64, B in {4, 8} and the coupled-leader buffers (k = %d)", k);
         return LYS_ENOSUP;
@@ -382,11 +449,16 @@ int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K
     int32_t* cg_cur = emeta ? totals + K : nullptr;
     const size_t lds = (size_t)K * sizeof(int);
     if (emeta) LYS_CHECK_HIP(hipMemsetAsync(cg_cur, 0, (nkey + 1) * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(csr_count_or_fill_kernel, dim3(T), dim3(64), lds, stream, idx, coef, nnz, K, k, N, T, S, counts,
-                       row_ptr, entry, 0, (int32_t*)nullptr, (float*)nullptr, emeta ? logb : 0, cg_cur,
-                       (int32_t*)nullptr);
+    const bool quad = emeta && k <= 16;  // block-sweep index with four signals per wave instruction
+    if (quad)
+        hipLaunchKernelGGL(bksvd_index_kernel<false>, dim3(T), dim3(64), lds, stream, idx, coef, K, k, N, T, S, counts,
+                           row_ptr, reinterpret_cast<int4*>(entry), logb, cg_cur, cg_entry);
+    else
+        hipLaunchKernelGGL(csr_count_or_fill_kernel, dim3(T), dim3(64), lds, stream, idx, coef, nnz, K, k, N, T, S,
+                           counts, row_ptr, entry, 0, (int32_t*)nullptr, (float*)nullptr, emeta ? logb : 0, cg_cur,
+                           (int32_t*)nullptr);
     LYS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(csr_scan_atoms_kernel, dim3(K), dim3(256), 0, stream, counts, T, totals);
+    hipLaunchKernelGGL(csr_scan_chunks_kernel, dim3((K + 63) / 64), dim3(1024), 0, stream, counts, T, K, totals);
     LYS_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, totals, K, row_ptr);
     LYS_LAUNCH_CHECK();
@@ -395,8 +467,13 @@ int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K
         LYS_LAUNCH_CHECK();
         LYS_CHECK_HIP(hipMemcpyAsync(cg_cur, cg_ptr, (nkey + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
     }
-    hipLaunchKernelGGL(csr_count_or_fill_kernel, dim3(T), dim3(64), lds, stream, idx, coef, nnz, K, k, N, T, S, counts,
-                       row_ptr, entry, emeta ? 2 : 1, emeta, ecoef, emeta ? logb : 0, cg_cur, cg_entry);
+    if (quad)
+        hipLaunchKernelGGL(bksvd_index_kernel<true>, dim3(T), dim3(64), lds, stream, idx, coef, K, k, N, T, S, counts,
+                           row_ptr, reinterpret_cast<int4*>(entry), logb, cg_cur, cg_entry);
+    else
+        hipLaunchKernelGGL(csr_count_or_fill_kernel, dim3(T), dim3(64), lds, stream, idx, coef, nnz, K, k, N, T, S,
+                           counts, row_ptr, entry, emeta ? 2 : 1, (int32_t*)nullptr, (float*)nullptr, emeta ? logb : 0,
+                           cg_cur, cg_entry);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }

@@ -359,9 +359,7 @@ template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
 __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c, int nb, int K, float* __restrict__ R,
                                                                 int64_t ldr, int n, int k,
                                                                 const int32_t* __restrict__ row_ptr,
-                                                                const int32_t* __restrict__ entry,
-                                                                const int32_t* __restrict__ emeta,
-                                                                const float* __restrict__ ecoef,
+                                                                const int4* __restrict__ erec,
                                                                 const int32_t* __restrict__ cg_ptr,
                                                                 const int32_t* __restrict__ cg_entry,
                                                                 const int32_t* __restrict__ idx,
@@ -729,9 +727,10 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
             const int e0 = tbeg + bo;
             if (e0 < tend) {  // uniform per team
                 const int ei = (e0 + q < tend) ? e0 + q : tend - 1;  // lanes past the chunk repeat its last entry
-                const int ent = entry[ei];
-                const int emt = emeta[ei];
-                const float ecf = ecoef[ei];
+                const int4 rec = erec[ei];                           // {signal, slot | flags, coefficient bits, 0}
+                const int ent = rec.x;
+                const int emt = rec.y;
+                const float ecf = __builtin_bit_cast(float, rec.z);
                 const int left = __builtin_amdgcn_readfirstlane(tend - e0);  // team 0 of a wave: longest remainder
 #pragma unroll
                 for (int j0 = 0; j0 < 16; j0 += U)
@@ -886,9 +885,7 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
 // ---------------------------------------------------------------------------------------------
 struct BkIndex {
     const int32_t* row_ptr;
-    const int32_t* entry;
-    const int32_t* emeta;
-    const float* ecoef;
+    const int4* erec;
     const int32_t* cg_ptr;
     const int32_t* cg_entry;
 };
@@ -921,8 +918,8 @@ static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ld
     }
     const int grid = (mode == 0 && c >= nb) ? 1 : BK_WBLOCKS + (narrow ? 1 : 0);
     hipLaunchKernelGGL((bksvd_step_kernel<FB, LOGB, SL, TEAMS, FULL>), dim3(grid), dim3(16 * TEAMS), lds, stream, mode,
-                       c, nb, K, R, ldr, n, k, ix.row_ptr, ix.entry, ix.emeta, ix.ecoef, ix.cg_ptr, ix.cg_entry, idx, coef, D,
-                       Dnext, padded_features(n), bbuf, lay);
+                       c, nb, K, R, ldr, n, k, ix.row_ptr, ix.erec, ix.cg_ptr, ix.cg_entry, idx, coef, D, Dnext,
+                       padded_features(n), bbuf, lay);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -942,11 +939,10 @@ static int launch_step(int sl, int mode, int c, int nb, int K, float* R, int64_t
 }
 
 // One half step: mode 0 = X(c), c in [0, nb]; mode 1 = Y(c), c in [1, nb] (see the header of this file).
-// row_ptr / entry / emeta / ecoef: lys_bksvd_index.
+// row_ptr / erec (16-byte entry records) / cg_ptr / cg_entry: lys_bksvd_index.
 int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr,
-               const int32_t* entry, const int32_t* emeta, const float* ecoef, const int32_t* cg_ptr,
-               const int32_t* cg_entry, const int32_t* idx, float* coef, const float* D, float* Dnext, double* bbuf,
-               hipStream_t stream) {
+               const void* erec, const int32_t* cg_ptr, const int32_t* cg_entry, const int32_t* idx, float* coef,
+               const float* D, float* Dnext, double* bbuf, hipStream_t stream) {
     if (n > 256 || k > 64 || (B != 4 && B != 8) || (B == 8 && n > 128)) {
         set_error("bksvd_step: unsupported shape n=%d k=%d B=%d", n, k, B);
         return LYS_ENOSUP;
@@ -956,7 +952,7 @@ int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int 
         set_error("bksvd_step: mode %d, block %d of %d", mode, c, nb);
         return LYS_EINVAL;
     }
-    const BkIndex ix{row_ptr, entry, emeta, ecoef, cg_ptr, cg_entry};
+    const BkIndex ix{row_ptr, static_cast<const int4*>(erec), cg_ptr, cg_entry};
     const BkLayout lay = bk_layout(n, B);
     const int sl = (k <= 16) ? 1 : (k <= 32) ? 2 : 4;
     const int fb = (n <= 64) ? 1 : (n <= 128) ? 2 : 4;
@@ -978,14 +974,13 @@ size_t bksvd_stats_doubles(int n, int K, int B) {
 }
 
 int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int32_t* row_ptr,
-                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int32_t* emeta, float* ecoef, int logb,
-                int32_t* cg_ptr, int32_t* cg_entry);  // ksvd.hip
+                int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int logb, int32_t* cg_ptr,
+                int32_t* cg_entry);  // ksvd.hip
 
 // One full cycle on one GPU: index, 2 K/B + 1 launches, D <- D_next.  bbuf is zeroed here.
 int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
-                const int32_t* nnz, int B, int32_t* row_ptr, int32_t* entry, int32_t* emeta, float* ecoef,
-                int32_t* cg_ptr, int32_t* cg_entry, void* ws, size_t ws_bytes, double* bbuf, float* D, float* Dnext,
-                hipStream_t stream) {
+                const int32_t* nnz, int B, int32_t* row_ptr, void* erec, int32_t* cg_ptr, int32_t* cg_entry, void* ws,
+                size_t ws_bytes, double* bbuf, float* D, float* Dnext, hipStream_t stream) {
     if (k > 64 || (unsigned long long)N * (unsigned long long)ldr * 4ull >= (1ull << 32) ||
         (unsigned long long)N * (unsigned long long)k * 4ull >= (1ull << 32)) {
         set_error("bksvd_sweep: k = %d, N = %lld outside the block sweep's range", k, (long long)N);
@@ -995,16 +990,16 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
         set_error("bksvd_sweep: block size %d", B);
         return LYS_EINVAL;
     }
-    int rc = csr_by_atom(idx, coef, nnz, K, k, N, row_ptr, entry, ws, ws_bytes, stream, emeta, ecoef, B == 8 ? 3 : 2,
-                         cg_ptr, cg_entry);
+    int rc = csr_by_atom(idx, coef, nnz, K, k, N, row_ptr, static_cast<int32_t*>(erec), ws, ws_bytes, stream,
+                         B == 8 ? 3 : 2, cg_ptr, cg_entry);
     if (rc) return rc;
     LYS_CHECK_HIP(hipMemsetAsync(bbuf, 0, bksvd_stats_doubles(n, K, B) * sizeof(double), stream));
     const int nb = (K + B - 1) / B;
     for (int c = 0; c <= nb; ++c) {
-        rc = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, entry, emeta, ecoef, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
+        rc = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
         if (rc) return rc;
         if (c >= 1) {
-            rc = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, entry, emeta, ecoef, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
+            rc = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
             if (rc) return rc;
         }
     }

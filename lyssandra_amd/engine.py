@@ -411,8 +411,7 @@ class HipKsvdOps(object):
     def fused_step(self, a):
         """[pending update of atom a-1] + [accumulation for atom a] in one launch (a = K: only the last update)."""
         _lib.check(self.lib.lys_ksvd_fused_step(a, self.dd.K, _ptr(self.R), _ld(self.R), self.dd.n, self.k,
-                                                _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.emeta), _ptr(self.ecoef),
-                                           _ptr(self.idx), _ptr(self.coef),
+                                                _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.idx), _ptr(self.coef),
                                                 _ptr(self.sbuf), _ptr(self.dd.D), _ptr(self.Dnext), _stream()),
                    "lys_ksvd_fused_step")
 
@@ -462,15 +461,12 @@ class HipBlockKsvdOps(object):
         if buffers.get("bkey") != key:
             buffers["bkey"] = key
             buffers["brow_ptr"] = torch.empty((dd.K + 1,), dtype=torch.int32, device=dd.device)
-            buffers["bentry"] = torch.empty((max(1, self.N * self.k),), dtype=torch.int32, device=dd.device)
-            buffers["bemeta"] = torch.empty((max(1, self.N * self.k),), dtype=torch.int32, device=dd.device)
-            buffers["becoef"] = torch.empty((max(1, self.N * self.k),), dtype=torch.float32, device=dd.device)
+            buffers["berec"] = torch.empty((max(1, self.N * self.k), 4), dtype=torch.int32, device=dd.device)  # 16-B records
             buffers["bcg_ptr"] = torch.empty((self.nb * (1 << self.B) + 1,), dtype=torch.int32, device=dd.device)
             buffers["bcg_entry"] = torch.empty((self.N * self.k // 2 + 1,), dtype=torch.int32, device=dd.device)
             buffers["stats"] = torch.zeros((self.nb, self.stride), dtype=torch.float64, device=dd.device)
             buffers["bDnext"] = torch.zeros_like(dd.D)
-        self.row_ptr, self.entry = buffers["brow_ptr"], buffers["bentry"]
-        self.emeta, self.ecoef = buffers["bemeta"], buffers["becoef"]
+        self.row_ptr, self.erec = buffers["brow_ptr"], buffers["berec"]
         self.cg_ptr, self.cg_entry = buffers["bcg_ptr"], buffers["bcg_entry"]
         self.stats, self.Dnext = buffers["stats"], buffers["bDnext"]
         self.nnz = nnz
@@ -496,18 +492,18 @@ class HipBlockKsvdOps(object):
         dd = self.dd
         _lib.check(self.lib.lys_bksvd_sweep(_ptr(self.R), _ld(self.R), dd.n, dd.K, self.k, self.N, _ptr(self.idx),
                                             _ptr(self.coef), _ptr(self.nnz), self.B, _ptr(self.row_ptr),
-                                            _ptr(self.entry), _ptr(self.emeta), _ptr(self.ecoef), _ptr(self.cg_ptr),
-                                            _ptr(self.cg_entry), _ptr(self.ws), self.ws.numel(), _ptr(self.stats),
-                                            _ptr(dd.D), _ptr(self.Dnext), _stream()), "lys_bksvd_sweep")
+                                            _ptr(self.erec), _ptr(self.cg_ptr), _ptr(self.cg_entry), _ptr(self.ws),
+                                            self.ws.numel(), _ptr(self.stats), _ptr(dd.D), _ptr(self.Dnext),
+                                            _stream()), "lys_bksvd_sweep")
         dd.invalidate()
         return self.unused()
 
     # -- the `ops` interface of dist.ksvd_cycle_blocks
     def begin(self):
         _lib.check(self.lib.lys_bksvd_index(_ptr(self.idx), _ptr(self.coef), _ptr(self.nnz), self.dd.K, self.k, self.N,
-                                            self.B, _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.emeta),
-                                            _ptr(self.ecoef), _ptr(self.cg_ptr), _ptr(self.cg_entry), _ptr(self.ws),
-                                            self.ws.numel(), _stream()), "lys_bksvd_index")
+                                            self.B, _ptr(self.row_ptr), _ptr(self.erec), _ptr(self.cg_ptr),
+                                            _ptr(self.cg_entry), _ptr(self.ws), self.ws.numel(), _stream()),
+                   "lys_bksvd_index")
         self.stats.zero_()
 
     def step(self, mode, c):
@@ -515,8 +511,8 @@ class HipBlockKsvdOps(object):
         do not use block c-1; mode 1 = Y(c): block c-1 applied + the rest of block c's statistics."""
         dd = self.dd
         _lib.check(self.lib.lys_bksvd_step(mode, c, self.B, _ptr(self.R), _ld(self.R), dd.n, dd.K, self.k,
-                                           _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.emeta), _ptr(self.ecoef),
-                                           _ptr(self.cg_ptr), _ptr(self.cg_entry), _ptr(self.idx), _ptr(self.coef),
+                                           _ptr(self.row_ptr), _ptr(self.erec), _ptr(self.cg_ptr), _ptr(self.cg_entry),
+                                           _ptr(self.idx), _ptr(self.coef),
                                            _ptr(dd.D), _ptr(self.Dnext), _ptr(self.stats), _stream()), "lys_bksvd_step")
 
     def slab(self, c):

@@ -303,3 +303,26 @@ def test_lasso_lars_homotopy(eng, n, K, N, lam, unit):
         Zc = sparse_encoder(algorithm='lasso', params={'lambda': lam, 'solver': 'cd'}, verbose=False).encode(X, D)
         assert np.max(np.abs(Zl - Z)) == 0.0
         assert np.max(np.abs(Zc - Zl)) < 1e-4 * np.abs(Zl).max()
+
+
+def test_legacy_per_atom_sweep_still_matches(eng, monkeypatch):
+    """The one-launch-per-atom kernels of csrc/ksvd.hip (kept for n > 256 / k > 64 and as LYS_KSVD_LEGACY=1) against the
+    reference's F5 outputs, and against the block sweep on the same input."""
+    from conftest import load_golden
+    from lyssandra_amd.dict_learning.ksvd import approx_ksvd
+    g = load_golden("F5")
+    X = g["X"].astype(np.float64)
+    K = g["D0"].shape[1]
+    gi, gc, gn = g["it0_idx"], g["it0_coef_in"], g["it0_nnz"]
+    Zin = np.zeros((K, X.shape[1]))
+    for i in range(X.shape[1]):
+        Zin[gi[i, :gn[i]], i] = gc[i, :gn[i]]
+    res = {}
+    for legacy in ("1", "0"):
+        monkeypatch.setenv("LYS_KSVD_LEGACY", legacy)
+        D, Z = g["D0"].astype(np.float64).copy(), Zin.copy()
+        _, _, unused = approx_ksvd(X, D, Z, n_cycles=2, verbose=False)
+        assert _atom_err(D, g["cyc2_D"]) < 1e-5
+        res[legacy] = (D, Z, unused)
+    assert res["0"][2] == res["1"][2]
+    assert _atom_err(res["0"][0], res["1"][0]) < 1e-6 and np.max(np.abs(res["0"][1] - res["1"][1])) < 1e-5
