@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from lyssandra_amd import engine, _lib
-n, K, k, N = 64, 1024, 10, 1 << 20
+n, K, k, N = 64, 1024, 10, (int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20)
 g = torch.Generator(device="cuda").manual_seed(3)
 Xs = torch.randn((N, n), device="cuda", generator=g)
 dd = engine.DeviceDictionary(n, K)
