@@ -150,10 +150,10 @@ __host__ __device__ constexpr int bk_maxg(int B) { return ((1 << B) - 1 - B) < 6
 // ---------------------------------------------------------------------------------------------
 // The B sequential atom updates of block c on the aggregated statistics (one workgroup of NTH threads, fp64).
 // Everything is staged in LDS first (the slab was written by atomics: every access to it is a fabric round trip),
-// then the atom loop runs on 4 waves = 16 sixteen-lane teams and costs ONE barrier per atom: the teams evaluate the
-// atom's non-empty groups (Horner over the prefix set with 16-lane DPP dot products) into stot[t], barrier, and every
-// team normalises redundantly and writes the same d_new into LDS (no second barrier: a team only reads back what it
-// wrote itself).
+// then the atom loop runs on 4 waves = 16 sixteen-lane teams and costs at most ONE barrier per atom: the teams evaluate
+// the atom's non-empty groups (Horner over the prefix set with 16-lane DPP dot products) into stot[t], barrier, and
+// every team normalises redundantly and writes the same d_new into LDS (no second barrier: a team only reads back what
+// it wrote itself).
 // ---------------------------------------------------------------------------------------------
 template <int LOGB, int FB, int NTH>
 __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D, float* __restrict__ Dnext, int ldd,
@@ -162,29 +162,37 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     constexpr int G = (1 << B) - 1 - B;
     constexpr int NF = FB * 64;  // padded feature count of the LDS rows
     constexpr int MAXG = bk_maxg(B);
-    // sm: dold[B][NF], dnew[B][NF], S[B][n+2], stot[B][NF], QC[MAXG][NF+B]
+    // The slab holds fp64 sums (atomics of ~10^4 fp32 products each); everything after staging runs in fp32: d_new is an
+    // fp32 result, so fp32 rounding of the staged sums (6e-8) is the rounding d_new gets anyway, and fp32 buys fused DPP
+    // adds, one ds_read_b128 per four features and half the LDS traffic on the serial chain of B atoms.
+    // sm (as floats): dold[B][NF], dnew[B][NF], base[B][NF], stot[B][NF], QC[MAXG][NF+B]
     __shared__ short gslot[G > 0 ? G : 1];
     __shared__ short glist[G > 0 ? G : 1];  // non-empty groups in ascending order (grouped by target)
     __shared__ int gfirst[B + 1];           // first entry of glist per target
-    double* dold = sm;
-    double* dnew = dold + (size_t)B * NF;
-    double* S = dnew + (size_t)B * NF;
-    double* stot = S + (size_t)B * (n + 2);
-    double* QC = stot + (size_t)B * NF;
+    __shared__ float s_cnt[B];
+    float* fm = reinterpret_cast<float*>(sm);
+    float* dold = fm;
+    float* dnew = dold + (size_t)B * NF;
+    float* base = dnew + (size_t)B * NF;
+    float* stot = base + (size_t)B * NF;
+    float* QC = stot + (size_t)B * NF;
     const double* bb = bbuf + (int64_t)c * lay.stride;
     const int tid = threadIdx.x, lane = tid & 63, team = tid >> 4, q = tid & 15;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BK_NSTAMP(i) do { if (tid == 0) ts[i] = wall_clock64(); } while (0)
     BK_NSTAMP(0);
-    // round 1: atoms, per-atom statistics, group counts (all loads independent)
+    // round 1: atoms, per-atom statistics (base = S + d_old sum x^2, in fp64 before the conversion), group counts
     for (int i = tid; i < B * NF; i += NTH) {
         const int t = i / NF, f = i % NF, a = c * B + t;
-        const double v = (a < K && f < n) ? (double)D[(int64_t)a * ldd + f] : 0.0;
-        dold[i] = v;
-        dnew[i] = v;
-        stot[i] = 0.0;
+        const bool in = (a < K && f < n);
+        const double d0 = in ? (double)D[(int64_t)a * ldd + f] : 0.0;
+        const double sv = in ? bb[(int64_t)t * (n + 2) + f] + d0 * bb[(int64_t)t * (n + 2) + n] : 0.0;
+        dold[i] = (float)d0;
+        dnew[i] = (float)d0;
+        base[i] = (float)sv;
+        stot[i] = 0.f;
     }
-    for (int i = tid; i < B * (n + 2); i += NTH) S[i] = bb[i];
+    if (tid < B) s_cnt[tid] = (float)bb[(int64_t)tid * (n + 2) + n + 1];
     if (tid < 64) {  // wave 0: ordered compaction of the non-empty groups (all count loads first, then ballots)
         constexpr int NW = (G + 63) / 64;
         bool ne[NW];
@@ -194,15 +202,15 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
             ne[w] = (g < G) && (bb[lay.offGC + g] > 0.0);
         }
         unsigned long long bal[NW];
-        int base = 0;
+        int basep = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const int g = 64 * w + lane;
             bal[w] = __ballot(ne[w]);
-            const int pos = base + __popcll(bal[w] & ((1ull << lane) - 1ull));
+            const int pos = basep + __popcll(bal[w] & ((1ull << lane) - 1ull));
             if (g < G) gslot[g] = ne[w] ? (short)((pos < MAXG) ? pos : -2) : (short)-1;
             if (ne[w]) glist[pos] = (short)g;
-            base += __popcll(bal[w]);
+            basep += __popcll(bal[w]);
         }
         if (lane <= B) {  // groups are numbered target-major: first list entry of target t = #non-empty groups below g0(t)
             const int gstart = (lane < B) ? ((1 << lane) - 1 - lane) : G;
@@ -237,7 +245,7 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + r * NTH + tid;
-                if (i < total) QC[i] = v[r];
+                if (i < total) QC[i] = (float)v[r];
             }
         }
     }
@@ -250,85 +258,108 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     for (int t = 0; t < B; ++t) {
         const int a = c * B + t;
         if (a >= K) break;
-        const double cnt = S[t * (n + 2) + n + 1];
-        if (cnt == 0.0) continue;  // unused atom keeps its column (ksvd.py:112-115): dnew[t] == dold[t]; uniform
+        if (s_cnt[t] == 0.f) continue;  // unused atom keeps its column (ksvd.py:112-115): dnew[t] == dold[t]; uniform
         // groups with target t: team j evaluates list entries gfirst[t] + j, + NT, ..
-        for (int li = gfirst[t] + team; li < gfirst[t + 1]; li += NT) {
+        const int lbeg = gfirst[t], lend = gfirst[t + 1];
+        for (int li = lbeg + team; li < lend; li += NT) {
             const int g = glist[li];
             const int sl = gslot[g];
             const unsigned pi = (unsigned)(g - ((1 << t) - 1 - t)) + 1u;
-            double u[FB][4];
+            float4 u[FB];
             if (sl >= 0) {
-                const double* src = QC + (size_t)sl * (NF + B);
+                const float* src = QC + (size_t)sl * (NF + B);
 #pragma unroll
-                for (int b = 0; b < FB; ++b)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) u[b][e] = src[64 * b + 4 * q + e];
+                for (int b = 0; b < FB; ++b) u[b] = *reinterpret_cast<const float4*>(src + 64 * b + 4 * q);
             } else {
 #pragma unroll
-                for (int b = 0; b < FB; ++b)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int f = 64 * b + 4 * q + e;
-                        u[b][e] = (f < n) ? bb[lay.offQ + (int64_t)g * n + f] : 0.0;
-                    }
+                for (int b = 0; b < FB; ++b) {
+                    const int f = 64 * b + 4 * q;
+                    u[b].x = (f < n) ? (float)bb[lay.offQ + (int64_t)g * n + f] : 0.f;
+                    u[b].y = (f + 1 < n) ? (float)bb[lay.offQ + (int64_t)g * n + f + 1] : 0.f;
+                    u[b].z = (f + 2 < n) ? (float)bb[lay.offQ + (int64_t)g * n + f + 2] : 0.f;
+                    u[b].w = (f + 3 < n) ? (float)bb[lay.offQ + (int64_t)g * n + f + 3] : 0.f;
+                }
             }
             // Horner: u = P_l (u + c_l d_l^old), l ascending over the prefix set.  The loop runs over the SET bits (a
             // wave's four teams hold different prefix sets: a loop over all l < t would execute the body for the union)
             for (unsigned rest = pi; rest; rest &= rest - 1) {
                 const int l = __ffs(rest) - 1;
-                const double cl = (sl >= 0) ? QC[(size_t)sl * (NF + B) + NF + l] : bb[lay.offC + (int64_t)g * B + l];
-                double dot = 0.0;
+                const float cl = (sl >= 0) ? QC[(size_t)sl * (NF + B) + NF + l] : (float)bb[lay.offC + (int64_t)g * B + l];
+                float4 dn[FB];
+                float dot = 0.f;
 #pragma unroll
-                for (int b = 0; b < FB; ++b)
+                for (int b = 0; b < FB; ++b) {
+                    const float4 d0 = *reinterpret_cast<const float4*>(dold + l * NF + 64 * b + 4 * q);
+                    dn[b] = *reinterpret_cast<const float4*>(dnew + l * NF + 64 * b + 4 * q);
+                    u[b].x = fmaf(cl, d0.x, u[b].x);
+                    u[b].y = fmaf(cl, d0.y, u[b].y);
+                    u[b].z = fmaf(cl, d0.z, u[b].z);
+                    u[b].w = fmaf(cl, d0.w, u[b].w);
+                    dot = fmaf(u[b].x, dn[b].x, dot);
+                    dot = fmaf(u[b].y, dn[b].y, dot);
+                    dot = fmaf(u[b].z, dn[b].z, dot);
+                    dot = fmaf(u[b].w, dn[b].w, dot);
+                }
+                dot = bk_row16_sum(dot);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int f = 64 * b + 4 * q + e;
-                        u[b][e] = fma(cl, dold[l * NF + f], u[b][e]);
-                        dot = fma(u[b][e], dnew[l * NF + f], dot);
-                    }
-                dot = bk_row16_sum_d(dot);
-#pragma unroll
-                for (int b = 0; b < FB; ++b)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int f = 64 * b + 4 * q + e;
-                        u[b][e] = fma(-dnew[l * NF + f], dot, u[b][e]);
-                    }
+                for (int b = 0; b < FB; ++b) {
+                    u[b].x = fmaf(-dn[b].x, dot, u[b].x);
+                    u[b].y = fmaf(-dn[b].y, dot, u[b].y);
+                    u[b].z = fmaf(-dn[b].z, dot, u[b].z);
+                    u[b].w = fmaf(-dn[b].w, dot, u[b].w);
+                }
             }
+            // the result replaces the group's moments in its staged slot; the slots are summed below in LIST ORDER, so
+            // the narrow step is deterministic given the slab (replicas on several GPUs must stay bit-identical)
+            if (sl >= 0) {
+                float* dst = QC + (size_t)sl * (NF + B);
 #pragma unroll
-            for (int b = 0; b < FB; ++b)
+                for (int b = 0; b < FB; ++b) *reinterpret_cast<float4*>(dst + 64 * b + 4 * q) = u[b];
+            } else {  // group beyond the staging capacity (not seen in practice): unordered LDS atomics
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(&stot[t * NF + 64 * b + 4 * q + e], u[b][e]);
+                for (int b = 0; b < FB; ++b) {
+                    atomicAdd(&stot[t * NF + 64 * b + 4 * q + 0], u[b].x);
+                    atomicAdd(&stot[t * NF + 64 * b + 4 * q + 1], u[b].y);
+                    atomicAdd(&stot[t * NF + 64 * b + 4 * q + 2], u[b].z);
+                    atomicAdd(&stot[t * NF + 64 * b + 4 * q + 3], u[b].w);
+                }
+            }
         }
-        __syncthreads();  // waves 4.. have exited: the barrier counts the live waves only
-        // every team: s = S_t + d_old sum x^2 + groups, d_new = s / (||s|| + eps)
-        const double sqs = S[t * (n + 2) + n];
-        double sv[FB][4];
-        double v2 = 0.0;
+        if (lend > lbeg) __syncthreads();  // uniform; waves 4.. have exited: the barrier counts the live waves only
+        // every team: s = S_t + d_old sum x^2 + groups, d_new = s / (||s|| + eps)  (utils/math.py:61-62; eps only matters
+        // for s = 0, where the result is the zero vector either way)
+        float4 sv[FB];
+        float v2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const float4 b4 = *reinterpret_cast<const float4*>(base + t * NF + 64 * b + 4 * q);
+            float4 s4 = *reinterpret_cast<const float4*>(stot + t * NF + 64 * b + 4 * q);
+            // the list position IS the staging slot (both count the non-empty groups in ascending order): no indirection
+            const int lstop = (lend < MAXG) ? lend : MAXG;
+#pragma unroll 4
+            for (int li = lbeg; li < lstop; ++li) {
+                const float4 g4 = *reinterpret_cast<const float4*>(QC + (size_t)li * (NF + B) + 64 * b + 4 * q);
+                s4.x += g4.x;
+                s4.y += g4.y;
+                s4.z += g4.z;
+                s4.w += g4.w;
+            }
+            sv[b] = make_float4(b4.x + s4.x, b4.y + s4.y, b4.z + s4.z, b4.w + s4.w);
+            v2 = fmaf(sv[b].x, sv[b].x, v2);
+            v2 = fmaf(sv[b].y, sv[b].y, v2);
+            v2 = fmaf(sv[b].z, sv[b].z, v2);
+            v2 = fmaf(sv[b].w, sv[b].w, v2);
+        }
+        v2 = bk_row16_sum(v2);
+        float scale = 0.f;
+        if (v2 > 0.f) {
+            const float y = __builtin_amdgcn_rsqf(v2);
+            scale = y * fmaf(-0.5f * v2 * y, y, 1.5f);  // one Newton step on the 1-ulp hardware estimate
+        }
 #pragma unroll
         for (int b = 0; b < FB; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int f = 64 * b + 4 * q + e;
-                const double base = (f < n) ? S[t * (n + 2) + f] : 0.0;
-                sv[b][e] = base + dold[t * NF + f] * sqs + stot[t * NF + f];
-                v2 = fma(sv[b][e], sv[b][e], v2);
-            }
-        v2 = bk_row16_sum_d(v2);
-        // x / (||x|| + eps) (utils/math.py:61-62) with 1/||x|| from v_rsq_f64 + two Newton steps: every team does this
-        // redundantly, a full IEEE sqrt + divide costs several times more.  eps only matters for x = 0, where the
-        // result is the zero vector either way.
-        double scale = 0.0;
-        if (v2 > 0.0) {
-            double y = __builtin_amdgcn_rsq(v2);
-            y = y * fma(-0.5 * v2 * y, y, 1.5);
-            scale = y * fma(-0.5 * v2 * y, y, 1.5);
-        }
-#pragma unroll
-        for (int b = 0; b < FB; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dnew[t * NF + 64 * b + 4 * q + e] = sv[b][e] * scale;
+            *reinterpret_cast<float4*>(dnew + t * NF + 64 * b + 4 * q) =
+                make_float4(sv[b].x * scale, sv[b].y * scale, sv[b].z * scale, sv[b].w * scale);
         if (t == 0) BK_NSTAMP(3);
     }
     BK_NSTAMP(4);
@@ -337,7 +368,7 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     // (the fence of __syncthreads) on every atom's critical path
     for (int i = tid; i < B * ldd; i += 16 * NT) {
         const int t = i / ldd, f = i % ldd, a = c * B + t;
-        if (a < K) Dnext[(int64_t)a * ldd + f] = (f < n) ? (float)dnew[t * NF + f] : 0.f;
+        if (a < K) Dnext[(int64_t)a * ldd + f] = (f < n) ? dnew[t * NF + f] : 0.f;
     }
     BK_NSTAMP(5);
     if (tid == 0)
@@ -897,7 +928,8 @@ static size_t group_lds_bytes(int n, int B) {  // LDS slots of X(c)'s group phas
 
 static size_t narrow_lds_bytes(int n, int B) {
     const size_t nf = (size_t)((n + 63) / 64) * 64;
-    return ((size_t)3 * B * nf + (size_t)B * (n + 2) + (size_t)bk_maxg(B) * (nf + B)) * sizeof(double);
+    (void)n;
+    return ((size_t)4 * B * nf + (size_t)bk_maxg(B) * (nf + B)) * sizeof(float);
 }
 
 template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
