@@ -1020,17 +1020,27 @@ __device__ __forceinline__ double block_sum_d(double x, double* pr /* [256] */, 
 }
 
 // One workgroup (256 threads).  Dynamic LDS: Q[(EIG_M + 1) * n] doubles.
+// Tall mode (entry != nullptr; n > 256 features, |omega_a| <= 256): the matrix is the |omega| x |omega| Gram matrix of
+// the restricted residual's ROWS, the start vector the atom's current coefficients, the result v goes to `vout`.
 __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const int32_t* __restrict__ row_ptr,
                                                        const double* __restrict__ Cg, const float* __restrict__ D,
-                                                       int ldd, float* __restrict__ Dnext, int c_in_lds) {
+                                                       int ldd, float* __restrict__ Dnext, int c_in_lds,
+                                                       const int32_t* __restrict__ entry = nullptr,
+                                                       const float* __restrict__ coef = nullptr,
+                                                       float* __restrict__ vout = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double Q[];  // [EIG_M + 1][n], then (c_in_lds) a copy of C [n][n]
     __shared__ double H[EIG_M][EIG_M], T[EIG_M][EIG_M];
     __shared__ double hh[EIG_M + 1], red[16], wv[256], pr[256], cvec[EIG_M];
     __shared__ int m_used;
     if (row_ptr[atom] >= row_ptr[atom + 1]) return;
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const bool tall = entry != nullptr;
+    if (tall) {
+        n = row_ptr[atom + 1] - row_ptr[atom];
+        c_in_lds = n <= 64;
+    }
     // n <= 256: thread tid owns component tid of every n-vector
-    const double d0 = (tid < n) ? (double)D[(int64_t)atom * ldd + tid] : 0.0;
+    const double d0 = (tid < n) ? (tall ? (double)coef[entry[row_ptr[atom] + tid]] : (double)D[(int64_t)atom * ldd + tid]) : 0.0;
     for (int i = tid; i < EIG_M * EIG_M; i += 256) (&H[0][0])[i] = 0.0;
     double nrm2 = block_sum_d(d0 * d0, pr, red);
     {
@@ -1159,7 +1169,10 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
     const double sg = block_sum_d(u * d0, pr, red);
     if (un2 > 0.0) u *= (sg < 0.0 ? -1.0 : 1.0) / sqrt(un2);
     else u = d0;
-    if (tid < n) Dnext[(int64_t)atom * ldd + tid] = (float)u;
+    if (tid < n) {
+        if (tall) vout[tid] = (float)u;
+        else Dnext[(int64_t)atom * ldd + tid] = (float)u;
+    }
 }
 
 // x_i = rk_i . u (= sigma v_i), R_i = rk_i - u x_i with u = D_next[atom] (ksvd.py:36-40)
@@ -1220,17 +1233,212 @@ __global__ __launch_bounds__(256) void ksvd_exact_apply_kernel(int atom, float* 
     }
 }
 
-size_t ksvd_exact_work_doubles(int n) { return (size_t)n * n; }
+// ---- n > 256 ("tall": many features, few signals per atom -- the LC-KSVD shape, lc_ksvd.py:165 stacks [X; sqrt(a) Q;
+// sqrt(b) H] to n_features + K + n_classes rows).  The rank-1 SVD of Rk (n x m, m = |omega| <= 256) goes through the
+// m x m Gram matrix of its COLUMNS: M = Rk' Rk, leading eigenvector v (same Lanczos kernel), u = +-Rk v / ||Rk v|| with
+// u . d_old >= 0, x_i = rk_i . u.  Workspace: [s2, u_raw . d_old | pad(6) | M (256^2) | v (256 floats) | u_raw (n floats)].
+constexpr int TALL_MAX = 256;
+constexpr int TALL_FCH = 256;  // features per workgroup of the Gram kernel
+
+__global__ __launch_bounds__(256) void ksvd_gram_t_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                                          const int32_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ entry,
+                                                          const float* __restrict__ coef, const float* __restrict__ D,
+                                                          int ldd, double* __restrict__ M) {
+    __shared__ __attribute__((aligned(16))) float As[32][68];  // [feature of the tile][signal of the block]
+    __shared__ __attribute__((aligned(16))) float Bs[32][68];
+    const int beg = row_ptr[atom], m = row_ptr[atom + 1] - beg;
+    if (m <= 0) return;
+    const int mb = (m + 63) >> 6;
+    int bi = 0, bj = blockIdx.y;  // upper-triangular 64x64 blocks of M, enumerated for the largest m (4 x 4)
+    while (bj >= 4 - bi) {
+        bj -= 4 - bi;
+        ++bi;
+    }
+    bj += bi;
+    if (bj >= mb) return;
+    const int f0 = blockIdx.x * TALL_FCH, f1 = min(n, f0 + TALL_FCH);
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int lsig = tid >> 2, lf = (tid & 3) * 8;  // loader: signal lsig of the block, 8 consecutive features
+    const int ia = bi * 64 + lsig, ib = bj * 64 + lsig;
+    int64_t sa = -1, sb = -1;
+    float xa = 0.f, xb = 0.f;
+    if (ia < m) {
+        const int ss = entry[beg + ia];
+        sa = ss / k;
+        xa = coef[ss];
+    }
+    if (ib < m) {
+        const int ss = entry[beg + ib];
+        sb = ss / k;
+        xb = coef[ss];
+    }
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+    for (int ft = f0; ft < f1; ft += 32) {
+        float va[8], vb[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int f = ft + lf + c;
+            const float d = (f < f1) ? D[(int64_t)atom * ldd + f] : 0.f;
+            va[c] = (f < f1 && sa >= 0) ? fmaf(d, xa, R[sa * ldr + f]) : 0.f;
+            vb[c] = (f < f1 && sb >= 0) ? fmaf(d, xb, R[sb * ldr + f]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            As[lf + c][lsig] = va[c];
+            Bs[lf + c][lsig] = vb[c];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int fl = 0; fl < 32; ++fl) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[fl][4 * ty]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[fl][4 * tx]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = fmaf(av[a], bv[c], acc[a][c]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int r = bi * 64 + 4 * ty + a, cc = bj * 64 + 4 * tx + c;
+            if (r < m && cc < m) {
+                atomicAdd(M + (int64_t)r * m + cc, (double)acc[a][c]);
+                if (bi != bj) atomicAdd(M + (int64_t)cc * m + r, (double)acc[a][c]);
+            }
+        }
+}
+
+// u_raw = Rk v (one thread per feature), s2 += ||u_raw||^2
+__global__ __launch_bounds__(256) void ksvd_tall_u_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                                          const int32_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ entry,
+                                                          const float* __restrict__ coef, const float* __restrict__ D,
+                                                          int ldd, const float* __restrict__ v, float* __restrict__ uraw,
+                                                          double* __restrict__ s2) {
+    __shared__ int64_t sg[TALL_MAX];
+    __shared__ float xs[TALL_MAX], vs[TALL_MAX];
+    __shared__ double pr[256], red[16];
+    const int beg = row_ptr[atom], m = row_ptr[atom + 1] - beg;
+    if (m <= 0) return;
+    const int tid = threadIdx.x;
+    if (tid < m) {
+        const int ss = entry[beg + tid];
+        sg[tid] = (int64_t)(ss / k) * ldr;
+        xs[tid] = coef[ss];
+        vs[tid] = v[tid];
+    }
+    __syncthreads();
+    const int f = blockIdx.x * 256 + tid;
+    float u0 = 0.f, u1 = 0.f;
+    if (f < n) {
+        const float d = D[(int64_t)atom * ldd + f];
+        int i = 0;
+        for (; i + 1 < m; i += 2) {
+            u0 = fmaf(vs[i], fmaf(d, xs[i], R[sg[i] + f]), u0);
+            u1 = fmaf(vs[i + 1], fmaf(d, xs[i + 1], R[sg[i + 1] + f]), u1);
+        }
+        if (i < m) u0 = fmaf(vs[i], fmaf(d, xs[i], R[sg[i] + f]), u0);
+        u0 += u1;
+        uraw[f] = u0;
+        u1 = u0 * d;
+    }
+    const double tot = block_sum_d((double)u0 * (double)u0, pr, red);
+    const double sd = block_sum_d((f < n) ? (double)u1 : 0.0, pr, red);
+    if (tid == 0) {
+        atomicAdd(s2, tot);
+        atomicAdd(s2 + 1, sd);  // u_raw . d_old: fixes the sign like the short path (u . d_old >= 0)
+    }
+}
+
+// one workgroup per signal of omega: x_i = rk_i . u, R_i = rk_i - u x_i with u = u_raw / sqrt(s2); workgroup 0 also
+// writes the new atom
+__global__ __launch_bounds__(256) void ksvd_tall_apply_kernel(int atom, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                              const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ entry, float* __restrict__ coef,
+                                                              const float* __restrict__ D, int ldd,
+                                                              const float* __restrict__ uraw,
+                                                              const double* __restrict__ s2, float* __restrict__ Dnext) {
+    __shared__ double pr[256], red[16];
+    const int beg = row_ptr[atom], m = row_ptr[atom + 1] - beg;
+    const int i = blockIdx.x;
+    if (i >= m) return;
+    const int tid = threadIdx.x;
+    const int ss = entry[beg + i];
+    float* Ri = R + (int64_t)(ss / k) * ldr;
+    const float xo = coef[ss];
+    const double s2v = s2[0];
+    const float inv = (s2v > 0.0) ? (float)((s2[1] < 0.0 ? -1.0 : 1.0) / sqrt(s2v)) : 0.f;
+    const float* dold = D + (int64_t)atom * ldd;
+    double dot = 0.0;
+    for (int f = tid; f < n; f += 256) dot += (double)fmaf(dold[f], xo, Ri[f]) * (double)uraw[f];
+    const float xn = (float)(block_sum_d(dot, pr, red) * (double)inv);
+    const float g = xn * inv;
+    for (int f = tid; f < n; f += 256) Ri[f] = fmaf(-uraw[f], g, fmaf(dold[f], xo, Ri[f]));
+    if (tid == 0) coef[ss] = xn;
+    if (i == 0)
+        for (int f = tid; f < n; f += 256) Dnext[(int64_t)atom * ldd + f] = (s2v > 0.0) ? uraw[f] * inv : dold[f];
+}
+
+size_t ksvd_exact_work_doubles(int n) {
+    if (n <= 256) return (size_t)n * n;
+    return 8 + (size_t)TALL_MAX * TALL_MAX + TALL_MAX / 2 + ((size_t)n + 1) / 2 + 8;
+}
+
+static int ksvd_exact_sweep_tall(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
+                                 float* coef, double* work, float* D, float* Dnext, int64_t max_support,
+                                 hipStream_t stream) {
+    if (max_support > TALL_MAX) {
+        set_error("exact ksvd with n = %d > 256 features needs every atom to be used by <= %d signals (largest: %lld)", n,
+                  TALL_MAX, (long long)max_support);
+        return LYS_ENOSUP;
+    }
+    if (max_support <= 0) return LYS_OK;
+    const int ldd = padded_features(n);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    LYS_CHECK_HIP(hipGetDevice(&dev));
+    const size_t eig_lds = ((size_t)(EIG_M + 1) * TALL_MAX + 64 * 64) * sizeof(double);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ksvd_eig_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds));
+        attr_set[dev] = true;
+    }
+    double* s2 = work;
+    double* M = work + 8;
+    float* v = reinterpret_cast<float*>(M + (size_t)TALL_MAX * TALL_MAX);
+    float* uraw = v + TALL_MAX;
+    const int mb = (int)((max_support + 63) / 64);
+    const unsigned fchunks = (unsigned)((n + TALL_FCH - 1) / TALL_FCH);
+    for (int a = 0; a < K; ++a) {
+        LYS_CHECK_HIP(hipMemsetAsync(work, 0, (8 + (size_t)max_support * max_support) * sizeof(double), stream));
+        hipLaunchKernelGGL(ksvd_gram_t_kernel, dim3(fchunks, mb == 1 ? 1 : 10), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
+                           entry, coef, D, ldd, M);
+        hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, a, n, row_ptr, M, D, ldd, Dnext, 0, entry,
+                           coef, v);
+        hipLaunchKernelGGL(ksvd_tall_u_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, R, ldr, n, k,
+                           row_ptr, entry, coef, D, ldd, v, uraw, s2);
+        hipLaunchKernelGGL(ksvd_tall_apply_kernel, dim3((unsigned)max_support), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
+                           entry, coef, D, ldd, uraw, s2, Dnext);
+        LYS_LAUNCH_CHECK();
+    }
+    return ksvd_commit(n, K, row_ptr, Dnext, D, stream);
+}
 
 // One exact cycle on one GPU.  max_support: upper bound of |omega_a| over the atoms (sizes the Gram grid).
 int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
                      float* coef, double* work, float* D, float* Dnext, int64_t max_support, hipStream_t stream) {
+    if (n > 256) return ksvd_exact_sweep_tall(R, ldr, n, K, k, row_ptr, entry, coef, work, D, Dnext, max_support, stream);
     const int ldd = padded_features(n);
     const int fb = fb_of(n);
-    if (!fb) {
-        set_error("ksvd: n = %d > 256 not supported", n);
-        return LYS_ENOSUP;
-    }
     static bool attr_set[64] = {};
     int dev = 0;
     LYS_CHECK_HIP(hipGetDevice(&dev));
@@ -1238,7 +1446,8 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     const size_t eig_lds = ((size_t)(EIG_M + 1) * n + (c_in_lds ? (size_t)n * n : 0)) * sizeof(double);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ksvd_eig_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (EIG_M + 1) * 256 * (int)sizeof(double)));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          ((EIG_M + 1) * 256 + 64 * 64) * (int)sizeof(double)));
         attr_set[dev] = true;
     }
     const int nb = (n + 63) / 64;

@@ -366,10 +366,12 @@ def test_exact_ksvd_golden(eng):
     assert errs[2] < errs[1] < errs[0]
 
 
-@pytest.mark.parametrize("n,K,k,N", [(200, 48, 4, 700), (100, 40, 3, 300), (16, 24, 2, 30)])
+@pytest.mark.parametrize("n,K,k,N", [(200, 48, 4, 700), (100, 40, 3, 300), (16, 24, 2, 30),
+                                     (700, 60, 3, 400), (401, 12, 3, 600), (1030, 40, 4, 200)])
 def test_exact_ksvd_other_shapes(eng, n, K, k, N):
     """exact K-SVD at n = 100/200 (2 and 4 feature blocks per lane), ragged n, tiny omega (rank-deficient Rk) and
-    an unused atom, against the oracle's exact SVD."""
+    an unused atom, against the oracle's exact SVD.  n > 256 runs the "tall" path (Gram matrix of the restricted
+    residual's columns, |omega| <= 256: the LC-KSVD shape) -- 20, 160 (three 64-blocks) and 20 signals per atom."""
     from oracle import lyssa_oracle as orc
     from lyssandra_amd.dict_learning.ksvd import ksvd
     rs = np.random.RandomState(n + K)
@@ -392,6 +394,21 @@ def test_exact_ksvd_other_shapes(eng, n, K, k, N):
     assert np.array_equal(Dh[:, K - 1], D0[:, K - 1])
     assert _atom_err(Dh, Do) < 5e-5, _atom_err(Dh, Do)
     assert np.max(np.abs(Zh - Zo)) < 5e-5 * np.abs(Zo).max()
+
+
+def test_exact_ksvd_tall_limit(eng):
+    """n > 256 with an atom used by more than 256 signals is outside both exact paths: loud error, no fallback."""
+    from lyssandra_amd.dict_learning.ksvd import ksvd
+    from lyssandra_amd import _lib
+    rs = np.random.RandomState(5)
+    n, K, N = 300, 4, 600
+    D = rs.randn(n, K)
+    D /= np.linalg.norm(D, axis=0)
+    Z = np.zeros((K, N))
+    Z[0, :] = rs.randn(N)
+    Z[1, ::2] = rs.randn(N // 2)
+    with pytest.raises(_lib.LyssaHipError):
+        ksvd(rs.randn(n, N), D, Z, verbose=False)
 
 
 def _lasso_problem(seed, n, K, N, active=6, noise=0.05):
