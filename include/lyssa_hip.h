@@ -180,8 +180,11 @@ int lys_ksvd_atom_apply(int atom, float* R, int64_t ldr, int n, int k,
  * The reference calls sklearn's randomized_svd(n_iter=10, flip_sign=False) (random sign, not bit-reproducible);
  * here, per atom: C = Rk Rk' (n x n, fp64), its leading eigenvector u by Lanczos with full re-orthogonalisation
  * (<= 24 steps, started at d_old) + Rayleigh-Ritz, then x_omega = Rk'u; sign u . d_old >= 0.
- * work: lys_ksvd_exact_workspace_bytes(n).  max_support >= max_a |omega_a| (N is always valid).  Unused atoms keep
- * their column.  Single GPU.
+ * n > 256 (the LC-KSVD stack [X; sqrt(alpha) Q; sqrt(beta) H], lyssa/dict_learning/lc_ksvd.py:140-172: many features,
+ * few signals per atom): the same eigen-solve on the |omega| x |omega| Gram matrix Rk'Rk of the COLUMNS, u = Rk v /
+ * ||Rk v||; needs max_support <= 256 there (LYS_ENOSUP otherwise -- no fallback).
+ * work: lys_ksvd_exact_workspace_bytes(n).  max_support >= max_a |omega_a| (N is always valid for n <= 256; for n > 256
+ * pass the true maximum).  Unused atoms keep their column.  Single GPU.
  */
 size_t lys_ksvd_exact_workspace_bytes(int n);
 int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k,

@@ -30,18 +30,33 @@ def pyramid_cells(pos, patch_size, imsize, levels=(1, 2, 4)):
     return cells, off
 
 
+def pool_cells_device(idx, coef, nnz, n_atoms, cells, n_cells, normalize=False):
+    """max-|z| pooling of a device triplet into `n_cells` cells: cells [n_levels, N] int32 (host array or cuda tensor,
+    -1 = not pooled at that level) -> cuda tensor [n_cells, n_atoms] fp32; `normalize` = l2-normalise every cell row."""
+    torch = engine.require_gpu()
+    lib = _lib.load()
+    N, k = int(idx.shape[0]), int(idx.shape[1])
+    cd = cells if isinstance(cells, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(cells))
+    cd = cd.to(device=idx.device, dtype=torch.int32).contiguous()
+    assert cd.shape[1] == N
+    out = torch.empty((n_cells, n_atoms), dtype=torch.float32, device=idx.device)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(lib.lys_pool_max_abs(P(idx), P(coef), P(nnz), k, N, P(cd), int(cd.shape[0]), n_atoms, n_cells, P(out),
+                                    int(bool(normalize)), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "lys_pool_max_abs")
+    return out
+
+
 def spatial_pyramid_pool(idx, coef, nnz, n_atoms, pos, patch_size, imsize, levels=(1, 2, 4), normalize=False):
     """Device triplet of ONE image's patches -> flattened pyramid feature (n_cells * n_atoms,) float64,
     i.e. `poolpatches.flatten()` of spatial_pyramid.py:96."""
-    torch = engine.require_gpu()
-    lib = _lib.load()
     cells, n_cells = pyramid_cells(pos, patch_size, imsize, levels)
-    N, k = int(idx.shape[0]), int(idx.shape[1])
-    assert cells.shape[1] == N
-    cd = torch.from_numpy(np.ascontiguousarray(cells)).to(idx.device)
-    out = torch.empty((n_cells, n_atoms), dtype=torch.float32, device=idx.device)
-    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-    _lib.check(lib.lys_pool_max_abs(P(idx), P(coef), P(nnz), k, N, P(cd), len(levels), n_atoms, n_cells, P(out),
-                                    int(bool(normalize)), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-               "lys_pool_max_abs")
-    return out.double().cpu().numpy().reshape(-1)
+    return pool_cells_device(idx, coef, nnz, n_atoms, cells, n_cells, normalize).double().cpu().numpy().reshape(-1)
+
+
+class sc_max_pooling(object):
+    """lyssa/feature_extract/pooling.py:4-7 (host callable kept for API parity; `sc_spm_extractor` recognises it and
+    pools on the device instead)."""
+
+    def __call__(self, Z):
+        return np.max(np.abs(Z), axis=1)

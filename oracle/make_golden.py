@@ -100,6 +100,122 @@ def make_f12():
     print("F12: omp(tol) nnz", [(k, int((v != 0).sum(0).max())) for k, v in out.items() if k.startswith("omp_") and k.endswith("_Z")])
 
 
+def make_f13():
+    """Config 5 in miniature, from the reference itself: ScSPM features of synthetic textured images through
+    `sc_spm_extractor.encode` with the real 'bomp' encoder, then `lc_ksvd` / `lc_ksvd_predict` on those features (stacked
+    dimension 672 + 12 + 4: the many-features / few-signals regime), and a second LC-KSVD problem with a small stack."""
+    load_reference()
+    from lyssa.sparse_coding import sparse_encoder
+    from lyssa.feature_extract.spatial_pyramid import sc_spm_extractor
+    from lyssa.feature_extract.pooling import sc_max_pooling
+    from lyssa.feature_extract.preproc import l2_normalizer
+    from lyssa.utils.img import grid_patches as ref_grid_patches
+    from lyssa.dict_learning.lc_ksvd import lc_ksvd as ref_lc_ksvd, lc_ksvd_predict as ref_predict
+    os.makedirs(OUT, exist_ok=True)
+    rs = np.random.RandomState(1313)
+    n_classes, per_class, H, W, ps, step, K = 4, 12, 32, 36, 8, 4, 32
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    imgs, labels = [], []
+    for c in range(n_classes):
+        ang = np.pi * c / n_classes
+        for _ in range(per_class):
+            freq, phase = 0.55 + 0.1 * rs.rand(), 2 * np.pi * rs.rand()
+            g = np.sin(freq * (np.cos(ang) * xx + np.sin(ang) * yy) + phase)
+            if c % 2:
+                g = g * (yy < H // 2) + 0.3 * rs.randn(H, W) * (yy >= H // 2)      # class-dependent layout for the pyramid
+            imgs.append(f32(g + 0.15 * rs.randn(H, W)))
+            labels.append(c)
+    labels = np.array(labels)
+    D = make_dict(rs, ps * ps, K)
+
+    class grid_extractor(object):      # the reference's own patch_extractor cannot run (grid_patches returns one value)
+        patch_size = ps
+
+        def extract(self, img):
+            n_h, n_w = (img.shape[0] - ps) // step + 1, (img.shape[1] - ps) // step + 1
+            ys, xs = np.meshgrid(np.arange(n_h) * step, np.arange(n_w) * step, indexing='ij')
+            return ref_grid_patches(img, patch_size=ps, step_size=step), np.stack([ys.ravel(), xs.ravel()], axis=1)
+
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 3}, n_jobs=1, verbose=False)
+    ex = sc_spm_extractor(feature_extractor=grid_extractor(), levels=(1, 2, 4), sparse_coder=se,
+                          pooling_operator=sc_max_pooling(), normalizer=l2_normalizer())
+    F = quiet(ex.encode, imgs, D)
+    out = dict(imgs=np.array(imgs, dtype=np.float32), labels=labels, D_patch=D.astype(np.float32), patch_size=ps,
+               step_size=step, features=F)
+    print("F13 ScSPM features", F.shape, "non-zero fraction %.3f" % (F != 0).mean())
+
+    # conditioning of every rank-1 problem the reference solves (sigma_2 / sigma_1 of Rk): LC-KSVD's label blocks make
+    # EXACTLY degenerate leading singular values easy to hit (an atom shared by two classes with equal counts), where
+    # the leading singular vector -- the reference's as well -- is decided by rounding.  Recorded so that the fixture can
+    # be chosen well-posed and the test can say how well-posed it is.
+    import lyssa.dict_learning.ksvd as ref_ksvd_mod
+    # Also recorded: the smallest norm of the D part of a new stacked atom.  When the leading singular vector lives in the
+    # label rows alone (sigma = a pure label-block value), the D part is ~1e-8 and `lc_ksvd` normalises rounding noise
+    # into a unit "atom" (lc_ksvd.py:180-183) -- not something any implementation can reproduce.
+    ratios, top_norms, n_top = [], [], [0]
+    inner_svd = ref_ksvd_mod.randomized_svd
+
+    def recording_svd(Rk, **kw):
+        U, sv, _ = np.linalg.svd(Rk, full_matrices=False)
+        ratios.append(sv[1] / sv[0] if sv.size > 1 and sv[0] > 0 else 0.0)
+        top_norms.append(np.linalg.norm(U[:n_top[0], 0]))
+        return inner_svd(Rk, **kw)
+
+    ref_ksvd_mod.randomized_svd = recording_svd
+
+    def run_lc(tag, X, y, n_class_atoms, k, alpha, beta, max_iter, train, test):
+        del ratios[:], top_norms[:]
+        n_top[0] = X.shape[0]
+        Xtr, ytr = X[:, train], y[train]
+        np.random.seed(77)
+        D0 = np.zeros((X.shape[0], n_class_atoms * n_classes))
+        for c in range(n_classes):
+            # sums of two training samples: an atom that IS a training sample makes that sample exactly representable,
+            # and the reference then fills its remaining k-1 slots from float64 rounding noise (SURVEY appendix A)
+            cols = np.flatnonzero(ytr == c)[:2 * n_class_atoms]
+            D0[:, c * n_class_atoms:(c + 1) * n_class_atoms] = Xtr[:, cols[0::2]] + Xtr[:, cols[1::2]]
+        D0 = f32(D0 / np.linalg.norm(D0, axis=0))
+        Q = np.zeros((D0.shape[1], Xtr.shape[1]))
+        for c in range(n_classes):
+            Q[c * n_class_atoms:(c + 1) * n_class_atoms, ytr == c] = 1
+        coder = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, n_jobs=1, verbose=False)
+        for it in range(1, max_iter + 1):
+            np.random.seed(500 + it)
+            Dl, Zl, Wl = quiet(ref_lc_ksvd, Xtr, ytr, D0.copy(), Q, alpha=alpha, beta=beta, sparse_coder=coder, max_iter=it)
+            out["%s_it%d_D" % (tag, it)], out["%s_it%d_Z" % (tag, it)], out["%s_it%d_W" % (tag, it)] = Dl, Zl, Wl
+        pred = np.array(quiet(ref_predict, X[:, test], Dl, Wl, coder))
+        out[tag + "_max_sv_ratio"] = max(ratios)
+        out[tag + "_min_top_norm"] = min(top_norms)
+        print("F13", tag, "largest sigma2/sigma1 over all atom updates: %.4f, smallest D-part norm %.3g" % (max(ratios), min(top_norms)))
+        out.update({tag + "_D0": D0, tag + "_train": train, tag + "_test": test, tag + "_pred": pred, tag + "_k": k,
+                    tag + "_alpha": alpha, tag + "_beta": beta, tag + "_n_class_atoms": n_class_atoms})
+        print("F13", tag, "stack", X.shape[0] + D0.shape[1] + n_classes, "test accuracy", (pred == y[test]).mean())
+
+    n_train = (9, 8, 7, 6)     # unequal class sizes: equal per-class counts in an atom's support are what makes sigma_1 = sigma_2
+    train = np.concatenate([np.flatnonzero(labels == c)[:n_train[c]] for c in range(n_classes)])
+    test = np.concatenate([np.flatnonzero(labels == c)[n_train[c]:] for c in range(n_classes)])
+    Fn = F / np.linalg.norm(F, axis=0)
+    out["features_normed"] = Fn
+    run_lc("spm", Fn, labels, 3, 3, 0.2, 0.1, 3, train, test)
+    # small stack (40 + 16 + 4 rows): class-structured random data
+    n, per = 40, 30
+    base = rs.randn(n, n_classes, 5)
+    Xs, ys = [], []
+    for c in range(n_classes):
+        for _ in range(per):
+            Xs.append(base[:, c, :] @ rs.randn(5) + 0.2 * rs.randn(n))
+            ys.append(c)
+    Xs = f32(np.array(Xs).T)
+    Xs = f32(Xs / np.linalg.norm(Xs, axis=0))
+    ys = np.array(ys)
+    out["small_X"], out["small_y"] = Xs, ys
+    tr = np.concatenate([np.flatnonzero(ys == c)[:20] for c in range(n_classes)])
+    te = np.concatenate([np.flatnonzero(ys == c)[20:] for c in range(n_classes)])
+    run_lc("small", Xs, ys, 4, 3, 1.0, 1.0, 2, tr, te)
+    ref_ksvd_mod.randomized_svd = inner_svd
+    np.savez_compressed(os.path.join(OUT, "F13.npz"), **out)
+
+
 def main():
     lyssa = load_reference()
     from lyssa.sparse_coding import sparse_encoder
@@ -390,6 +506,9 @@ def main():
 if __name__ == "__main__":
     if sys.argv[1:] == ["F12"]:
         make_f12()
+    elif sys.argv[1:] == ["F13"]:
+        make_f13()
     else:
         main()
         make_f12()
+        make_f13()

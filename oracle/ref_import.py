@@ -21,6 +21,7 @@ What it does:
        - ``if init_dict == 'data'`` with an ndarray argument -> isinstance guard
        - ``type(data) is np.core.memmap`` -> ``np.memmap`` (numpy 2 removed np.core alias warning)
        - ``img[slices]`` with a LIST of slices (utils/img.py:462) -> ``img[tuple(slices)]`` (numpy >= 1.23)
+       - ``sklearn.grid_search`` / ``sklearn.cross_validation`` imports of classify.py -> ``sklearn.model_selection``
      None of them changes the arithmetic of the hot path.
   4. points HOME at the temp dir (import-time side effects create ``~/lyssa_files``),
   5. imports the converted package and returns the module.
@@ -85,6 +86,12 @@ def load_reference():
              r"\1w = float(g[0])\n\2v = w * w\n", True)])
     _patch(os.path.join(dst, "dict_learning", "ksvd.py"),
            [(r"if init_dict == 'data':", "if isinstance(init_dict, str) and init_dict == 'data':", True)])
+    # sklearn >= 0.20 moved ParameterGrid / StratifiedKFold (needed only so that `lyssa.classify`, and with it
+    # `lyssa.dict_learning.lc_ksvd`, import; the fixtures call `lc_ksvd` / `lc_ksvd_predict` directly)
+    _patch(os.path.join(dst, "classify.py"),
+           [(r"from sklearn\.grid_search import ParameterGrid", "from sklearn.model_selection import ParameterGrid", True),
+            (r"from sklearn\.cross_validation import StratifiedKFold", "from sklearn.model_selection import StratifiedKFold",
+             True)])
     # config.yml points at non-existent paths; keep 'paths' inside the temp dir
     with open(os.path.join(tmp, "config.yml"), "w") as f:
         f.write("paths:\n  - %s\n" % os.path.join(tmp, "workspaces"))

@@ -11,6 +11,8 @@
 import numpy as np
 import pytest
 
+from conftest import load_golden  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -326,3 +328,97 @@ def test_legacy_per_atom_sweep_still_matches(eng, monkeypatch):
         res[legacy] = (D, Z, unused)
     assert res["0"][2] == res["1"][2]
     assert _atom_err(res["0"][0], res["1"][0]) < 1e-6 and np.max(np.abs(res["0"][1] - res["1"][1])) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def test_scspm_pipeline_golden(eng):
+    """ScSPM features (spatial_pyramid.py:45-97) of 40 synthetic images through the device pipeline patches -> bomp ->
+    pyramid max-|z| pooling -> l2 per cell, against the reference's own `sc_spm_extractor.encode` with its real 'bomp'
+    encoder (F13)."""
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    from lyssandra_amd.feature_extract.spatial_pyramid import patch_extractor, sc_spm_extractor, spatial_pyramid
+    from lyssandra_amd.feature_extract.pooling import sc_max_pooling
+    from lyssandra_amd.feature_extract.preproc import l2_normalizer
+    g = load_golden("F13")
+    imgs = [im for im in g["imgs"]]
+    D = g["D_patch"].astype(np.float64)
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 3}, verbose=False)
+    ex = sc_spm_extractor(feature_extractor=patch_extractor(step_size=int(g["step_size"]), patch_size=int(g["patch_size"])),
+                          levels=(1, 2, 4), sparse_coder=se, pooling_operator=sc_max_pooling(), normalizer=l2_normalizer())
+    F = ex.encode(imgs, D)
+    assert F.shape == g["features"].shape and F.dtype == np.float64
+    assert np.array_equal(F != 0, g["features"] != 0)
+    assert np.max(np.abs(F - g["features"])) < 2e-5
+    # chunked (one image per launch sequence) == batched, and the `spatial_pyramid` front door
+    import lyssandra_amd.feature_extract.spatial_pyramid as sp
+    old = sp._CHUNK_PATCHES
+    try:
+        sp._CHUNK_PATCHES = 1
+        sp_obj = spatial_pyramid()
+        sp_obj.D = D
+        F1 = sp_obj.extract(imgs[:5], pyramid_feat_extractor=ex)
+    finally:
+        sp._CHUNK_PATCHES = old
+    assert np.array_equal(F1, F[:, :5])
+    # the host-array form of the extractor agrees with the reference's grid (positions row-major, top-left corners)
+    P, pos = ex.feature_extractor.extract(imgs[0])
+    assert P.shape == (64, 7 * 8) and pos[1].tolist() == [0, 4] and pos[8].tolist() == [4, 0]
+
+
+@pytest.mark.parametrize("tag,iters", [("spm", 3), ("small", 2)])
+def test_lc_ksvd_golden(eng, tag, iters):
+    """lc_ksvd.py:105-216 against the reference's own run (F13): D, W and the codes after 1..iters iterations up to the
+    sign of each stacked atom (the reference's randomized SVD leaves it arbitrary), identical test predictions.
+    'spm': ScSPM features, stack of 672 + 12 + 4 rows (exact K-SVD through the column-Gram path); 'small': 40 + 16 + 4."""
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    from lyssandra_amd.dict_learning.lc_ksvd import lc_ksvd, lc_ksvd_predict
+    g = load_golden("F13")
+    X = g["features_normed"] if tag == "spm" else g["small_X"]
+    y = g["labels"] if tag == "spm" else g["small_y"]
+    train, test = g[tag + "_train"], g[tag + "_test"]
+    nca, k = int(g[tag + "_n_class_atoms"]), int(g[tag + "_k"])
+    alpha, beta = float(g[tag + "_alpha"]), float(g[tag + "_beta"])
+    Xtr, ytr = X[:, train], y[train]
+    n_classes = len(set(y.tolist()))
+    Q = np.zeros((nca * n_classes, Xtr.shape[1]))
+    for c in range(n_classes):
+        Q[c * nca:(c + 1) * nca, ytr == c] = 1
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    # the rank-1 problems are only as well posed as their singular gap: F13 records the largest sigma_2 / sigma_1 the
+    # reference met (LC-KSVD's label blocks produce near-degenerate pairs); fp32 error is amplified by 1 / (1 - ratio)
+    # and by 1 / ||D part|| when lc_ksvd renormalises the stacked atom (lc_ksvd.py:180-183); also recorded
+    tol = max(5e-5, 2e-6 / (1.0 - float(g[tag + "_max_sv_ratio"])) / float(g[tag + "_min_top_norm"]))
+    for it in range(1, iters + 1):
+        D, Z, W = lc_ksvd(Xtr, ytr, g[tag + "_D0"].copy(), Q, alpha=alpha, beta=beta, sparse_coder=se, max_iter=it)
+        Dr, Zr, Wr = g["%s_it%d_D" % (tag, it)], g["%s_it%d_Z" % (tag, it)], g["%s_it%d_W" % (tag, it)]
+        sgn = np.sign(np.sum(D * Dr, axis=0))
+        sgn[sgn == 0] = 1
+        assert np.array_equal(Z != 0, Zr != 0), it
+        assert _atom_err(D, Dr * sgn) < tol, (it, _atom_err(D, Dr * sgn), tol)
+        assert np.max(np.abs(W - Wr * sgn)) < tol * max(1.0, np.abs(Wr).max()), it
+        assert np.max(np.abs(Z - Zr * sgn[:, None])) < tol * np.abs(Zr).max(), it
+    pred = lc_ksvd_predict(X[:, test], D, W, se)
+    assert np.array_equal(np.array(pred), g[tag + "_pred"])
+
+
+def test_lc_ksvd_classifier_end_to_end(eng):
+    """Config 5 front to back on the device: images -> ScSPM features -> lc_ksvd_classifier (split with the global RNG,
+    dictionary initialised from the class data, LC-KSVD, predict).  Separable synthetic classes: accuracy well above
+    chance, and the run is reproducible from the seed."""
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    from lyssandra_amd.dict_learning.lc_ksvd import lc_ksvd_classifier
+    from lyssandra_amd.utils.math import norm_cols
+    g = load_golden("F13")
+    X = norm_cols(g["features"].copy())
+    y = g["labels"]
+    scores = []
+    for _ in range(2):
+        np.random.seed(5)
+        se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': 3}, verbose=False)
+        lc = lc_ksvd_classifier(sparse_coder=se, max_iter=3, n_class_samples=5, n_test_samples=4, n_tests=2,
+                                param_grid=[{'alpha': [1, 4], 'beta': [1]}])
+        lc(X, y)
+        assert lc.D.shape == (X.shape[0], 20) and lc.W.shape == (4, 20)
+        scores.append((lc.best_score, tuple(sorted(lc.best_param_set.items()))))
+    assert scores[0] == scores[1]
+    assert scores[0][0] > 0.7, scores
