@@ -73,6 +73,7 @@ int ksvd_fused_step(int, int, float*, int64_t, int, int, const int32_t*, const i
                     const float*, float*, hipStream_t, const int32_t* row_ptr_host = nullptr);
 int bksvd_default_block(int n);
 int bk_debug_timestamps(unsigned long long* out64);
+int exact_debug_stamps(unsigned long long* out16);
 size_t bksvd_stats_doubles(int n, int K, int B);
 struct BkLayout {
     int B, G, stride, offQ, offC, offGC;
@@ -524,7 +525,9 @@ int lys_bksvd_block_size(int n) { return bksvd_default_block(n); }
 
 int lys_debug_timestamps(uint64_t* out64) {
     LYS_REQUIRE(out64, "debug_timestamps: null pointer");
-    return bk_debug_timestamps(reinterpret_cast<unsigned long long*>(out64));
+    const int rc = bk_debug_timestamps(reinterpret_cast<unsigned long long*>(out64));
+    if (rc) return rc;
+    return exact_debug_stamps(reinterpret_cast<unsigned long long*>(out64) + 16);  // slots 16..31: exact K-SVD kernels
 }
 
 int lys_bksvd_layout(int n, int B, int32_t* out6) {

@@ -999,6 +999,93 @@ __global__ __launch_bounds__(256) void ksvd_gram_kernel(int atom, const float* _
         }
 }
 
+// phase timestamps (100 MHz wall clock) of the last exact-update launches (lys_debug_timestamps slots 16..31):
+// [0..7] eigen-solver (start, C loaded, Lanczos done, end, steps used), [8..15] workgroup 0 of the Gram kernel
+__device__ unsigned long long g_exact_stamp[16];
+int exact_debug_stamps(unsigned long long* out16) {
+    LYS_CHECK_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_exact_stamp), 16 * sizeof(unsigned long long)));
+    return LYS_OK;
+}
+
+// n <= 64: C = Rk Rk' on the matrix cores, without atomics.  Workgroup b of P owns a contiguous slice of the atom's
+// signals, stages 64 restricted-residual rows at a time in LDS (next round's rows prefetched into registers) and
+// accumulates the 64 x 64 product with v_mfma_f32_32x32x2_f32 (one 32 x 32 quadrant per wave); the fp32 partial goes to
+// part[b][64][64] with plain stores and the eigen-solver sums the P partials in fp64 while it loads C.
+constexpr int G64_MAX_PARTS = 64;
+constexpr int G64_ROWS = 768;  // most signals one workgroup takes (descriptor staging area)
+
+__global__ __launch_bounds__(256) void ksvd_gram64_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                                          const int32_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ entry,
+                                                          const float* __restrict__ coef, const float* __restrict__ D,
+                                                          int ldd, float* __restrict__ part) {
+    __shared__ float s_a[64][65];
+    __shared__ int64_t s_off[G64_ROWS];
+    __shared__ float s_x[G64_ROWS];
+    const int beg = row_ptr[atom], m = row_ptr[atom + 1] - beg;
+    if (m <= 0) return;
+    const int P = gridDim.x;
+    int chunk = (m + P - 1) / P;
+    chunk = ((chunk + 63) >> 6) << 6;
+    const int e0 = blockIdx.x * chunk, cnt = max(0, min(chunk, m - e0));
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ti = wid >> 1, tj = wid & 1;
+    const unsigned long long ts0 = wall_clock64();
+    using f16v = __attribute__((ext_vector_type(16))) float;
+    f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < cnt; i += 256) {
+        const int ss = entry[beg + e0 + i];
+        s_off[i] = (int64_t)(ss / k) * ldr;
+        s_x[i] = coef[ss];
+    }
+    const float d = (lane < n) ? D[(int64_t)atom * ldd + lane] : 0.f;
+    __syncthreads();
+    // wave w stages rows w, w + 4, .. of each 64-row round; lane = feature.  The prefetch holds RAW residual values
+    // (unconditional loads from clamped addresses: a select on the loaded value would make the compiler wait for every
+    // load in turn); x_i d is added and out-of-range rows / features are zeroed when the round is written to LDS.
+    float cur[16], nxt[16];
+    const int lf = min(lane, n - 1);
+    auto fetch = [&](int r0, float* v) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = R[s_off[min(r0 + wid + 4 * q, cnt - 1)] + lf];
+    };
+    unsigned long long ts1 = wall_clock64();
+    if (cnt > 0) fetch(0, cur);
+    for (int r0 = 0; r0 < cnt; r0 += 64) {
+        if (r0 + 64 < cnt) fetch(r0 + 64, nxt);
+        // LDS-only barriers: __syncthreads() would also wait for the prefetch loads just issued (vmcnt(0))
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the previous round's MFMAs have read s_a
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = r0 + wid + 4 * q;
+            s_a[wid + 4 * q][lane] = (i < cnt && lane < n) ? fmaf(d, s_x[min(i, cnt - 1)], cur[q]) : 0.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 8
+        for (int i = 0; i < 64; i += 2) {
+            const int kk = i + (lane >> 5);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_a[kk][32 * ti + (lane & 31)], s_a[kk][32 * tj + (lane & 31)], acc,
+                                                       0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
+    }
+    const unsigned long long ts2 = wall_clock64();
+    float* out = part + (int64_t)blockIdx.x * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3), col = lane & 31;
+        out[(32 * ti + row) * 64 + 32 * tj + col] = acc[r];
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        g_exact_stamp[8] = ts0;
+        g_exact_stamp[9] = ts1;
+        g_exact_stamp[10] = ts2;
+        g_exact_stamp[11] = wall_clock64();
+        g_exact_stamp[12] = (unsigned long long)cnt;
+    }
+}
+
 constexpr int EIG_M = 24;  // Lanczos steps (Krylov dimension)
 
 // sum over the 256 threads of the workgroup through LDS (two levels of 16; no cross-lane fp64 shuffles)
@@ -1019,6 +1106,63 @@ __device__ __forceinline__ double block_sum_d(double x, double* pr /* [256] */, 
     return tot;
 }
 
+// Leading eigenpair of the m x m projected matrix S = Q'CQ (S_ij = H[min(i,j)][max(i,j)]) on ONE wave: S^(2^10) by
+// repeated squaring (rescaled by the largest diagonal entry each time), c = its column with the largest diagonal,
+// normalised.  out[0] = theta = c'Sc, out[1] = ||S c - theta c||.  LDS traffic of one wave is in order, so the lanes
+// see each other's writes without a workgroup barrier.
+__device__ void ritz_wave(int m, const double (*H)[EIG_M], double* Ta, double* Tb, double* cvec, double* ys, double* out,
+                          int lane) {
+    // every reduction below is done redundantly by every lane from LDS broadcast reads: m <= 24 values, against six
+    // two-instruction ds_bpermute rounds per fp64 cross-lane reduction
+    for (int i = lane; i < m * m; i += 64) {
+        const int r = i / m, c = i - r * m;
+        Ta[r * EIG_M + c] = H[min(r, c)][max(r, c)];
+    }
+    double* A = Ta;
+    double* B = Tb;
+    for (int it = 0; it < 10; ++it) {
+        __builtin_amdgcn_wave_barrier();
+        double dg = 0.0;
+        for (int l = 0; l < m; ++l) dg = fmax(dg, fabs(A[l * EIG_M + l]));
+        if (!(dg > 0.0)) break;
+        const double inv2 = (1.0 / dg) * (1.0 / dg);
+        for (int i = lane; i < m * m; i += 64) {
+            const int r = i / m, c = i - r * m;
+            double t = 0.0;
+            for (int l = 0; l < m; ++l) t = fma(A[r * EIG_M + l], A[l * EIG_M + c], t);
+            B[r * EIG_M + c] = t * inv2;
+        }
+        double* tmp = A;
+        A = B;
+        B = tmp;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int jb = 0;
+    for (int j = 1; j < m; ++j)
+        if (A[j * EIG_M + j] > A[jb * EIG_M + jb]) jb = j;
+    double nrm2 = 0.0;
+    for (int l = 0; l < m; ++l) nrm2 = fma(A[l * EIG_M + jb], A[l * EIG_M + jb], nrm2);
+    double c = (lane < m) ? A[lane * EIG_M + jb] : 0.0;
+    c = (nrm2 > 0.0) ? c / sqrt(nrm2) : (lane == 0 ? 1.0 : 0.0);
+    if (lane < EIG_M) cvec[lane] = (lane < m) ? c : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    double y = 0.0;
+    if (lane < m)
+        for (int j = 0; j < m; ++j) y = fma(H[min(lane, j)][max(lane, j)], cvec[j], y);
+    if (lane < EIG_M) ys[lane] = y;
+    __builtin_amdgcn_wave_barrier();
+    double theta = 0.0, r2 = 0.0;
+    for (int l = 0; l < m; ++l) theta = fma(cvec[l], ys[l], theta);
+    for (int l = 0; l < m; ++l) {
+        const double r = ys[l] - theta * cvec[l];
+        r2 = fma(r, r, r2);
+    }
+    if (lane == 0) {
+        out[0] = theta;
+        out[1] = sqrt(r2);
+    }
+}
+
 // One workgroup (256 threads).  Dynamic LDS: Q[(EIG_M + 1) * n] doubles.
 // Tall mode (entry != nullptr; n > 256 features, |omega_a| <= 256): the matrix is the |omega| x |omega| Gram matrix of
 // the restricted residual's ROWS, the start vector the atom's current coefficients, the result v goes to `vout`.
@@ -1027,14 +1171,15 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
                                                        int ldd, float* __restrict__ Dnext, int c_in_lds,
                                                        const int32_t* __restrict__ entry = nullptr,
                                                        const float* __restrict__ coef = nullptr,
-                                                       float* __restrict__ vout = nullptr) {
+                                                       float* __restrict__ vout = nullptr, int parts = 0) {
     extern __shared__ __attribute__((aligned(16))) double Q[];  // [EIG_M + 1][n], then (c_in_lds) a copy of C [n][n]
-    __shared__ double H[EIG_M][EIG_M], T[EIG_M][EIG_M];
-    __shared__ double hh[EIG_M + 1], red[16], wv[256], pr[256], cvec[EIG_M];
+    __shared__ double H[EIG_M][EIG_M], T[EIG_M][EIG_M], T2[EIG_M][EIG_M];
+    __shared__ double hh[EIG_M + 1], red[16], wv[256], pr[256], cvec[EIG_M], ritz[2], rys[EIG_M];
     __shared__ int m_used;
     if (row_ptr[atom] >= row_ptr[atom + 1]) return;
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const bool tall = entry != nullptr;
+    const unsigned long long ts0 = wall_clock64();
     if (tall) {
         n = row_ptr[atom + 1] - row_ptr[atom];
         c_in_lds = n <= 64;
@@ -1052,10 +1197,44 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
     const double* C = Cg;
     if (c_in_lds) {
         double* Cl = Q + (int64_t)(EIG_M + 1) * n;
-        for (int i = tid; i < n * n; i += 256) Cl[i] = Cg[i];
+        if (parts > 0) {
+            // n <= 64: C arrives as `parts` fp32 partial 64 x 64 sums of ksvd_gram64_kernel; summed here in fp64
+            // (thread t owns entries 4t..4t+3 of each 1024-entry quarter: four 16-byte loads per partial, eight
+            // partials unrolled = 32 loads in flight per lane; one pass over parts x 16 KB)
+            const float4* P = reinterpret_cast<const float4*>(Cg);
+            double t[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t[q] = 0.0;
+            for (int p0 = 0; p0 < parts; p0 += 8) {
+                float4 v[8][4];  // all 32 loads are issued before the first add (clamped partial index, masked below)
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[pp][q] = P[(int64_t)min(p0 + pp, parts - 1) * 1024 + tid + 256 * q];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) {
+                    const double on = (p0 + pp < parts) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        t[4 * q + 0] = fma(on, (double)v[pp][q].x, t[4 * q + 0]);
+                        t[4 * q + 1] = fma(on, (double)v[pp][q].y, t[4 * q + 1]);
+                        t[4 * q + 2] = fma(on, (double)v[pp][q].z, t[4 * q + 2]);
+                        t[4 * q + 3] = fma(on, (double)v[pp][q].w, t[4 * q + 3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = 4 * tid + 1024 * (q >> 2) + (q & 3), r = e >> 6, c = e & 63;
+                if (r < n && c < n) Cl[r * n + c] = t[q];
+            }
+        } else {
+            for (int i = tid; i < n * n; i += 256) Cl[i] = Cg[i];
+        }
         C = Cl;
     }
     __syncthreads();
+    const unsigned long long ts1 = wall_clock64();
     double scale0 = 0.0;
     int m = 0;
     for (int j = 0; j < EIG_M; ++j) {
@@ -1115,53 +1294,22 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
         const double beta = sqrt(beta2);
         m = j + 1;
         if (j == 0) scale0 = fabs(H[0][0]) + beta;
-        if (!(beta > 1e-13 * scale0) || j == EIG_M - 1 || j + 1 >= n) break;  // Krylov space exhausted
+        const bool last = !(beta > 1e-13 * scale0) || j == EIG_M - 1 || j + 1 >= n;  // Krylov space exhausted
+        // Rayleigh-Ritz on the m x m projection (one wave; every step up to m = 12, every second one after that) and
+        // the residual of the leading Ritz pair, ||C u - theta u||^2 = ||S c - theta c||^2 + (beta c_m)^2: converged
+        // pairs stop the recurrence -- K-SVD's restricted residuals have one dominant direction, typically 6-10 steps
+        if (last || m <= 12 || (m & 1) == 0) {
+            __syncthreads();  // H column j complete
+            if (wid == 0) ritz_wave(m, H, &T[0][0], &T2[0][0], cvec, rys, ritz, lane);
+            __syncthreads();
+            const double tail = beta * cvec[m - 1];
+            if (last || sqrt(ritz[1] * ritz[1] + tail * tail) <= 1e-9 * fabs(ritz[0])) break;
+        }
         if (tid < n) Q[(int64_t)(j + 1) * n + tid] = w / beta;
         __syncthreads();
     }
-    // Rayleigh-Ritz: leading eigenvector of the m x m projected matrix Q'CQ by repeated squaring (2^10 power steps)
     __syncthreads();
-    for (int i = tid; i < EIG_M * EIG_M; i += 256) {
-        const int r = i / EIG_M, c = i % EIG_M;
-        T[r][c] = (r < m && c < m) ? H[min(r, c)][max(r, c)] : 0.0;  // H holds q_i . C q_j for i <= j
-    }
-    __syncthreads();
-    for (int it = 0; it < 10; ++it) {
-        double mx = 0.0;
-        for (int i = tid; i < EIG_M * EIG_M; i += 256) mx = fmax(mx, fabs((&T[0][0])[i]));
-        for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
-        __syncthreads();
-        if (lane == 0) red[wid] = mx;
-        __syncthreads();
-        mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-        if (!(mx > 0.0)) break;
-        const double inv = 1.0 / mx;
-        constexpr int PER = (EIG_M * EIG_M + 255) / 256;  // entries of the projected matrix per thread
-        double tnew[PER];
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const int i = tid + 256 * e;
-            double t = 0.0;
-            if (i < EIG_M * EIG_M) {
-                const int r = i / EIG_M, c = i % EIG_M;
-                for (int l = 0; l < EIG_M; ++l) t = fma(T[r][l] * inv, T[l][c] * inv, t);
-            }
-            tnew[e] = t;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < PER; ++e)
-            if (tid + 256 * e < EIG_M * EIG_M) (&T[0][0])[tid + 256 * e] = tnew[e];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        int jb = 0;
-        for (int j = 1; j < m; ++j)
-            if (T[j][j] > T[jb][jb]) jb = j;
-        const bool ok = T[jb][jb] > 0.0;
-        for (int i = 0; i < EIG_M; ++i) cvec[i] = ok ? T[i][jb] : (i == 0 ? 1.0 : 0.0);
-    }
-    __syncthreads();
+    const unsigned long long ts2 = wall_clock64();
     double u = 0.0;
     if (tid < n)
         for (int j = 0; j < m; ++j) u = fma(cvec[j], Q[(int64_t)j * n + tid], u);
@@ -1172,6 +1320,192 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
     if (tid < n) {
         if (tall) vout[tid] = (float)u;
         else Dnext[(int64_t)atom * ldd + tid] = (float)u;
+    }
+    if (tid == 0) {
+        g_exact_stamp[0] = ts0;
+        g_exact_stamp[1] = ts1;
+        g_exact_stamp[2] = ts2;
+        g_exact_stamp[3] = wall_clock64();
+        g_exact_stamp[4] = (unsigned long long)m;
+    }
+}
+
+// Cheap convergence test for the single-wave solver: with full re-orthogonalisation the projected matrix is tridiagonal
+// (a_i = H[i][i], b_i = H[i][i+1]) up to rounding.  Largest eigenvalue by Newton's iteration on the characteristic
+// polynomial from the Gershgorin bound (monotone from the right of the largest root), eigenvector by the BACKWARD
+// three-term recurrence (stable for the decaying leading vector); rows 1..m-1 of (T - theta) s = 0 then hold by
+// construction and the whole residual sits in row 0, so the test verifies itself: a Newton iteration that has not
+// converged just fails the test.  Every lane computes the same scalars; O(m) per Newton step.  Returns true when the
+// Ritz pair's residual sqrt(r_0^2 + (beta s_m)^2) <= tol * theta, with the normalised s in cvec.
+__device__ bool ritz_tridiag(int m, const double (*H)[EIG_M], double beta, double* cvec, double tol, int lane) {
+    double sc = 0.0;
+    for (int i = 0; i < m; ++i) {
+        double row = fabs(H[i][i]);
+        if (i > 0) row += fabs(H[i - 1][i]);
+        if (i < m - 1) row += fabs(H[i][i + 1]);
+        sc = fmax(sc, row);
+    }
+    if (!(sc > 0.0)) return false;
+    const double isc = 1.0 / sc;
+    double x = 1.0;  // scaled Gershgorin bound
+    for (int it = 0; it < 48; ++it) {
+        double p0 = 1.0, d0 = 0.0, p1 = H[0][0] * isc - x, d1 = -1.0;
+        for (int i = 1; i < m; ++i) {
+            const double a = H[i][i] * isc - x, b = H[i - 1][i] * isc, b2 = b * b;
+            const double p2 = a * p1 - b2 * p0, d2 = a * d1 - p1 - b2 * d0;
+            p0 = p1;
+            d0 = d1;
+            p1 = p2;
+            d1 = d2;
+        }
+        if (d1 == 0.0) break;
+        const double dx = p1 / d1;
+        x -= dx;
+        if (fabs(dx) <= 4e-16) break;
+    }
+    const double theta = x * sc;
+    // backward recurrence, s_{m-1} = 1
+    double s1 = 1.0, s2 = 0.0, mine = (lane == m - 1) ? 1.0 : 0.0, nrm2 = 1.0;  // s1 = s_i, s2 = s_{i+1}
+    for (int i = m - 1; i >= 1; --i) {
+        const double b = H[i - 1][i];
+        if (b == 0.0) return false;
+        const double bi = (i < m - 1) ? H[i][i + 1] : 0.0;
+        const double s0 = ((theta - H[i][i]) * s1 - bi * s2) / b;
+        s2 = s1;
+        s1 = s0;
+        if (lane == i - 1) mine = s0;
+        nrm2 = fma(s0, s0, nrm2);
+    }
+    if (!(nrm2 > 0.0) || !(nrm2 < 1e300)) return false;
+    const double inv = 1.0 / sqrt(nrm2);
+    const double r0 = ((H[0][0] - theta) * s1 + ((m > 1) ? H[0][1] * s2 : 0.0)) * inv;
+    const double tail = beta * inv;  // beta * s_{m-1}, s_{m-1} = 1 before normalisation
+    if (lane < EIG_M) cvec[lane] = (lane < m) ? mine * inv : 0.0;
+    return sqrt(r0 * r0 + tail * tail) <= tol * fabs(theta);
+}
+
+// n <= 64 with the partial Gram sums of ksvd_gram64_kernel: the same Lanczos / Rayleigh-Ritz recurrence on ONE wave
+// (lane = vector component).  The four-wave kernel above spends its time in ~15 workgroup barriers per step; here all
+// reductions are LDS broadcast reads inside a wave (no barrier at all): ~1.5 us per step instead of ~6.  The 256
+// threads only share the load of C (sum of the fp32 partials in fp64), then waves 1..3 retire.
+constexpr int E64_QS = 65;  // row stride of the Krylov basis (doubles): lanes reading different rows hit different banks
+
+__global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const int32_t* __restrict__ row_ptr,
+                                                         const float* __restrict__ part, int parts,
+                                                         const float* __restrict__ D, int ldd, float* __restrict__ Dnext) {
+    __shared__ double Cl[64 * 64];
+    __shared__ double Q[(EIG_M + 1) * E64_QS];
+    __shared__ double H[EIG_M][EIG_M], T[EIG_M][EIG_M], T2[EIG_M][EIG_M];
+    __shared__ double hh[EIG_M + 1], wv[64], cvec[EIG_M], ritz[2], rys[EIG_M];
+    if (row_ptr[atom] >= row_ptr[atom + 1]) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long ts0 = wall_clock64();
+    {
+        const float4* P = reinterpret_cast<const float4*>(part);
+        double t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = 0.0;
+        for (int p0 = 0; p0 < parts; p0 += 8) {
+            float4 v[8][4];  // all 32 loads are issued before the first add (clamped partial index, masked below)
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[pp][q] = P[(int64_t)min(p0 + pp, parts - 1) * 1024 + tid + 256 * q];
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+                const double on = (p0 + pp < parts) ? 1.0 : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    t[4 * q + 0] = fma(on, (double)v[pp][q].x, t[4 * q + 0]);
+                    t[4 * q + 1] = fma(on, (double)v[pp][q].y, t[4 * q + 1]);
+                    t[4 * q + 2] = fma(on, (double)v[pp][q].z, t[4 * q + 2]);
+                    t[4 * q + 3] = fma(on, (double)v[pp][q].w, t[4 * q + 3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Cl[4 * tid + 1024 * (q >> 2) + (q & 3)] = t[q];  // 64 x 64, rows/cols >= n are zero
+    }
+    for (int i = tid; i < EIG_M * EIG_M; i += 256) (&H[0][0])[i] = 0.0;
+    __syncthreads();
+    if (tid >= 64) return;
+    const unsigned long long ts1 = wall_clock64();
+    const double d0 = (lane < n) ? (double)D[(int64_t)atom * ldd + lane] : 0.0;
+    auto sumsq64 = [&](double x) {  // sum over the wave of x^2, computed by every lane from LDS
+        __builtin_amdgcn_wave_barrier();
+        wv[lane] = x;
+        __builtin_amdgcn_wave_barrier();
+        double t = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) t = fma(wv[c], wv[c], t);
+        return t;
+    };
+    {
+        const double nrm2 = sumsq64(d0);
+        Q[lane] = (nrm2 > 0.0) ? d0 / sqrt(nrm2) : (lane == 0 ? 1.0 : 0.0);
+    }
+    double scale0 = 0.0;
+    int m = 0;
+    for (int j = 0; j < EIG_M; ++j) {
+        __builtin_amdgcn_wave_barrier();
+        const double* qj = Q + j * E64_QS;
+        double w = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) w = fma(Cl[c * 64 + lane], qj[c], w);  // C symmetric: column access, conflict-free
+        // classical Gram-Schmidt, twice: lane i <= j takes the dot product q_i . w
+        for (int round = 0; round < 2; ++round) {
+            __builtin_amdgcn_wave_barrier();
+            wv[lane] = w;
+            __builtin_amdgcn_wave_barrier();
+            if (lane <= j) {
+                const double* qi = Q + lane * E64_QS;
+                double h = 0.0;
+#pragma unroll 8
+                for (int c = 0; c < 64; ++c) h = fma(qi[c], wv[c], h);
+                hh[lane] = h;
+                if (round == 0) H[lane][j] = h;
+                else H[lane][j] += h;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int i = 0; i <= j; ++i) w = fma(-hh[i], Q[i * E64_QS + lane], w);
+        }
+        const double beta = sqrt(sumsq64(w));
+        m = j + 1;
+        if (j == 0) scale0 = fabs(H[0][0]) + beta;
+        const bool last = !(beta > 1e-13 * scale0) || j == EIG_M - 1 || j + 1 >= n;
+        __builtin_amdgcn_wave_barrier();
+        if (last) {  // the robust dense Rayleigh-Ritz (repeated squaring) closes the recurrence
+            ritz_wave(m, H, &T[0][0], &T2[0][0], cvec, rys, ritz, lane);
+            __builtin_amdgcn_wave_barrier();
+            break;
+        }
+        if (m >= 3 && ritz_tridiag(m, H, beta, cvec, 1e-9, lane)) {
+            __builtin_amdgcn_wave_barrier();
+            break;
+        }
+        Q[(j + 1) * E64_QS + lane] = w / beta;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long ts2 = wall_clock64();
+    double u = 0.0;
+    for (int j = 0; j < m; ++j) u = fma(cvec[j], Q[j * E64_QS + lane], u);
+    const double un2 = sumsq64(u);
+    __builtin_amdgcn_wave_barrier();
+    wv[lane] = u * d0;
+    __builtin_amdgcn_wave_barrier();
+    double sg = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) sg += wv[c];
+    if (un2 > 0.0) u *= (sg < 0.0 ? -1.0 : 1.0) / sqrt(un2);
+    else u = d0;
+    if (lane < n) Dnext[(int64_t)atom * ldd + lane] = (float)u;
+    if (lane == 0) {
+        g_exact_stamp[0] = ts0;
+        g_exact_stamp[1] = ts1;
+        g_exact_stamp[2] = ts2;
+        g_exact_stamp[3] = wall_clock64();
+        g_exact_stamp[4] = (unsigned long long)m;
     }
 }
 
@@ -1389,6 +1723,7 @@ __global__ __launch_bounds__(256) void ksvd_tall_apply_kernel(int atom, float* _
 }
 
 size_t ksvd_exact_work_doubles(int n) {
+    if (n <= 64) return (size_t)G64_MAX_PARTS * 4096 / 2;  // fp32 partial Gram matrices of ksvd_gram64_kernel
     if (n <= 256) return (size_t)n * n;
     return 8 + (size_t)TALL_MAX * TALL_MAX + TALL_MAX / 2 + ((size_t)n + 1) / 2 + 8;
 }
@@ -1452,11 +1787,25 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     }
     const int nb = (n + 63) / 64;
     const unsigned gx = (unsigned)std::max<int64_t>(1, (max_support + GRAM_SPB - 1) / GRAM_SPB);
+    // n <= 64: MFMA Gram kernel with per-workgroup partial sums (no memset, no atomics); slices of <= 320 signals
+    int parts = (int)std::min<int64_t>(G64_MAX_PARTS, std::max<int64_t>(1, (max_support + 319) / 320));
+    if ((max_support + parts - 1) / parts + 63 > G64_ROWS) parts = 0;  // an atom used by > 45k signals: atomics path
+    if (n > 64) parts = 0;
     for (int a = 0; a < K; ++a) {
-        LYS_CHECK_HIP(hipMemsetAsync(work, 0, (size_t)n * n * sizeof(double), stream));
-        hipLaunchKernelGGL(ksvd_gram_kernel, dim3(gx, nb * (nb + 1) / 2), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
-                           entry, coef, D, ldd, work);
-        hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, a, n, row_ptr, work, D, ldd, Dnext, c_in_lds);
+        if (parts > 0) {
+            hipLaunchKernelGGL(ksvd_gram64_kernel, dim3((unsigned)parts), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry,
+                               coef, D, ldd, reinterpret_cast<float*>(work));
+        } else {
+            LYS_CHECK_HIP(hipMemsetAsync(work, 0, (size_t)n * n * sizeof(double), stream));
+            hipLaunchKernelGGL(ksvd_gram_kernel, dim3(gx, nb * (nb + 1) / 2), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
+                               entry, coef, D, ldd, work);
+        }
+        if (parts > 0)
+            hipLaunchKernelGGL(ksvd_eig64_kernel, dim3(1), dim3(256), 0, stream, a, n, row_ptr,
+                               reinterpret_cast<const float*>(work), parts, D, ldd, Dnext);
+        else
+            hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, a, n, row_ptr, work, D, ldd, Dnext,
+                               c_in_lds);
         switch (fb) {
             case 1: hipLaunchKernelGGL(ksvd_exact_apply_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
             case 2: hipLaunchKernelGGL(ksvd_exact_apply_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
