@@ -1435,10 +1435,15 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
         __builtin_amdgcn_wave_barrier();
         wv[lane] = x;
         __builtin_amdgcn_wave_barrier();
-        double t = 0.0;
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) t = fma(wv[c], wv[c], t);
-        return t;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // four chains: the loops are bound by the fp64 FMA latency
+#pragma unroll 4
+        for (int c = 0; c < 64; c += 4) {
+            t0 = fma(wv[c], wv[c], t0);
+            t1 = fma(wv[c + 1], wv[c + 1], t1);
+            t2 = fma(wv[c + 2], wv[c + 2], t2);
+            t3 = fma(wv[c + 3], wv[c + 3], t3);
+        }
+        return (t0 + t1) + (t2 + t3);
     };
     {
         const double nrm2 = sumsq64(d0);
@@ -1450,8 +1455,17 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
         __builtin_amdgcn_wave_barrier();
         const double* qj = Q + j * E64_QS;
         double w = 0.0;
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) w = fma(Cl[c * 64 + lane], qj[c], w);  // C symmetric: column access, conflict-free
+        {
+            double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;  // C symmetric: column access, conflict-free
+#pragma unroll 4
+            for (int c = 0; c < 64; c += 4) {
+                w0 = fma(Cl[c * 64 + lane], qj[c], w0);
+                w1 = fma(Cl[(c + 1) * 64 + lane], qj[c + 1], w1);
+                w2 = fma(Cl[(c + 2) * 64 + lane], qj[c + 2], w2);
+                w3 = fma(Cl[(c + 3) * 64 + lane], qj[c + 3], w3);
+            }
+            w = (w0 + w1) + (w2 + w3);
+        }
         // classical Gram-Schmidt, twice: lane i <= j takes the dot product q_i . w
         for (int round = 0; round < 2; ++round) {
             __builtin_amdgcn_wave_barrier();
@@ -1459,9 +1473,15 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
             __builtin_amdgcn_wave_barrier();
             if (lane <= j) {
                 const double* qi = Q + lane * E64_QS;
-                double h = 0.0;
-#pragma unroll 8
-                for (int c = 0; c < 64; ++c) h = fma(qi[c], wv[c], h);
+                double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
+#pragma unroll 4
+                for (int c = 0; c < 64; c += 4) {
+                    h0 = fma(qi[c], wv[c], h0);
+                    h1 = fma(qi[c + 1], wv[c + 1], h1);
+                    h2 = fma(qi[c + 2], wv[c + 2], h2);
+                    h3 = fma(qi[c + 3], wv[c + 3], h3);
+                }
+                const double h = (h0 + h1) + (h2 + h3);
                 hh[lane] = h;
                 if (round == 0) H[lane][j] = h;
                 else H[lane][j] += h;
