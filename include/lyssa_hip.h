@@ -335,6 +335,35 @@ int lys_profile_collect(double* gemm_ms_host, double* omp_ms_host, int* launches
 int lys_event_record(int id, void* stream);
 int lys_event_elapsed_ms(int id_start, int id_stop, float* ms_host); /* synchronises on id_stop */
 
+/*
+ * Synthetic signals of SURVEY 8(d): X[i][f] (i < N, f < n, row stride ldx) = standard normal value number f of signal
+ * `first + i`, from the counter-based generator Philox4x32-10 (counter = (signal index, f / 4), key = seed) followed by
+ * Box-Muller evaluated in double and rounded to fp32.  Any shard regenerates the same values on any device;
+ * oracle/bomp_oracle.c::lyso_synth_signals is the identical host generator (used for the CPU leg of bench.py).
+ * Replaces the `np.random.randn` data of the reference's examples / tests (e.g. tests/test_dictionary_learn.py:12).
+ */
+int lys_synth_signals(uint64_t seed, int64_t first, int64_t N, int n, float* X, int64_t ldx, void* stream);
+/*
+ * Library-owned context (the ABI SURVEY 8b proposes): usable from plain C with host arrays only -- the context owns
+ * the stream, the packed dictionary + Gram matrix, the alpha0 workspace and the staging buffers.  One context is used
+ * from one host thread at a time; every call is synchronous on return; errors: negative code + lys_last_error().
+ *   lys_ctx_set_dictionary   D_atom_major_host [K][n] fp32 (atom k = row k; the transpose of the reference's (n, K) D,
+ *                            sparse_coding.py:603) -> upload, pack, G = D'D                    (sparse_coding.py:629)
+ *   lys_ctx_bomp_encode      X_sig_major_host [N][n] fp32 (signal i = row i, the transpose of the reference's X),
+ *                            results into host arrays idx/coef [N][k], nnz [N]                 (sparse_coding.py:302-367,630-635)
+ *   lys_ctx_bomp_encode_synthetic   signals first..first+N-1 of lys_synth_signals generated on the device and encoded;
+ *                            stats4 = {N, mean nnz, encode ms, patches/s with inputs resident}
+ *   lys_ctx_timings          ms4 = {host->device (or generation), encode kernels, device->host, sum} of the last call
+ */
+typedef struct lys_ctx lys_ctx;
+int lys_ctx_create(int device, lys_ctx** out);
+void lys_ctx_destroy(lys_ctx* ctx);
+int lys_ctx_set_dictionary(lys_ctx* ctx, const float* D_atom_major_host, int n, int K);
+int lys_ctx_bomp_encode(lys_ctx* ctx, const float* X_sig_major_host, int64_t N, int k,
+                        int32_t* idx_host, float* coef_host, int32_t* nnz_host);
+int lys_ctx_bomp_encode_synthetic(lys_ctx* ctx, uint64_t seed, int64_t first, int64_t N, int k, double* stats4);
+int lys_ctx_timings(const lys_ctx* ctx, double* ms4);
+
 #ifdef __cplusplus
 }
 #endif

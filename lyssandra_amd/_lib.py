@@ -75,6 +75,13 @@ SIGNATURES = {
                                  ctypes.POINTER(_I), ctypes.POINTER(_L)]),
     "lys_event_record": (_I, [_I, _P]),
     "lys_event_elapsed_ms": (_I, [_I, _I, ctypes.POINTER(_F)]),
+    "lys_synth_signals": (_I, [ctypes.c_uint64, _L, _L, _I, _P, _L, _P]),
+    "lys_ctx_create": (_I, [_I, ctypes.POINTER(_P)]),
+    "lys_ctx_destroy": (None, [_P]),
+    "lys_ctx_set_dictionary": (_I, [_P, _P, _I, _I]),
+    "lys_ctx_bomp_encode": (_I, [_P, _P, _L, _I, _P, _P, _P]),
+    "lys_ctx_bomp_encode_synthetic": (_I, [_P, ctypes.c_uint64, _L, _L, _I, ctypes.POINTER(ctypes.c_double)]),
+    "lys_ctx_timings": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
 }
 
 

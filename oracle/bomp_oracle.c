@@ -218,3 +218,49 @@ int lyso_approx_ksvd(const double* X, double* D, int n, int K, int k, int64_t N,
     free(R); free(ptr); free(fill); free(ent); free(v); free(dold);
     return n_unused;
 }
+
+/*
+ * Synthetic signals of SURVEY 8(d), host side: the same counter-based generator as the engine's lys_synth_signals
+ * (Philox4x32-10, counter = (signal index, feature block), key = seed; Box-Muller in double, rounded to fp32), so that
+ * the CPU leg of bench.py and the parity tests see the patches the GPU generated without copying them back.
+ * X [N][n] fp32, signal i = global signal first + i.
+ */
+static void lyso_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                               uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1,
+                       n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void lyso_synth_signals(uint64_t seed, int64_t first, int64_t N, int n, float* X) {
+    const double two32 = 1.0 / 4294967296.0, twopi = 6.283185307179586476925286766559;
+    const int nb = (n + 3) / 4;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        const uint64_t g = (uint64_t)(first + i);
+        for (int b = 0; b < nb; ++b) {
+            uint32_t r[4];
+            float z[4];
+            lyso_philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)b, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            for (int h = 0; h < 2; ++h) {
+                const double u1 = ((double)r[2 * h] + 0.5) * two32, u2 = ((double)r[2 * h + 1] + 0.5) * two32;
+                const double rad = sqrt(-2.0 * log(u1));
+                z[2 * h] = (float)(rad * cos(twopi * u2));
+                z[2 * h + 1] = (float)(rad * sin(twopi * u2));
+            }
+            for (int e = 0; e < 4; ++e)
+                if (4 * b + e < n) X[(size_t)i * n + 4 * b + e] = z[e];
+        }
+    }
+}
+
+/* known-answer hook for the generator's block function (Random123's published Philox4x32-10 vectors) */
+void lyso_philox_block(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    lyso_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}

@@ -20,7 +20,7 @@ def build(force=False):
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
+        if not os.path.exists(LIB) or (os.path.exists(SRC) and os.path.getmtime(SRC) > os.path.getmtime(LIB)):
             build()
         _lib = ctypes.CDLL(LIB)
     return _lib
@@ -68,3 +68,14 @@ def approx_ksvd_sparse(X, D, idx, coef, nnz, n_cycles=1):
     nu = lib.lyso_approx_ksvd(P(Xs), P(Da), ctypes.c_int(n), ctypes.c_int(K), ctypes.c_int(k), ctypes.c_int64(N),
                               P(idx), P(coef), P(nnz), ctypes.c_int(n_cycles), P(unused), ctypes.byref(err))
     return np.ascontiguousarray(Da.T), coef, unused[:nu].tolist(), float(err.value)
+
+
+def synth_signals(seed, first, N, n):
+    """Host counterpart of the engine's lys_synth_signals: fp32 array [N, n] (signal-major) of the synthetic patches
+    first .. first + N - 1 (Philox4x32-10 + Box-Muller, same values as generated on the device)."""
+    lib = load()
+    X = np.empty((int(N), int(n)), dtype=np.float32)
+    lib.lyso_synth_signals.restype = None
+    lib.lyso_synth_signals(ctypes.c_uint64(int(seed)), ctypes.c_int64(int(first)), ctypes.c_int64(int(N)), ctypes.c_int(int(n)),
+                           X.ctypes.data_as(ctypes.c_void_p))
+    return X

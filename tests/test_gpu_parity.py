@@ -4,6 +4,8 @@ Bars (BASELINE.json north_star): identical OMP support sets on signals without c
 min relative top-1/top-2 gap >= 1e-5), coefficients and learned atoms within 1e-5 relative (fp32 engine vs
 float64 reference).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1110,3 +1112,74 @@ def test_omp_template_sweep(eng, n, K, k):
     assert ok.mean() > 0.9 and same[ok].all(), np.flatnonzero(ok & ~same)[:10]
     err = (np.abs(Z - Zo)[:, ok].max(axis=0) / np.abs(Zo)[:, ok].max(axis=0)).max()
     assert err < COEF_TOL, err
+
+
+def test_synth_signals_match_host_generator(eng):
+    """the counter-based generator (Philox4x32-10 + Box-Muller) gives the same patches on the device and on
+    the host (oracle/bomp_oracle.c), for any shard offset -- bit-identical apart from fp32 roundings that a <= 2 ulp(double)
+    difference of the two math libraries can flip (about 1 value in 10^8, then by one fp32 ulp)."""
+    import ctypes
+    import torch
+    from oracle import c_oracle
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    for seed, first, N, n in [(7, 0, 1 << 18, 64), (7, 123456789012, 5000, 256), (99, 17, 3000, 30)]:
+        X = torch.full((N, n + 2), -7.0, dtype=torch.float32, device="cuda")
+        _lib.check(lib.lys_synth_signals(seed, first, N, n, ctypes.c_void_p(X.data_ptr()), n + 2,
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "synth")
+        H = X.cpu().numpy()
+        assert np.all(H[:, n:] == -7.0)                      # padding columns untouched
+        ref = c_oracle.synth_signals(seed, first, N, n)
+        diff = H[:, :n] != ref
+        assert diff.mean() < 1e-6, diff.mean()
+        if diff.any():
+            a, b = H[:, :n][diff].view(np.int32), ref[diff].view(np.int32)
+            assert np.max(np.abs(a.astype(np.int64) - b.astype(np.int64))) <= 1
+
+
+def test_c_abi_context(eng):
+    """The library-owned context of include/lyssa_hip.h: (i) a plain C program compiled with gcc -- no
+    PyTorch, no HIP calls of its own -- sets a dictionary, encodes host arrays and reads the timings; (ii) through
+    ctypes, the context's host-pointer encode equals the engine's device-resident encode on the same signals."""
+    import ctypes
+    import subprocess
+    import tempfile
+    import torch
+    from oracle import c_oracle
+    from lyssandra_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "lyssandra_amd")
+    exe = os.path.join(tempfile.mkdtemp(prefix="lys_cabi_"), "c_abi_smoke")
+    subprocess.run(["gcc", "-O1", "-o", exe, os.path.join(root, "tests", "c_abi_smoke.c"), "-I" + os.path.join(root, "include"),
+                    "-L" + libdir, "-llyssa_hip", "-lm", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout
+    # (ii)
+    lib = _lib.load()
+    n, K, k, N = 64, 1024, 10, 20000
+    rs = np.random.RandomState(3)
+    D = rs.randn(n, K)
+    D = (D / np.linalg.norm(D, axis=0)).astype(np.float32)
+    Xh = c_oracle.synth_signals(5, 40, N, n)                                  # [N, n] fp32
+    ctx = ctypes.c_void_p()
+    _lib.check(lib.lys_ctx_create(0, ctypes.byref(ctx)), "ctx_create")
+    try:
+        Dt = np.ascontiguousarray(D.T)
+        _lib.check(lib.lys_ctx_set_dictionary(ctx, Dt.ctypes.data_as(ctypes.c_void_p), n, K), "set_dictionary")
+        idx = np.empty((N, k), dtype=np.int32)
+        coef = np.empty((N, k), dtype=np.float32)
+        nnz = np.empty((N,), dtype=np.int32)
+        _lib.check(lib.lys_ctx_bomp_encode(ctx, Xh.ctypes.data_as(ctypes.c_void_p), N, k, idx.ctypes.data_as(ctypes.c_void_p),
+                                           coef.ctypes.data_as(ctypes.c_void_p), nnz.ctypes.data_as(ctypes.c_void_p)), "encode")
+        ms = (ctypes.c_double * 4)()
+        _lib.check(lib.lys_ctx_timings(ctx, ms), "timings")
+        assert ms[1] > 0 and abs(ms[3] - (ms[0] + ms[1] + ms[2])) < 1e-5
+        st = (ctypes.c_double * 4)()
+        _lib.check(lib.lys_ctx_bomp_encode_synthetic(ctx, 5, 40, N, k, st), "synthetic")
+        assert st[0] == N and abs(st[1] - nnz.mean()) < 1e-9        # the device generated the same signals
+    finally:
+        lib.lys_ctx_destroy(ctx)
+    dd = eng.DeviceDictionary.from_host(D.astype(np.float64))
+    i2, c2, z2 = eng.bomp_encode(torch.from_numpy(Xh).cuda(), dd, k)
+    assert np.array_equal(idx, i2.cpu().numpy()) and np.array_equal(nnz, z2.cpu().numpy())
+    assert np.array_equal(coef, c2.cpu().numpy())

@@ -335,3 +335,27 @@ def test_round2_widenings_match_reference():
             assert (r < tol).all()                                   # every signal stopped because ||r|| < tol
     Zt = orc.thresh_encode(g["th_X"].astype(np.float64), g["th_D"].astype(np.float64), n_nonzero_coefs=9)
     assert np.array_equal(Zt != 0, g["th_k9_Z"] != 0) and np.max(np.abs(Zt - g["th_k9_Z"])) <= 1e-12
+
+
+def test_philox_generator_known_answers():
+    """The synthetic-signal generator shared by bench.py's GPU and CPU legs: Philox4x32-10 against the
+    known-answer vectors published with Random123, and the moments / shard consistency of the Gaussian stream."""
+    import ctypes
+    from oracle import c_oracle
+    lib = c_oracle.load()
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        c = (ctypes.c_uint32 * 4)(*ctr)
+        k = (ctypes.c_uint32 * 2)(*key)
+        o = (ctypes.c_uint32 * 4)()
+        lib.lyso_philox_block(c, k, o)
+        assert tuple(o) == want
+    X = c_oracle.synth_signals(11, 0, 100000, 64)
+    assert abs(X.mean()) < 2e-3 and abs(X.std() - 1.0) < 2e-3 and abs((X.astype(np.float64) ** 4).mean() - 3.0) < 0.05
+    # any shard regenerates the same values; a different seed / feature count gives a different / prefix-compatible stream
+    assert np.array_equal(c_oracle.synth_signals(11, 7000, 300, 64), X[7000:7300])
+    assert not np.array_equal(c_oracle.synth_signals(12, 0, 300, 64), X[:300])
+    assert np.array_equal(c_oracle.synth_signals(11, 0, 300, 30), X[:300, :30])
