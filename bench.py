@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 N_FEATURES, N_ATOMS, K_NNZ = 64, 1024, 10
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
+SEED_SIGNALS, SEED_DICTIONARY = 20260928, 1234
 
 
 def flops_per_signal(n, K, k):
@@ -89,11 +90,17 @@ def main():
     n, K, k, S = N_FEATURES, N_ATOMS, K_NNZ, args.signals
     # synthetic Gaussian patches (fp32, signal-major) and a unit-norm Gaussian dictionary, generated on the device.
     # every rank draws a different shard of the global batch; the dictionary is the same everywhere.
-    gd = torch.Generator(device=dev).manual_seed(1234)
-    Dt = torch.randn((n, K), device=dev, generator=gd)
+    # the counter-based generator of the library (Philox4x32-10 + Box-Muller keyed by (seed, global signal
+    # index, feature)) -- rank r holds signals r*S .. (r+1)*S - 1 of ONE global stream, and the CPU leg regenerates its
+    # sample on the host with the identical generator of oracle/bomp_oracle.c instead of copying it back.
+    def synth(seed, first, count):
+        X = torch.empty((count, n), dtype=torch.float32, device=dev)
+        _lib.check(lib.lys_synth_signals(seed, first, count, n, ctypes.c_void_p(X.data_ptr()), n,
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "lys_synth_signals")
+        return X
+    Dt = synth(SEED_DICTIONARY, 0, K).t().contiguous()              # atoms = the first K signals of another stream
     Dt = Dt / (Dt.norm(dim=0, keepdim=True) + float(np.finfo(np.float64).eps))
-    gx = torch.Generator(device=dev).manual_seed(1000 + rank)
-    Xs = torch.randn((S, n), device=dev, generator=gx)
+    Xs = synth(SEED_SIGNALS, rank * S, S)
     dd = engine.DeviceDictionary(n, K, dev)
     dd.set(Dt)
     dd.gram()
@@ -168,7 +175,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic (Philox4x32-10 Gaussian patches, lys_synth_signals; random unit-norm dictionary)",
             "config": {"workload": "Batch-OMP encode step of configs[1] (approx-K-SVD 1M 8x8 patches): n=64, K=1024 "
                                    "atoms, k=10, %d Gaussian patches per GPU per step, device-resident sparse output" % S,
                        "signals_per_gpu": S, "n_features": n, "n_atoms": K, "n_nonzero_coefs": k,
@@ -207,7 +214,7 @@ def main():
                 result["odl_batch"] = ob
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(Xs, Dt, k, args.cpu_sample, args.cpu_pool_workers)
+            result["cpu_baseline"] = cpu_baseline(Xs.shape[0], n, Dt, k, args.cpu_sample, args.cpu_pool_workers)
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
@@ -350,21 +357,28 @@ def _cpu_worker(job):
     return orc.bomp_encode(X, D, k).shape[1]
 
 
-def cpu_baseline(Xs, Dt, k, sample, pool_workers=-1):
+def cpu_baseline(S, n, Dt, k, sample, pool_workers=-1):
     """The reference CPU path (float64 numpy/scipy port in oracle/, same per-signal structure as
     lyssa/sparse_coding.py:302-367 + :629-635) on a bounded sample of the SAME patches:
     `value` = n_jobs=1 (one core); `all_cores` = a process map over column batches like the reference's
     run_parallel (lyssa/utils/__init__.py:92-129), spawned workers so that nothing forks after HIP initialisation."""
     import numpy as np
     from oracle import lyssa_oracle as orc
-    X = Xs[:sample].t().contiguous().double().cpu().numpy()
+    from oracle import c_oracle
+
+    def host_patches(count):
+        """(n, count) float64: the first `count` patches of rank 0's batch, regenerated on the host (same values as on
+        the device: tests/test_gpu_parity.py::test_synth_signals_match_host_generator)."""
+        return np.ascontiguousarray(c_oracle.synth_signals(SEED_SIGNALS, 0, count, n).T.astype(np.float64))
+    X = host_patches(min(sample, S))
     D = Dt.double().cpu().numpy()
     t0 = time.perf_counter()
     Z = orc.bomp_encode(X, D, k)
     dt = time.perf_counter() - t0
     assert Z.shape == (D.shape[1], X.shape[1])
     out = {"value": X.shape[1] / dt, "unit": "patches/s", "cores": 1, "kind": "port",
-           "sample": "first %d patches of rank 0's batch, float64 numpy/scipy port of batch_omp (n_jobs=1), %.1f s"
+           "sample": "first %d patches of rank 0's batch (regenerated on the host), float64 numpy/scipy port of batch_omp "
+                     "(n_jobs=1), %.1f s"
                      % (X.shape[1], dt),
            "host_cpus": os.cpu_count()}
     workers = min(os.cpu_count() or 1, 64) if pool_workers < 0 else pool_workers
@@ -372,8 +386,8 @@ def cpu_baseline(Xs, Dt, k, sample, pool_workers=-1):
         try:
             import multiprocessing as mp
             per = max(200, int(out["value"] * 3))            # about 3 s of single-core work per worker
-            n_tot = min(Xs.shape[0], per * workers)
-            Xp = Xs[:n_tot].t().contiguous().double().cpu().numpy()
+            n_tot = min(S, per * workers)
+            Xp = host_patches(n_tot)
             jobs = [(np.ascontiguousarray(Xp[:, i * per:(i + 1) * per]), D, k) for i in range(workers)
                     if i * per < n_tot]
             os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
@@ -392,9 +406,8 @@ def cpu_baseline(Xs, Dt, k, sample, pool_workers=-1):
             out["all_cores_error"] = repr(e)
     # informative: the plain-C restatement (oracle/bomp_oracle.c, OpenMP over signals) -- what a tuned CPU port does
     try:
-        from oracle import c_oracle
-        n_c = min(Xs.shape[0], 1 << 20)          # a few seconds of work on all cores
-        Xc = Xs[:n_c].t().contiguous().double().cpu().numpy()
+        n_c = min(S, 1 << 20)          # a few seconds of work on all cores
+        Xc = host_patches(n_c)
         c_oracle.bomp_encode_sparse(Xc[:, :256], D, k)
         t0 = time.perf_counter()
         c_oracle.bomp_encode_sparse(Xc, D, k)
