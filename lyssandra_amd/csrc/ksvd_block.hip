@@ -40,6 +40,9 @@
 
 #include <algorithm>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace lys {
@@ -402,10 +405,13 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     constexpr int U = (FB == 1) ? 8 : 4;  // signals in flight per team
     constexpr int NTH = 16 * TEAMS;
     extern __shared__ double sm[];  // narrow step only
-    int nwg = (int)gridDim.x;
+    // The narrow step is workgroup 0: with ~100 KB of dynamic LDS only one workgroup fits a CU, a launch of 257 on 256 CUs
+    // leaves one waiting, and the serial narrow step -- the launch's critical path -- must not be the one that waits.
+    int nwg = (int)gridDim.x, bx = (int)blockIdx.x;
     if (mode == 0 && c >= 1) {
         --nwg;
-        if ((int)blockIdx.x == nwg) {
+        --bx;
+        if (bx < 0) {
             bk_narrow_body<LOGB, FB, NTH>(c - 1, K, n, D, Dnext, ldd, bbuf, lay, sm);
             return;
         }
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     const bool have_p = (mode == 1) && p >= 0;  // block c-1 is applied in this launch
     const bool have_c = c < nb;
     const int tid = threadIdx.x, team = tid >> 4, q = tid & 15;
-    const int stamp0 = (blockIdx.x == 0) ? 32 : ((int)blockIdx.x == nwg / 2) ? 48 : -1;
+    const int stamp0 = (bx == 0) ? 32 : (bx == nwg / 2) ? 48 : -1;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BK_WSTAMP(i) do { if (stamp0 >= 0) ts[i] = wall_clock64(); } while (0)
     BK_WSTAMP(0);
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     // all per-signal addresses are 32-bit byte offsets on uniform bases (host checks N*ldr*4 and N*k*4 < 4 GB)
     const unsigned rsz = (unsigned)ldr * 4u, ksz = (unsigned)k * 4u;
     const int pcmp = have_p ? p : -2;  // dropped slots carry atom -1 = "block -1": must not look like block p
-    const int gteam = (int)blockIdx.x * TEAMS + team, nteams = nwg * TEAMS;
+    const int gteam = bx * TEAMS + team, nteams = nwg * TEAMS;
     // state of the list walk (set by `begin_list`)
     int which = 0, tbeg = 0, tend = 0, chunk = 0, tpos = 0, rp_next = 0;
 
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
         __shared__ int s_nslot;
         const int kb = c << B;  // first key of the block
         const int cgb = cg_ptr[kb], cge = cg_ptr[kb + (1 << B)];
-        const int lo = cgb + (int)blockIdx.x * GCH;
+        const int lo = cgb + bx * GCH;
         if (lo < cge) {  // uniform per workgroup
             const int hi = (lo + GCH < cge) ? lo + GCH : cge;
             double* gq = sm;
@@ -948,7 +954,9 @@ static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ld
                                           (int)std::max(narrow_lds_bytes(64 * FB, 1 << LOGB), group_lds_bytes(64 * FB, 1 << LOGB))));
         attr_set[dev] = true;
     }
-    const int grid = (mode == 0 && c >= nb) ? 1 : BK_WBLOCKS + (narrow ? 1 : 0);
+    // X(c >= 1): the narrow workgroup + 255 wide ones = one per CU, all resident at once (the LDS of the narrow step
+    // limits a CU to one workgroup of this launch)
+    const int grid = (mode == 0 && c >= nb) ? 1 : BK_WBLOCKS;
     hipLaunchKernelGGL((bksvd_step_kernel<FB, LOGB, SL, TEAMS, FULL>), dim3(grid), dim3(16 * TEAMS), lds, stream, mode,
                        c, nb, K, R, ldr, n, k, ix.row_ptr, ix.erec, ix.cg_ptr, ix.cg_entry, idx, coef, D, Dnext,
                        padded_features(n), bbuf, lay);
@@ -1027,13 +1035,75 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
     if (rc) return rc;
     LYS_CHECK_HIP(hipMemsetAsync(bbuf, 0, bksvd_stats_doubles(n, K, B) * sizeof(double), stream));
     const int nb = (K + B - 1) / B;
-    for (int c = 0; c <= nb; ++c) {
-        rc = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
-        if (rc) return rc;
-        if (c >= 1) {
-            rc = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
-            if (rc) return rc;
+    auto steps = [&](hipStream_t st) -> int {
+        for (int c = 0; c <= nb; ++c) {
+            int r = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, st);
+            if (r) return r;
+            if (c >= 1) {
+                r = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, st);
+                if (r) return r;
+            }
         }
+        return LYS_OK;
+    };
+    // LYS_BKSVD_GRAPH=1: the 2 K/B + 1 dependent launches replayed as one hipGraph while the buffers stay the same (the
+    // learners allocate them once per fit).  The first sweep on a device always runs eagerly (function attributes).
+    static int use_graph = -1;
+    if (use_graph < 0) {
+        const char* e = getenv("LYS_BKSVD_GRAPH");
+        use_graph = (e && e[0] == '1') ? 1 : 0;
+    }
+    struct Key {
+        void *R, *row_ptr, *erec, *cg_ptr, *cg_entry, *idx, *coef, *D, *Dnext, *bbuf;
+        int64_t ldr;
+        int n, K, k, B;
+    };
+    struct Cache {
+        bool warmed = false, valid = false;
+        Key key;
+        hipGraphExec_t exec = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    };
+    static Cache cache[64];
+    int dev = 0;
+    if (use_graph && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && cache[dev].warmed) {
+        Cache& c = cache[dev];
+        if (!c.stream) {
+            LYS_CHECK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+            LYS_CHECK_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
+            LYS_CHECK_HIP(hipEventCreateWithFlags(&c.ev_out, hipEventDisableTiming));
+        }
+        const Key key{R, row_ptr, erec, cg_ptr, cg_entry, (void*)idx, coef, D, Dnext, bbuf, ldr, n, K, k, B};
+        if (!(c.valid && memcmp(&c.key, &key, sizeof(Key)) == 0)) {
+            if (c.exec) (void)hipGraphExecDestroy(c.exec);
+            c.exec = nullptr;
+            c.valid = false;
+            hipGraph_t graph = nullptr;
+            LYS_CHECK_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal));
+            rc = steps(c.stream);
+            const hipError_t e2 = hipStreamEndCapture(c.stream, &graph);
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            LYS_CHECK_HIP(e2);
+            const hipError_t e3 = hipGraphInstantiate(&c.exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            LYS_CHECK_HIP(e3);
+            memset(&c.key, 0, sizeof(Key));
+            c.key = key;
+            c.valid = true;
+        }
+        LYS_CHECK_HIP(hipEventRecord(c.ev_in, stream));
+        LYS_CHECK_HIP(hipStreamWaitEvent(c.stream, c.ev_in, 0));
+        LYS_CHECK_HIP(hipGraphLaunch(c.exec, c.stream));
+        LYS_CHECK_HIP(hipEventRecord(c.ev_out, c.stream));
+        LYS_CHECK_HIP(hipStreamWaitEvent(stream, c.ev_out, 0));
+    } else {
+        rc = steps(stream);
+        if (rc) return rc;
+        if (dev >= 0 && dev < 64) cache[dev].warmed = true;
     }
     LYS_CHECK_HIP(hipMemcpyAsync(D, Dnext, (size_t)K * padded_features(n) * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return LYS_OK;
