@@ -184,6 +184,9 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BK_NSTAMP(i) do { if (tid == 0) ts[i] = wall_clock64(); } while (0)
     BK_NSTAMP(0);
+    // (Requesting the moments of ALL groups up front, to save the dependent round trip of round 2, was measured slower:
+    // 142 KB instead of 37 KB through one CU's miss queue took 8.8 us against 2.1 + 3.5 -- reading the slab, which was
+    // written by device-scope atomics and comes back through the fabric, costs about 0.1 us per KB on one CU.)
     // round 1: atoms, per-atom statistics (base = S + d_old sum x^2, in fp64 before the conversion), group counts
     for (int i = tid; i < B * NF; i += NTH) {
         const int t = i / NF, f = i % NF, a = c * B + t;
@@ -233,22 +236,22 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     // padding columns n..NF of a staged row are zero-filled
     {
         const int nst = min(gfirst[B], MAXG), per = NF + B, total = nst * per;
-        for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
-            double v[4];
+        constexpr int RU = (MAXG * (NF + B) + NTH - 1) / NTH;  // one pass: every load of the staging is in flight at once
+        for (int i0 = 0; i0 < total; i0 += RU * NTH) {
+            // unconditional loads from clamped addresses (a load under a branch is waited for before the next one issues)
+            double v[RU];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + r * NTH + tid;
-                v[r] = 0.0;
-                if (i < total) {
-                    const int sl = i / per, e = i % per, g = glist[sl];
-                    if (e < n) v[r] = bb[lay.offQ + (int64_t)g * n + e];
-                    if (e >= NF) v[r] = bb[lay.offC + (int64_t)g * B + (e - NF)];
-                }
+            for (int r = 0; r < RU; ++r) {
+                const int i = min(i0 + r * NTH + tid, total - 1);
+                const int sl = i / per, e = i % per, g = glist[sl];
+                const int64_t at = (e >= NF) ? lay.offC + (int64_t)g * B + (e - NF) : lay.offQ + (int64_t)g * n + min(e, n - 1);
+                v[r] = bb[at];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RU; ++r) {
                 const int i = i0 + r * NTH + tid;
-                if (i < total) QC[i] = (float)v[r];
+                const int e = i % per;
+                if (i < total) QC[i] = (e < n || e >= NF) ? (float)v[r] : 0.f;
             }
         }
     }
