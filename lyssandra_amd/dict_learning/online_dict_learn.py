@@ -31,7 +31,8 @@ def online_dict_learn(X, n_atoms, sparse_coder=None, batch_size=None, A=None, B=
     Xs = engine.signals_to_device(X)
     dd = engine.DeviceDictionary.from_host(D)
     device_coder = _is_device_coder(sparse_coder)
-    batch_idx = gen_batches(X.shape[1], batch_size=batch_size)
+    # `batch_size` may also be an explicit list of column ranges (dist.shard_minibatches with uneven shards)
+    batch_idx = list(batch_size) if isinstance(batch_size, (list, tuple)) else gen_batches(X.shape[1], batch_size=batch_size)
     n_iter = len(batch_idx)
     warm = not (A is None and B is None)                           # :59-63: both or none
     state = engine.OdlState(dd, A=A, B=B) if warm else engine.OdlState(dd)

@@ -60,24 +60,27 @@ def shard_minibatches(X, batch_size, group=None):
     The reference walks the signals in consecutive batches (`gen_batches`, lyssa/utils/__init__.py:183-201).  To
     keep exactly that sequence of (global) batches under data parallelism every rank takes the `shard_range` slice
     of EACH batch; running `online_dict_learn(..., batch_size=local_batch_size, group=...)` on the result then
-    processes the same global batches as a single process would.  Requires every batch (the remainder batch
-    included) to split into equal shards.  Returns (X_local, local_batch_size).
+    processes the same global batches as a single process would.  Returns (X_local, local_batch_size); when a batch does
+    not split evenly over the ranks (the last rank takes the remainder, like `shard_range`) the second value is the LIST
+    of this rank's local batch ranges instead of one size -- `online_dict_learn` accepts either as `batch_size`.
     """
     from .utils import gen_batches
     ws, rk = world(group)
     N = X.shape[1]
-    cols = []
-    local_bs = None
+    cols, ranges, base, even = [], [], 0, True
     for b in gen_batches(N, batch_size):
         n_b = b.stop - b.start
-        if n_b % ws != 0:
-            raise ValueError("mini-batch of %d signals does not split evenly over %d ranks" % (n_b, ws))
+        even = even and (n_b % ws == 0)
         s, e = shard_range(n_b, ws, rk)
-        if local_bs is None:
-            local_bs = e - s
         cols.append(np.arange(b.start + s, b.start + e))
+        ranges.append(range(base, base + (e - s)))
+        base += e - s
     idx = np.concatenate(cols) if cols else np.zeros(0, dtype=int)
-    return X[:, idx], (local_bs if batch_size is not None else None)
+    if batch_size is None:
+        return X[:, idx], None
+    if even and ranges:
+        return X[:, idx], len(ranges[0])
+    return X[:, idx], ranges
 
 
 # ------------------------------------------------------------------------------------------------ approx K-SVD

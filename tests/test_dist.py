@@ -237,6 +237,11 @@ def _worker(rank, world, port, out):
         assert lbs == 4 and Xloc.shape == (2, 10)
         exp = [c for b0, nb in ((0, 8), (8, 8), (16, 4)) for c in range(b0 + rank * nb // 2, b0 + (rank + 1) * nb // 2)]
         assert Xloc[0].tolist() == [float(c) for c in exp]
+        # uneven batches (7, 7, 6 over 2 ranks: 3|4, 3|4, 3|3): explicit local ranges, remainder to the last rank
+        Xloc, lranges = ld.shard_minibatches(Xm, 7)
+        assert [len(r) for r in lranges] == ([3, 3, 3] if rank == 0 else [4, 4, 3])
+        exp = [c for b0, nb in ((0, 7), (7, 7), (14, 6)) for c in range(b0 + (rank * nb) // 2, b0 + ((rank + 1) * nb) // 2)]
+        assert Xloc[0].tolist() == [float(c) for c in exp] and lranges[-1].stop == Xloc.shape[1]
         # ---- scalar reduction used for the error
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         ld.allreduce_sum_(t)
