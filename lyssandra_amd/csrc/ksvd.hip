@@ -875,6 +875,97 @@ int ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, const 
     return LYS_OK;
 }
 
+__device__ __forceinline__ double block_sum_d(double x, double* pr, double* red);
+
+// ---- n > 256 (colour patches, stacked features): the same two phases per atom with the features spread over threads
+// instead of a 16-lane team per signal.  Accumulate: workgroup (feature slab of 1024, signal chunk) keeps four features
+// per thread in registers while it walks its signals (every thread reads the same row: coalesced), fp64 atomics at the
+// end.  Apply: `ksvd_wide_finalize_kernel` publishes d_new = normalize(s + d_old sum x^2) once, then one workgroup per
+// signal does the two passes of ksvd.py:121-123 over the row.
+constexpr int WIDE_SLAB = 1024;    // features per workgroup of the accumulate kernel
+constexpr int WIDE_CHUNKS = 64;    // signal chunks (grid.y)
+
+__global__ __launch_bounds__(256) void ksvd_accumulate_wide_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n,
+                                                                   int k, const int32_t* __restrict__ row_ptr,
+                                                                   const int32_t* __restrict__ entry,
+                                                                   const float* __restrict__ coef,
+                                                                   double* __restrict__ sbuf) {
+    __shared__ int64_t s_off[256];
+    __shared__ float s_x[256];
+    const int beg = row_ptr[atom], m = row_ptr[atom + 1] - beg;
+    const int per = (m + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int e0 = blockIdx.y * per, e1 = min(m, e0 + per);
+    if (e0 >= e1) return;
+    const int tid = threadIdx.x, f0 = blockIdx.x * WIDE_SLAB + tid;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    double sq = 0.0;
+    for (int c0 = e0; c0 < e1; c0 += 256) {
+        __syncthreads();
+        if (c0 + tid < e1) {
+            const int ss = entry[beg + c0 + tid];
+            s_off[tid] = (int64_t)(ss / k) * ldr;
+            s_x[tid] = coef[ss];
+        }
+        __syncthreads();
+        const int cnt = min(256, e1 - c0);
+        for (int i = 0; i < cnt; ++i) {
+            const float x = s_x[i];
+            const float* row = R + s_off[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = f0 + 256 * j;
+                acc[j] = fmaf((f < n) ? row[f] : 0.f, x, acc[j]);
+            }
+            if (blockIdx.x == 0 && tid == 0) sq = fma((double)x, (double)x, sq);
+        }
+    }
+    double* dst = sbuf + (int64_t)atom * (n + 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = f0 + 256 * j;
+        if (f < n) atomicAdd(dst + f, (double)acc[j]);
+    }
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(dst + n, sq);
+}
+
+// d_new = normalize(s + d_old sum x^2) -> Dnext[atom] (one workgroup)
+__global__ __launch_bounds__(256) void ksvd_wide_finalize_kernel(int atom, int n, const double* __restrict__ sbuf,
+                                                                 const float* __restrict__ D, int ldd,
+                                                                 float* __restrict__ Dnext) {
+    __shared__ double pr[256], red[16];
+    const double* s = sbuf + (int64_t)atom * (n + 1);
+    const double sumsq = s[n];
+    double nrm2 = 0.0;
+    for (int f = threadIdx.x; f < n; f += 256) {
+        const double v = s[f] + (double)D[(int64_t)atom * ldd + f] * sumsq;
+        nrm2 = fma(v, v, nrm2);
+    }
+    const double scale = 1.0 / (sqrt(block_sum_d(nrm2, pr, red)) + 2.220446049250313e-16);
+    for (int f = threadIdx.x; f < ldd; f += 256)
+        Dnext[(int64_t)atom * ldd + f] = (f < n) ? (float)((s[f] + (double)D[(int64_t)atom * ldd + f] * sumsq) * scale) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void ksvd_apply_wide_kernel(int atom, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                              const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ entry, float* __restrict__ coef,
+                                                              const float* __restrict__ D, int ldd,
+                                                              const float* __restrict__ Dnext) {
+    __shared__ double pr[256], red[16];
+    const int beg = row_ptr[atom], end = row_ptr[atom + 1];
+    const float* dold = D + (int64_t)atom * ldd;
+    const float* dnew = Dnext + (int64_t)atom * ldd;
+    for (int e = beg + blockIdx.x; e < end; e += gridDim.x) {
+        const int ss = entry[e];
+        float* Ri = R + (int64_t)(ss / k) * ldr;
+        const float xo = coef[ss];
+        double dot = 0.0;
+        for (int f = threadIdx.x; f < n; f += 256) dot += (double)fmaf(dold[f], xo, Ri[f]) * (double)dnew[f];
+        const float xn = (float)block_sum_d(dot, pr, red);  // (R_i + d_old x_old)' d_new
+        for (int f = threadIdx.x; f < n; f += 256) Ri[f] = fmaf(-dnew[f], xn, fmaf(dold[f], xo, Ri[f]));
+        if (threadIdx.x == 0) coef[ss] = xn;
+    }
+}
+
 static int fb_of(int n) { return (n <= 64) ? 1 : (n <= 128) ? 2 : (n <= 256) ? 4 : 0; }
 
 int ksvd_atom_accumulate(int atom, const float* R, int64_t ldr, int n, int k, const int32_t* row_ptr,
@@ -883,7 +974,10 @@ int ksvd_atom_accumulate(int atom, const float* R, int64_t ldr, int n, int k, co
         case 1: hipLaunchKernelGGL(ksvd_accumulate_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf); break;
         case 2: hipLaunchKernelGGL(ksvd_accumulate_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf); break;
         case 4: hipLaunchKernelGGL(ksvd_accumulate_kernel<4>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf); break;
-        default: set_error("ksvd: n = %d > 256 not supported", n); return LYS_ENOSUP;
+        default:
+            hipLaunchKernelGGL(ksvd_accumulate_wide_kernel, dim3((unsigned)((n + WIDE_SLAB - 1) / WIDE_SLAB), WIDE_CHUNKS), dim3(256), 0,
+                               stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf);
+            break;
     }
     LYS_LAUNCH_CHECK();
     return LYS_OK;
@@ -896,7 +990,11 @@ int ksvd_atom_apply(int atom, float* R, int64_t ldr, int n, int k, const int32_t
         case 1: hipLaunchKernelGGL(ksvd_apply_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf, D, ldd, Dnext); break;
         case 2: hipLaunchKernelGGL(ksvd_apply_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf, D, ldd, Dnext); break;
         case 4: hipLaunchKernelGGL(ksvd_apply_kernel<4>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, sbuf, D, ldd, Dnext); break;
-        default: set_error("ksvd: n = %d > 256 not supported", n); return LYS_ENOSUP;
+        default:
+            hipLaunchKernelGGL(ksvd_wide_finalize_kernel, dim3(1), dim3(256), 0, stream, atom, n, sbuf, D, ldd, Dnext);
+            hipLaunchKernelGGL(ksvd_apply_wide_kernel, dim3(1024), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, D,
+                               ldd, Dnext);
+            break;
     }
     LYS_LAUNCH_CHECK();
     return LYS_OK;

@@ -98,7 +98,7 @@ def ksvd_cycle_sharded(ops, K, group=None):
     """
     counts = ops.local_counts()
     allreduce_sum_(counts, group)
-    if hasattr(ops, "fused_step"):
+    if getattr(ops, "has_fused", hasattr(ops, "fused_step")):
         # one launch per atom: [pending update of a-1] + [accumulation for a], then the all-reduce of stats(a)
         for a in range(K + 1):
             ops.fused_step(a)

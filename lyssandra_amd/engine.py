@@ -390,6 +390,12 @@ class HipKsvdOps(object):
         self.sbuf.zero_()
         self.Dnext = buffers["Dnext"]
 
+    @property
+    def has_fused(self):
+        """The one-launch-per-atom fused kernel holds an atom in registers (n <= 256); wider signals use the two-phase
+        kernels with the features spread over threads."""
+        return self.dd.n <= 256
+
     def local_counts(self):
         torch = _torch()
         return (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
@@ -426,7 +432,7 @@ class HipKsvdOps(object):
     def sweep_single_gpu(self):
         """All atoms of one cycle in one C call (no per-atom Python / collective), fused K+1-launch form."""
         import os
-        if os.environ.get("LYS_KSVD_FUSED", "1") != "0":
+        if os.environ.get("LYS_KSVD_FUSED", "1") != "0" and self.has_fused:
             _lib.check(self.lib.lys_ksvd_sweep_fused(_ptr(self.R), _ld(self.R), self.dd.n, self.dd.K, self.k,
                                                      _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.idx),
                                                      _ptr(self.coef), _ptr(self.sbuf), _ptr(self.dd.D),

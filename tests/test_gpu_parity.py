@@ -714,10 +714,12 @@ def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
 
 
 # ------------------------------------------------------------------------------------------------ more shapes
-@pytest.mark.parametrize("n,K,k,N", [(128, 96, 4, 700), (200, 150, 6, 500), (30, 40, 3, 257)])
+@pytest.mark.parametrize("n,K,k,N", [(128, 96, 4, 700), (200, 150, 6, 500), (30, 40, 3, 257),
+                                     (300, 64, 4, 900), (768, 48, 3, 400), (1100, 40, 3, 600)])
 def test_approx_ksvd_other_feature_sizes(eng, n, K, k, N):
     """Atom-update kernels at n = 128 (2 feature blocks), n = 200 (4 blocks, ragged) and n = 30 against the oracle,
-    driven from the oracle's own codes; 2 cycles; one atom deliberately unused."""
+    driven from the oracle's own codes; 2 cycles; one atom deliberately unused.  n > 256 (16x16x3 colour patches = 768,
+    more than one 1024-feature slab) runs the per-atom kernels with the features spread over threads."""
     from lyssandra_amd.dict_learning.ksvd import approx_ksvd
     from oracle import lyssa_oracle as orc
     rs = np.random.RandomState(n + K)
