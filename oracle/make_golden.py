@@ -213,6 +213,18 @@ def make_f13():
     te = np.concatenate([np.flatnonzero(ys == c)[20:] for c in range(n_classes)])
     run_lc("small", Xs, ys, 4, 3, 1.0, 1.0, 2, tr, te)
     ref_ksvd_mod.randomized_svd = inner_svd
+    # host harness of the classifiers: the reference's dataset split (global RNG) and parameter-grid order
+    from lyssa.utils.dataset import split_dataset as ref_split
+    from lyssa.classify import avg_class_accuracy as ref_avg_acc, class_accuracy as ref_acc
+    from sklearn.model_selection import ParameterGrid
+    np.random.seed(4242)
+    tr1, te1 = ref_split(np.array([5, 5, 5, 5]), np.array([4, 4, 4, 4]), labels)
+    tr2, te2 = ref_split(np.array([7, 3, 6, 2]), None, labels)
+    out.update(split_seed=4242, split_tr1=tr1, split_te1=te1, split_tr2=tr2, split_te2=te2)
+    grid = [{'alpha': [1, 4], 'beta': [0.5, 2], 'C': [10]}, {'alpha': [3]}]
+    out["grid_order"] = np.array([sorted(d.items()).__repr__() for d in ParameterGrid(grid)])
+    yp = np.array([(c * 7 + i) % n_classes for i, c in enumerate(labels)])
+    out.update(acc_pred=yp, acc=ref_acc(yp, labels), avg_acc=ref_avg_acc(yp, labels))
     np.savez_compressed(os.path.join(OUT, "F13.npz"), **out)
 
 

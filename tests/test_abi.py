@@ -143,3 +143,22 @@ def test_run_parallel_matches_reference_semantics():
     L = run_parallel(func=lambda xs: np.array([len(x) for x in xs], dtype=float), data=["a", "bb", "ccc", "dddd", "e"],
                      result_shape=5, batch_size=2, n_jobs=2)
     assert L.tolist() == [1, 2, 3, 4, 1]
+
+
+def test_classifier_harness_matches_reference():
+    """lyssandra_amd/classify.py (host control flow of config 5) against the reference's own outputs stored in F13:
+    `split_dataset` consumes the global RNG in the same order (utils/dataset.py:241-265), the parameter grid is visited in
+    sklearn's order, the two accuracy measures agree (classify.py:9-25)."""
+    from conftest import load_golden
+    from lyssandra_amd import classify
+    g = load_golden("F13")
+    y = g["labels"]
+    np.random.seed(int(g["split_seed"]))
+    tr1, te1 = classify.split_dataset(np.array([5, 5, 5, 5]), np.array([4, 4, 4, 4]), y)
+    tr2, te2 = classify.split_dataset(np.array([7, 3, 6, 2]), None, y)
+    for mine, ref in ((tr1, "split_tr1"), (te1, "split_te1"), (tr2, "split_tr2"), (te2, "split_te2")):
+        assert np.array_equal(mine, g[ref]), ref
+    grid = [{'alpha': [1, 4], 'beta': [0.5, 2], 'C': [10]}, {'alpha': [3]}]
+    assert [repr(sorted(d.items())) for d in classify.parameter_grid(grid)] == list(g["grid_order"])
+    assert classify.class_accuracy(g["acc_pred"], y) == float(g["acc"])
+    assert abs(classify.avg_class_accuracy(g["acc_pred"], y) - float(g["avg_acc"])) < 1e-15
