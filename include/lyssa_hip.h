@@ -191,6 +191,20 @@ int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k,
                          const int32_t* row_ptr, const int32_t* entry, float* coef,
                          double* work, size_t work_bytes, float* D_packed, float* D_next,
                          int64_t max_support, void* stream);
+/*
+ * The same update per atom for signal SHARDS (n <= 256; one process per GPU): lys_ksvd_exact_gram writes this shard's
+ * Rk Rk' into the fp64 n x n buffer C (zeroed inside); the caller all-reduces C over the ranks (the exchange step the
+ * exact update needs: the Gram matrix IS the sufficient statistic); lys_ksvd_exact_update runs the eigen-solve on the
+ * reduced matrix -- replicated, every rank obtains the same u -- and applies it to the local rows.  used_ptr: a
+ * row_ptr-like int32 [K+1] that is non-empty for the atoms used on ANY rank (row_ptr is the local index);
+ * lys_ksvd_commit(used_ptr) publishes the new atoms at the end of the cycle.   (ksvd.py:19-43, per shard)
+ */
+int lys_ksvd_exact_gram(int atom, const float* R, int64_t ldr, int n, int k,
+                        const int32_t* row_ptr, const int32_t* entry, const float* coef,
+                        const float* D_packed, double* C, int64_t max_support, void* stream);
+int lys_ksvd_exact_update(int atom, float* R, int64_t ldr, int n, int k,
+                          const int32_t* row_ptr, const int32_t* used_ptr, const int32_t* entry, float* coef,
+                          const double* C, const float* D_packed, float* D_next, void* stream);
 /* Whole cycle on one GPU (atoms 0..K-1 in order, both phases, then commit); sbuf is zeroed inside. */
 int lys_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k,
                    const int32_t* row_ptr, const int32_t* entry, float* coef,

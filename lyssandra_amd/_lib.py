@@ -58,6 +58,8 @@ SIGNATURES = {
     "lys_bksvd_step": (_I, [_I, _I, _I, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lys_bksvd_sweep": (_I, [_P, _L, _I, _I, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P]),
     "lys_ksvd_exact_workspace_bytes": (_Z, [_I]),
+    "lys_ksvd_exact_gram": (_I, [_I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
+    "lys_ksvd_exact_update": (_I, [_I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lys_ksvd_exact_sweep": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _Z, _P, _P, _L, _P]),
     "lys_odl_increments": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lys_axpby": (_I, [_P, _F, _P, _L, _P]),

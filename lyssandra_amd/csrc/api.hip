@@ -61,6 +61,10 @@ int ksvd_commit(int, int, const int32_t*, const float*, float*, hipStream_t);
 int ksvd_exact_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
                      int64_t, hipStream_t);
 size_t ksvd_exact_work_doubles(int);
+int ksvd_exact_gram(int, const float*, int64_t, int, int, const int32_t*, const int32_t*, const float*, const float*, double*,
+                    int64_t, hipStream_t);
+int ksvd_exact_update(int, float*, int64_t, int, int, const int32_t*, const int32_t*, const int32_t*, float*, const double*,
+                      const float*, float*, hipStream_t);
 int lasso_from_alpha0(const float*, const float*, int, int, float, float, int, int, int64_t, int32_t*, float*, int32_t*,
                       int32_t*, hipStream_t, int warm = 0);
 int lasso_lars_from_alpha0(const float*, const float*, int, int, float, int, int, int64_t, int32_t*, float*, int32_t*,
@@ -579,6 +583,21 @@ int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32
                 "ksvd_exact_sweep: bad arguments");
     LYS_REQUIRE(work_bytes >= ksvd_exact_work_doubles(n) * sizeof(double), "ksvd_exact_sweep: work buffer too small");
     return ksvd_exact_sweep(R, ldr, n, K, k, row_ptr, entry, coef, work, D_packed, D_next, max_support, STREAM(stream));
+}
+
+int lys_ksvd_exact_gram(int atom, const float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,
+                        const float* coef, const float* D_packed, double* C, int64_t max_support, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && coef && D_packed && C && n > 0 && atom >= 0 && k >= 1 && max_support >= 0,
+                "ksvd_exact_gram: bad arguments");
+    return ksvd_exact_gram(atom, R, ldr, n, k, row_ptr, entry, coef, D_packed, C, max_support, STREAM(stream));
+}
+
+int lys_ksvd_exact_update(int atom, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* used_ptr,
+                          const int32_t* entry, float* coef, const double* C, const float* D_packed, float* D_next,
+                          void* stream) {
+    LYS_REQUIRE(R && row_ptr && used_ptr && entry && coef && C && D_packed && D_next && n > 0 && atom >= 0 && k >= 1,
+                "ksvd_exact_update: bad arguments");
+    return ksvd_exact_update(atom, R, ldr, n, k, row_ptr, used_ptr, entry, coef, C, D_packed, D_next, STREAM(stream));
 }
 
 int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, float* D_packed, void* stream) {

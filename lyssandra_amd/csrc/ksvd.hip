@@ -1934,6 +1934,56 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     return ksvd_commit(n, K, row_ptr, Dnext, D, stream);
 }
 
+// Per-atom halves of the exact update for signal shards (n <= 256): `ksvd_exact_gram` adds this shard's C = Rk Rk' into
+// an fp64 n x n buffer (zeroed here) -- the caller all-reduces it over the ranks --, `ksvd_exact_update` runs the
+// eigen-solve on the reduced matrix (replicated: every rank gets the same u) and applies it to the local rows.
+int ksvd_exact_gram(int atom, const float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,
+                    const float* coef, const float* D, double* C, int64_t max_support, hipStream_t stream) {
+    if (n > 256) {
+        set_error("sharded exact ksvd needs n <= 256 (n = %d)", n);
+        return LYS_ENOSUP;
+    }
+    const int ldd = padded_features(n), nb = (n + 63) / 64;
+    const unsigned gx = (unsigned)std::max<int64_t>(1, (max_support + GRAM_SPB - 1) / GRAM_SPB);
+    LYS_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)n * n * sizeof(double), stream));
+    hipLaunchKernelGGL(ksvd_gram_kernel, dim3(gx, nb * (nb + 1) / 2), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry,
+                       coef, D, ldd, C);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// `used_ptr`: a row_ptr-like array that is non-empty for atoms used on ANY rank (the eigen-solve and the atom write
+// must run on every rank, also on one whose shard does not use the atom); `row_ptr` is the local index.
+int ksvd_exact_update(int atom, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* used_ptr,
+                      const int32_t* entry, float* coef, const double* C, const float* D, float* Dnext,
+                      hipStream_t stream) {
+    const int fb = fb_of(n);
+    if (!fb) {
+        set_error("sharded exact ksvd needs n <= 256 (n = %d)", n);
+        return LYS_ENOSUP;
+    }
+    const int ldd = padded_features(n);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    LYS_CHECK_HIP(hipGetDevice(&dev));
+    const int c_in_lds = (n <= 64) ? 1 : 0;
+    const size_t eig_lds = ((size_t)(EIG_M + 1) * n + (c_in_lds ? (size_t)n * n : 0)) * sizeof(double);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ksvd_eig_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          ((EIG_M + 1) * 256 + 64 * 64) * (int)sizeof(double)));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, atom, n, used_ptr, C, D, ldd, Dnext, c_in_lds);
+    switch (fb) {
+        case 1: hipLaunchKernelGGL(ksvd_exact_apply_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
+        case 2: hipLaunchKernelGGL(ksvd_exact_apply_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
+        default: hipLaunchKernelGGL(ksvd_exact_apply_kernel<4>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, atom, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
+    }
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 // The 2K+2 dependent launches of one cycle are captured once into a hipGraph and replayed while the buffer
 // pointers stay the same (the drop-in learners allocate R/codes/index once per fit): a replayed boundary costs
 // about 1.5 us against 3-4 us of host time per eager launch.

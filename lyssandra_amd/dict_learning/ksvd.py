@@ -89,8 +89,6 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
         max_iter = 0
     if non_neg and not approx:
         raise NotImplementedError("nn_ksvd (non_neg=True with approx=False) is outside the accelerated path")
-    if not approx and group is not None:
-        raise NotImplementedError("the exact K-SVD update runs on one GPU (approx=True shards over a group)")
     if eta is not None and group is not None:
         raise NotImplementedError("eta (force_mi) is not available in group (sharded) mode")
     X = np.asarray(X)
@@ -137,7 +135,7 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
             if approx:
                 unused_atoms += engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group, buffers=buffers)
             else:  # ksvd.py:189-190: exact rank-1 update
-                unused_atoms += engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=buffers)
+                unused_atoms += engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=buffers, group=group)
         # ---- replace unused atoms (host RNG, ksvd.py:199-207)
         for atom in unused_atoms:
             if not unused_data:

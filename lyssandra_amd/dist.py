@@ -113,6 +113,29 @@ def ksvd_cycle_sharded(ops, K, group=None):
     return [int(a) for a in (counts == 0).nonzero().flatten().tolist()]
 
 
+def ksvd_exact_cycle_sharded(ops, K, group=None):
+    """One cycle of the EXACT rank-1 update (ksvd.py:19-43) over signal shards.  The sufficient statistic of an atom is the
+    n x n Gram matrix of its restricted residual: per atom IN ORDER
+
+        ops.gram(a)   -> fp64 tensor [n, n]: this shard's Rk Rk'           (all-reduced here)
+        ops.update(a) -> replicated eigen-solve on the reduced matrix + local coefficient / residual update
+
+    plus `ops.local_counts()`, `ops.set_used(global_counts)` and `ops.commit()`.  K collectives of n^2 doubles per cycle
+    (32 KB at n = 64): latency-bound, like the reference semantics demand (atom a+1 reads the residual atom a left).
+    Returns the atoms unused on every rank."""
+    counts = ops.local_counts()
+    allreduce_sum_(counts, group)
+    ops.set_used(counts)
+    host_counts = counts.cpu().tolist()
+    for a in range(K):
+        if host_counts[a] == 0:
+            continue                                   # unused everywhere: keeps its column (ksvd.py:27-29)
+        allreduce_sum_(ops.gram(a), group)
+        ops.update(a)
+    ops.commit()
+    return [a for a in range(K) if host_counts[a] == 0]
+
+
 def ksvd_cycle_blocks(ops, group=None):
     """One cycle of the BLOCK sweep over signal shards (csrc/ksvd_block.hip).  Per block c of B atoms:
 

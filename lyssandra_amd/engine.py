@@ -555,18 +555,74 @@ def ksvd_cycle(R, dd, idx, coef, nnz, group=None, buffers=None, block=None):
     return _d.ksvd_cycle_sharded(ops, dd.K, group)
 
 
-def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None):
+class HipExactKsvdOps(object):
+    """`ops` of dist.ksvd_exact_cycle_sharded: the exact rank-1 update per atom on a signal shard (n <= 256).  The Gram
+    matrix Rk Rk' of an atom's restricted residual is its sufficient statistic: local part -> all-reduce -> replicated
+    eigen-solve -> local coefficient / residual update."""
+
+    def __init__(self, R, dd, idx, coef, nnz, buffers=None):
+        torch = _torch()
+        self.lib = _lib.load()
+        if dd.n > 256:
+            raise _lib.LyssaHipError("the sharded exact K-SVD update needs n <= 256 (n = %d)" % dd.n)
+        self.R, self.dd, self.coef = R, dd, coef
+        self.k = int(idx.shape[1])
+        self.row_ptr, self.entry = csr_by_atom(idx, coef, nnz, dd.K)
+        if buffers is None:
+            buffers = {}
+        C = buffers.get("exact_C")
+        if C is None or C.numel() != dd.n * dd.n:
+            C = buffers["exact_C"] = torch.zeros((dd.n, dd.n), dtype=torch.float64, device=dd.device)
+        Dnext = buffers.get("exact_Dnext")
+        if Dnext is None or Dnext.shape != dd.D.shape:
+            Dnext = buffers["exact_Dnext"] = torch.zeros_like(dd.D)
+        self.C, self.Dnext = C, Dnext
+        counts = self.row_ptr[1:] - self.row_ptr[:-1]
+        self.max_support = int(counts.max().item()) if counts.numel() else 0
+        self.used = None
+
+    def local_counts(self):
+        torch = _torch()
+        return (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
+
+    def set_used(self, global_counts):
+        torch = _torch()
+        self.used = torch.zeros((self.dd.K + 1,), dtype=torch.int32, device=self.dd.device)
+        self.used[1:] = torch.cumsum(torch.clamp(global_counts.to(self.dd.device), max=1), 0).to(torch.int32)
+
+    def gram(self, a):
+        _lib.check(self.lib.lys_ksvd_exact_gram(a, _ptr(self.R), _ld(self.R), self.dd.n, self.k, _ptr(self.row_ptr),
+                                                _ptr(self.entry), _ptr(self.coef), _ptr(self.dd.D), _ptr(self.C),
+                                                self.max_support, _stream()), "lys_ksvd_exact_gram")
+        return self.C
+
+    def update(self, a):
+        _lib.check(self.lib.lys_ksvd_exact_update(a, _ptr(self.R), _ld(self.R), self.dd.n, self.k, _ptr(self.row_ptr),
+                                                  _ptr(self.used), _ptr(self.entry), _ptr(self.coef), _ptr(self.C),
+                                                  _ptr(self.dd.D), _ptr(self.Dnext), _stream()), "lys_ksvd_exact_update")
+
+    def commit(self):
+        _lib.check(self.lib.lys_ksvd_commit(self.dd.n, self.dd.K, _ptr(self.used), _ptr(self.Dnext), _ptr(self.dd.D),
+                                            _stream()), "lys_ksvd_commit")
+        self.dd.invalidate()
+
+
+def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None):
     """One cycle of the EXACT rank-1 K-SVD update (lyssa/dict_learning/ksvd.py:19-43), in place on R, coef, dd.D.
 
     Per atom: Gram matrix of the restricted residual, its leading eigenvector (Lanczos + Rayleigh-Ritz in one
     workgroup), coefficient / residual update (the reference: sklearn ``randomized_svd(n_iter=10)``, random sign).
-    Returns the unused atoms.  Single GPU.
+    Returns the unused atoms.  ``group``: signals sharded over the ranks of a torch.distributed group -- one all-reduce
+    of the atom's n x n Gram matrix per atom (dist.ksvd_exact_cycle_sharded; n <= 256).
     """
     torch = _torch()
     lib = _lib.load()
     k = int(idx.shape[1])
     if buffers is None:
         buffers = {}
+    if group is not None:
+        from . import dist as _d
+        return _d.ksvd_exact_cycle_sharded(HipExactKsvdOps(R, dd, idx, coef, nnz, buffers), dd.K, group)
     row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
     need = int(lib.lys_ksvd_exact_workspace_bytes(dd.n)) // 8
     work = buffers.get("exact_work")

@@ -55,6 +55,46 @@ class NumpyKsvdOps(object):
         self.D[:, used] = self.Dnext[:, used]
 
 
+class NumpyExactKsvdOps(object):
+    """Shard-local phases of the exact rank-1 update in numpy (stand-in for engine.HipExactKsvdOps): the n x n Gram
+    matrix of the restricted residual is all-reduced, the eigen-solve is replicated."""
+
+    def __init__(self, Y, D, Z):
+        self.D, self.Z = D, Z
+        self.R = Y - D @ Z
+        self.C = torch.zeros((D.shape[0], D.shape[0]), dtype=torch.float64)
+        self.Dnext = D.copy()
+        self.used = None
+
+    def local_counts(self):
+        return torch.from_numpy((self.Z != 0).sum(axis=1).astype(np.int64))
+
+    def set_used(self, counts):
+        self.used = counts.numpy() > 0
+
+    def gram(self, a):
+        om = self.Z[a] != 0
+        Rk = self.R[:, om] + np.outer(self.D[:, a], self.Z[a, om])
+        self.C[:] = torch.from_numpy(Rk @ Rk.T)
+        return self.C
+
+    def update(self, a):
+        w, V = np.linalg.eigh(self.C.numpy())
+        u = V[:, -1]
+        if np.dot(u, self.D[:, a]) < 0:
+            u = -u
+        self.Dnext[:, a] = u
+        om = self.Z[a] != 0
+        if om.any():
+            Rk = self.R[:, om] + np.outer(self.D[:, a], self.Z[a, om])
+            x = Rk.T @ u
+            self.R[:, om] = Rk - np.outer(u, x)
+            self.Z[a, om] = x
+
+    def commit(self):
+        self.D[:, self.used] = self.Dnext[:, self.used]
+
+
 class NumpyBlockKsvdOps(object):
     """float64 numpy stand-in for engine.HipBlockKsvdOps: the block Gauss-Seidel sweep of csrc/ksvd_block.hip (B atoms
     per step, exact in-block coupling through tuple moments) with the same `ops` interface and the same slab layout
@@ -207,6 +247,13 @@ def _worker(rank, world, port, out):
         assert unused == list(unused_ref) == [K - 1]
         assert np.max(np.abs(Dl - Dref)) < 1e-12
         assert np.max(np.abs(Zl - Zref[:, span[0]:span[1]])) < 1e-12
+        # ---- exact rank-1 update: one Gram-matrix all-reduce per atom == the exact SVD on the full data
+        Dl, Zl = D0.copy(), Z[:, span[0]:span[1]].copy()
+        unused = ld.ksvd_exact_cycle_sharded(NumpyExactKsvdOps(Xl, Dl, Zl), K)
+        De, Ze, ue = orc.ksvd_exact(X, D0.copy(), Z.copy())
+        assert unused == list(ue) == [K - 1]
+        assert np.max(np.abs(Dl - De)) < 1e-9, np.max(np.abs(Dl - De))
+        assert np.max(np.abs(Zl - Ze[:, span[0]:span[1]])) < 1e-9
         # ---- the block sweep (one slab all-reduce per block of B atoms) == sequential reference semantics
         for B in (4, 8):
             Dl, Zl = D0.copy(), Z[:, span[0]:span[1]].copy()

@@ -664,6 +664,15 @@ def _sharded_worker(rank, world, port, out):
         Do, Ao, Bo = online_dict_learn(Xb, K, sparse_coder=se, batch_size=lbs, D_init=D0.copy(), beta=0.9, n_epochs=1,
                                        group=dist.group.WORLD)
         res.update(Dk=Dk, Do=Do, Ao=Ao)
+        # ---- exact rank-1 update on shards: one Gram-matrix all-reduce per atom
+        dd2 = eng.DeviceDictionary.from_host(D0)
+        i2, c2, z2 = eng.bomp_encode(Xs, dd2, k)
+        R2, _ = eng.residual(Xs, dd2, i2, c2, z2, want_R=True, want_err=False)
+        ux = eng.ksvd_exact_cycle(R2, dd2, i2, c2, z2, group=dist.group.WORLD)
+        np.random.seed(98)
+        Dx, _ = ksvd_dict_learn(Xl, 48, init_dict='data', sparse_coder=se, max_iter=2, approx=False, verbose=False,
+                                return_codes=False, group=dist.group.WORLD, shard_span=span, n_total=X.shape[1])
+        res.update(D_exact=dd2.to_host(), coef_exact=c2.cpu().numpy(), unused_exact=ux, Dx=Dx)
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -710,6 +719,20 @@ def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
     Do, Ao, Bo = online_dict_learn(X, D0.shape[1], sparse_coder=se, batch_size=500, D_init=D0.copy(), beta=0.9,
                                    n_epochs=1)
     assert np.array_equal(r0["Do"], r1["Do"]) and _atom_err(r0["Do"], Do) < 1e-4
+    # exact rank-1 update: 2 shards == one GPU with the full data (atoms to the eigen-solver's accuracy)
+    dd = eng.DeviceDictionary.from_host(D0)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+    ux = eng.ksvd_exact_cycle(R, dd, idx, coef, nnz)
+    assert ux == r0["unused_exact"] == r1["unused_exact"]
+    assert np.array_equal(r0["D_exact"], r1["D_exact"])
+    assert _atom_err(r0["D_exact"], dd.to_host()) < 2e-5
+    cx = np.concatenate([r0["coef_exact"], r1["coef_exact"]])
+    assert np.max(np.abs(cx - coef.cpu().numpy())) < 2e-5 * np.abs(cx).max()
+    np.random.seed(98)
+    Dx, _ = ksvd_dict_learn(X, 48, init_dict='data', sparse_coder=se, max_iter=2, approx=False, verbose=False,
+                            return_codes=False)
+    assert np.array_equal(r0["Dx"], r1["Dx"]) and _atom_err(r0["Dx"], Dx) < 1e-3
     assert np.max(np.abs(r0["Ao"] - Ao)) < 1e-4 * np.abs(Ao).max()
 
 
