@@ -46,29 +46,28 @@ def lc_ksvd(X, y, D, Q, alpha=1, beta=1, lambda1=1, lambda2=1,
     initial dictionary, Q (n_atoms, n_samples) with Q[k, i] = 1 iff atom k and sample i share a class.
     Returns ``(D, Z, W)``: Z are the last iteration's codes AFTER the K-SVD coefficient update (the reference hands its
     Z to `ksvd`, which updates it in place)."""
-    n_features, n_samples = X.shape
-    n_atoms = D.shape[1]
+    n_features, K = X.shape[0], D.shape[1]
     n_classes = len(set(np.asarray(y).tolist()))
     H = _label_matrix(y, n_classes)
-    Z = np.zeros((n_atoms, n_samples))
+    Z = np.zeros((K, X.shape[1]))
     # with Z = 0 these are zero matrices (:136-139) -- kept as the reference computes them
     W = _ridge(Z, H, lambda1)
     G = _ridge(Z, Q, lambda2)
     stacked_X = np.vstack((X, np.sqrt(alpha) * Q, np.sqrt(beta) * H))
     D, G, W, stacked_D = _stack(np.array(D, dtype=np.float64), G, W, alpha, beta)
-    error_prev = 0
+    last_error = 0
     for it in range(max_iter):
         Z = sparse_coder(X, D)
         stacked_D, _, unused_atoms = ksvd(stacked_X, stacked_D, Z, verbose=False)
         if verbose:
             print("iteration %d: number of unused atoms: %d" % (it, len(unused_atoms)))
-        D, G, W, stacked_D = _stack(stacked_D[:n_features], stacked_D[n_features:n_features + n_atoms],
-                                    stacked_D[n_features + n_atoms:], alpha, beta)
+        D, G, W, stacked_D = _stack(stacked_D[:n_features], stacked_D[n_features:n_features + K],
+                                    stacked_D[n_features + K:], alpha, beta)
         if verbose:
-            error_curr = approx_error(D, Z, X, n_jobs=2)
+            error = approx_error(D, Z, X, n_jobs=2)
             acc = np.mean(np.argmax(W @ Z, axis=0) == np.asarray(y).astype(int))
-            print("error: %g  error difference: %g  classification accuracy: %g" % (error_curr, error_curr - error_prev, acc))
-            error_prev = error_curr
+            print("error: %g  error difference: %g  classification accuracy: %g" % (error, error - last_error, acc))
+            last_error = error
     return D, Z, W
 
 
@@ -88,38 +87,34 @@ class lc_ksvd_classifier(classifier):
                  alpha=1, beta=1, mmap=False, verbose=False, n_jobs=1):
         classifier.__init__(self, n_folds=n_folds, param_grid=param_grid, n_class_samples=n_class_samples,
                             n_test_samples=n_test_samples, n_tests=n_tests, name='lc_ksvd_classifier')
-        self.class_dict_coder = class_dict_coder
-        self.n_class_atoms = None
-        self.sparse_coder = sparse_coder
-        self.max_iter = max_iter
-        self.approx = approx
-        self.alpha, self.beta = alpha, beta
-        self.mmap = mmap
-        self.verbose = verbose
-        self.n_jobs = n_jobs
-        self.sparse_coder.n_jobs = n_jobs
+        kept = dict(class_dict_coder=class_dict_coder, sparse_coder=sparse_coder, max_iter=max_iter, approx=approx,
+                    alpha=alpha, beta=beta, mmap=mmap, verbose=verbose, n_jobs=n_jobs)
+        for name, value in kept.items():
+            setattr(self, name, value)
+        self.n_class_atoms = None          # per-class atom counts, fixed by the first `train`
+        sparse_coder.n_jobs = n_jobs       # the reference pokes the coder (:45)
 
     def train(self, X_train, y_train, param_set=None):
         if param_set is not None:
             self.alpha, self.beta = param_set['alpha'], param_set['beta']
         y_train = np.asarray(y_train)
-        n_classes = len(set(y_train.tolist()))
-        if self.class_dict_coder is not None:
+        classes = range(len(set(y_train.tolist())))
+        if self.class_dict_coder is None:
+            # one block of atoms per class, drawn from the class's own columns (global RNG, lc_ksvd.py:56-68)
+            if self.n_class_atoms is None:
+                self.n_class_atoms = np.full(len(classes), self.n_class_samples, dtype=int)
+            blocks = [init_dictionary(X_train[:, y_train == c], self.n_class_atoms[c], method='data', normalize=True)
+                      for c in classes]
+            D = np.zeros((X_train.shape[0], int(np.sum(self.n_class_atoms))))
+            for c, Dc in zip(classes, blocks):
+                first = c * self.n_class_atoms[c]                      # (:66 -- equal class sizes assumed)
+                D[:, first:first + Dc.shape[1]] = Dc
+        else:
             D = self.class_dict_coder(X_train, y_train)
             self.n_class_atoms = self.class_dict_coder.n_class_atoms
-        else:
-            if self.n_class_atoms is None:
-                self.n_class_atoms = (np.zeros(n_classes) + self.n_class_samples).astype(int)
-            D = np.zeros((X_train.shape[0], int(np.sum(self.n_class_atoms))))
-            for c in range(n_classes):
-                Dc = init_dictionary(X_train[:, y_train == c], self.n_class_atoms[c], method='data', normalize=True)
-                base = c * self.n_class_atoms[c]                       # (:66 -- equal class sizes assumed)
-                D[:, base:base + self.n_class_atoms[c]] = Dc
-        Q = np.zeros((int(np.sum(self.n_class_atoms)), X_train.shape[1]))
-        start = 0
-        for c in range(n_classes):
-            Q[start:start + self.n_class_atoms[c], y_train == c] = 1
-            start += self.n_class_atoms[c]
+        # Q[k, i] = 1 iff atom k and sample i belong to the same class (:73-80)
+        owner = np.repeat(np.arange(len(classes)), np.asarray(self.n_class_atoms, dtype=int))
+        Q = (owner[:, None] == y_train[None, :]).astype(np.float64)
         self.D, Z, self.W = lc_ksvd(X_train, y_train, D, Q, sparse_coder=self.sparse_coder, alpha=self.alpha,
                                     beta=self.beta, lambda1=1, lambda2=1, max_iter=self.max_iter, approx=self.approx,
                                     verbose=self.verbose, n_jobs=self.n_jobs)

@@ -21,13 +21,10 @@ class feature_encoder(object):
     """lyssa/feature_encoding.py:40-89."""
 
     def __init__(self, algorithm=None, params=None, n_jobs=1, verbose=True, mmap=False):
-        self.algorithm = algorithm
-        self.params = params
-        if self.params is None:
-            self.params = {}
-        self.n_jobs = n_jobs
-        self.verbose = verbose
-        self.mmap = mmap
+        settings = dict(algorithm=algorithm, params={} if params is None else params, n_jobs=n_jobs, verbose=verbose,
+                        mmap=mmap)
+        for name, value in settings.items():
+            setattr(self, name, value)
 
     def encode(self, X, D):
         return self.__call__(X, D)
