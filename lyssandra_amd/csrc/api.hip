@@ -36,6 +36,9 @@ int gemm_nt(const float*, int64_t, const float*, int64_t, float*, int64_t, int64
 int pack_dictionary(const float*, int, int, float*, hipStream_t);
 bool alpha0_fast_path(int n, int Kp);
 int alpha0_n64(const float*, int64_t, const float*, int, float*, int, int64_t, int, hipStream_t);
+int alpha0_n64_bf16x3(const float*, int64_t, const float*, int, float*, int, int64_t, int, void*, hipStream_t, bool presplit = false);
+int alpha0_bf16x3_split(const float*, int, int, int, void*, hipStream_t);
+size_t alpha0_bf16x3_scratch_bytes(int Kp);
 bool bomp_has_wave_kernel(int Kp, int k);
 size_t bomp_generic_scratch_bytes(int Kp, int k);
 int bomp_from_alpha0(const float*, const float*, int, int, int64_t, int32_t*, float*, int32_t*, float*, hipStream_t,
@@ -114,14 +117,29 @@ static int64_t tile_signals(int Kp) {
 }
 
 // alpha0 = X D: signal-tile-stationary kernel for n <= 64, generic NT GEMM otherwise
+// `split_scratch` (alpha0_bf16x3_scratch_bytes, or null): room for the dictionary's three bf16 planes -- with it the
+// n <= 64 product runs on the bf16 matrix cores at fp32 accuracy (gemm.hip, "bf16x3"); LYS_ALPHA0_BF16X3=0 disables it.
+static bool alpha0_bf16x3_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("LYS_ALPHA0_BF16X3");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+
 static int alpha0_any(const float* X, int64_t ldx, const float* D, int ldd, float* a0, int Kp, int64_t cnt, int n,
-                      hipStream_t stream) {
+                      hipStream_t stream, void* split_scratch = nullptr, bool presplit = false) {
     static int use_fast = -1;
     if (use_fast < 0) {
         const char* e = getenv("LYS_ALPHA0_FAST");
         use_fast = (e && e[0] == '0') ? 0 : 1;
     }
-    if (use_fast && alpha0_fast_path(n, Kp)) return alpha0_n64(X, ldx, D, ldd, a0, Kp, cnt, n, stream);
+    if (use_fast && alpha0_fast_path(n, Kp)) {
+        if (split_scratch && alpha0_bf16x3_enabled())
+            return alpha0_n64_bf16x3(X, ldx, D, ldd, a0, Kp, cnt, n, split_scratch, stream, presplit);
+        return alpha0_n64(X, ldx, D, ldd, a0, Kp, cnt, n, stream);
+    }
     return gemm_nt(X, ldx, D, ldd, a0, Kp, cnt, Kp, n, stream, true);
 }
 
@@ -236,6 +254,7 @@ size_t lys_bomp_workspace_bytes(int n, int K, int k, int64_t N) {
     int64_t rows = (N <= t) ? ((N < 1) ? 1 : N) : (pipeline_enabled() ? 2 * t : t);  // one tile (two if ping-pong)
     size_t bytes = (size_t)rows * (size_t)Kp * sizeof(float);
     if (!bomp_has_wave_kernel(Kp, k)) bytes += bomp_generic_scratch_bytes(Kp, k);
+    if (alpha0_fast_path(n, Kp)) bytes += alpha0_bf16x3_scratch_bytes(Kp);  // the dictionary's bf16 planes, at the end
     return bytes;
 }
 
@@ -279,6 +298,17 @@ static int encode_tiles(int mode, const float* X, int64_t ldx, const float* D_pa
     }
     float* gen = wave ? nullptr : static_cast<float*>(workspace);
     float* alpha0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + gen_bytes);
+    // the last alpha0_bf16x3_scratch_bytes of a workspace sized by lys_bomp_workspace_bytes hold the dictionary's bf16
+    // planes; a smaller (older-sized) workspace simply keeps the fp32 matrix-core kernel
+    void* split = nullptr;
+    if (alpha0_fast_path(n, Kp)) {
+        const size_t sp = alpha0_bf16x3_scratch_bytes(Kp);
+        if (workspace_bytes >= gen_bytes + sp + (size_t)Kp * sizeof(float) + 16) {
+            workspace_bytes -= sp;
+            split = static_cast<char*>(workspace) + ((workspace_bytes) & ~(size_t)15);
+            workspace_bytes = (workspace_bytes & ~(size_t)15);
+        }
+    }
     const int64_t rows = (int64_t)((workspace_bytes - gen_bytes) / ((size_t)Kp * sizeof(float)));
     const int64_t pref = tile_signals(Kp);
     hipStream_t user = STREAM(stream);
@@ -287,7 +317,7 @@ static int encode_tiles(int mode, const float* X, int64_t ldx, const float* D_pa
         // single tile: both kernels on the caller's stream
         const bool prof = g_prof.on && g_prof.used + StageProfile::PER_TILE <= StageProfile::CAP;
         if (prof && (rc = prof_mark(user))) return rc;
-        if ((rc = alpha0_any(X, ldx, D_packed, ldd, alpha0, Kp, N, n, user))) return rc;
+        if ((rc = alpha0_any(X, ldx, D_packed, ldd, alpha0, Kp, N, n, user, split))) return rc;
         if (prof && ((rc = prof_mark(user)) || (rc = prof_mark(user)))) return rc;
         if ((rc = (mode == 2) ? thresh_from_alpha0(alpha0, K, Kp, k, N, idx, coef, nnz, user)
                               : bomp_from_alpha0(alpha0, G, Kp, k, N, idx, coef, nnz, gen, user, mode == 0)))
@@ -313,6 +343,11 @@ static int encode_tiles(int mode, const float* X, int64_t ldx, const float* D_pa
         LYS_CHECK_HIP(hipStreamWaitEvent(sg, pp->ev_in, 0));
         LYS_CHECK_HIP(hipStreamWaitEvent(so, pp->ev_in, 0));
     }
+    bool presplit = false;
+    if (split && alpha0_bf16x3_enabled()) {  // one split of the dictionary for all tiles of this call
+        if ((rc = alpha0_bf16x3_split(D_packed, ldd, Kp, n, split, sg))) return rc;
+        presplit = true;
+    }
     int64_t t = 0;
     for (int64_t s0 = 0; s0 < N; s0 += tile, ++t) {
         const int64_t cnt = (N - s0 < tile) ? N - s0 : tile;
@@ -321,7 +356,7 @@ static int encode_tiles(int mode, const float* X, int64_t ldx, const float* D_pa
         const bool prof = g_prof.on && g_prof.used + StageProfile::PER_TILE <= StageProfile::CAP;
         if (piped && t >= 2) LYS_CHECK_HIP(hipStreamWaitEvent(sg, pp->ev_omp[b], 0));  // buffer b is free again
         if (prof && (rc = prof_mark(sg))) return rc;
-        if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, sg))) return rc;
+        if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, sg, split, presplit))) return rc;
         if (prof && (rc = prof_mark(sg))) return rc;
         if (piped) {
             LYS_CHECK_HIP(hipEventRecord(pp->ev_gemm[b], sg));

@@ -362,6 +362,247 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void alpha0_n64_kernel(cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// alpha0 = X D on the bf16 matrix cores with fp32 accuracy ("bf16x3").  Every fp32 operand is split into three bf16
+// planes, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 mantissa bits, fp32's exponent
+// range), and the product is the six plane products with i + j <= 4 -- (1,1) (1,2) (2,1) (1,3) (3,1) (2,2) -- accumulated
+// in fp32 by v_mfma_f32_32x32x16_bf16; the dropped terms are below 2^-25 of the result, a bf16 x bf16 product is exact
+// in fp32.  Six MFMAs at 16x the fp32 matrix rate = 2.7x fewer matrix-pipe cycles than the fp32 kernel above, which
+// leaves the kernel bound by its 1 GiB of alpha0 stores alone (measured floor of the store scheme: 0.23 ms per 262 144
+// signals; fp32 kernel 0.35 ms).  Same tile walk, same software-pipelined buffer stores as MODE 2 above.
+// Which feature a (register slot, lane half) pair of the MFMA's K = 16 carries is irrelevant as long as A and B use the
+// same assignment: slot s of half h carries feature 16 ks + 8 h + s for both.
+// ------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int B3_LD = 72;  // bf16 elements per LDS row (144 B = 36 dwords = 4 mod 32: conflict-free ds_read_b128)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// three bf16 planes of two floats (packed lo | hi << 16 per plane)
+__device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xffff0000u);
+    p3 = cvt_pk_bf16(sa, sb);
+}
+
+// D_packed [Kp][ldd] fp32 -> Dsp [3][Kp][64] bf16 (features >= min(n, ldd) are zero)
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ D, int ldd, int Kp, int n,
+                                                           unsigned* __restrict__ Dsp) {
+    const int t = blockIdx.x * 256 + threadIdx.x;  // one feature PAIR
+    if (t >= Kp * 32) return;
+    const int a = t >> 5, f = (t & 31) * 2;
+    const float v0 = (f < n && f < ldd) ? D[(int64_t)a * ldd + f] : 0.f;
+    const float v1 = (f + 1 < n && f + 1 < ldd) ? D[(int64_t)a * ldd + f + 1] : 0.f;
+    unsigned p1, p2, p3;
+    split3(v0, v1, p1, p2, p3);
+    Dsp[t] = p1;
+    Dsp[(size_t)Kp * 32 + t] = p2;
+    Dsp[(size_t)2 * Kp * 32 + t] = p3;
+}
+
+// Workgroup = 4 waves = 128 signals x 64 atoms per iteration; wave (wsig, watom) owns 64 signals x 32 atoms.  The
+// SIGNAL fragments are loop invariant and live in registers (2 blocks x 4 k-steps x 3 planes x 4 VGPRs = 96): only the
+// atom planes go through LDS (3 x 64 x 144 B per buffer, double buffered: one barrier per iteration), which leaves room
+// for two workgroups per CU -- with one, every prologue / barrier / store drain is exposed (measured 0.39 ms against
+// 0.35 ms for the fp32 kernel).
+__global__ __launch_bounds__(256, 2) void alpha0_n64_bf16x3_kernel(const float* __restrict__ X, int64_t ldx,
+                                                                  const unsigned* __restrict__ Dsp,
+                                                                  float* __restrict__ C, int Kp, int n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem3[];
+    constexpr int BUF = 3 * 64 * B3_LD;               // bf16 elements of one atom-tile buffer
+    unsigned short* Bs = smem3;                       // [2][3][64][B3_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wsig = __builtin_amdgcn_readfirstlane(wid >> 1), watom = __builtin_amdgcn_readfirstlane(wid & 1);
+    const int64_t bm = (int64_t)blockIdx.x * 128;
+    const int h = lane >> 5, l31 = lane & 31;
+    // ---- signal fragments: the fp32 tile goes through LDS once (coalesced global reads), then every lane splits its own
+    // 2 blocks x 4 k-steps x 8 features into the three planes
+    bf16x8 afr[2][4][3];
+    {
+        float* Xs = reinterpret_cast<float*>(smem3);  // [128][68] floats = 34 816 B <= the two atom buffers (55 296 B)
+        const bool x_vec = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+        const int lrow = tid >> 4, lc4 = (tid & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = lrow + 16 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* p = X + (bm + r) * ldx + lc4;
+            if (x_vec && lc4 + 3 < n) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (lc4 + 0 < n) v.x = p[0];
+                if (lc4 + 1 < n) v.y = p[1];
+                if (lc4 + 2 < n) v.z = p[2];
+                if (lc4 + 3 < n) v.w = p[3];
+            }
+            *reinterpret_cast<float4*>(&Xs[r * A0_LD + lc4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float* src = &Xs[(wsig * 64 + i * 32 + l31) * A0_LD + ks * 16 + h * 8];
+                const float4 u = *reinterpret_cast<const float4*>(src), w = *reinterpret_cast<const float4*>(src + 4);
+                unsigned p1[4], p2[4], p3[4];
+                split3(u.x, u.y, p1[0], p2[0], p3[0]);
+                split3(u.z, u.w, p1[1], p2[1], p3[1]);
+                split3(w.x, w.y, p1[2], p2[2], p3[2]);
+                split3(w.z, w.w, p1[3], p2[3], p3[3]);
+                afr[i][ks][0] = __builtin_bit_cast(bf16x8, (u32x4){p1[0], p1[1], p1[2], p1[3]});
+                afr[i][ks][1] = __builtin_bit_cast(bf16x8, (u32x4){p2[0], p2[1], p2[2], p2[3]});
+                afr[i][ks][2] = __builtin_bit_cast(bf16x8, (u32x4){p3[0], p3[1], p3[2], p3[3]});
+            }
+        __syncthreads();  // the atom buffers may now overwrite the staging area
+    }
+    // ---- atom tile prefetch: 3 planes x 64 atoms x 128 B = 1536 x 16 B, 6 per thread
+    u32x4 pre[6];
+    auto fetch = [&](int bn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = tid + 256 * i;            // 16-byte chunk: plane = e / 512, atom = (e / 8) % 64, chunk = e % 8
+            const int pl = e >> 9, a = (e >> 3) & 63, ch = e & 7;
+            pre[i] = *reinterpret_cast<const u32x4*>(Dsp + ((size_t)pl * Kp + bn + a) * 32 + ch * 4);
+        }
+    };
+    auto stage_b = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = tid + 256 * i;
+            const int pl = e >> 9, a = (e >> 3) & 63, ch = e & 7;
+            *reinterpret_cast<u32x4*>(&Bs[buf * BUF + (pl * 64 + a) * B3_LD + ch * 8]) = pre[i];
+        }
+    };
+    fetch(0);
+    f32x16 accA[2], accB[2];
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(C + bm * Kp, 0, 128 * Kp * (int)sizeof(float), 0x00020000);
+    const int lane_off = ((4 * h) * Kp + l31) * (int)sizeof(float);
+    auto store_part = [&](f32x16 (&acc)[2], int bn, int part) __attribute__((always_inline)) {   // 4 parts of 8 stores
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int i = part >> 1, r = (part & 1) * 8 + rr;
+            const int soff = ((wsig * 64 + i * 32 + (r & 3) + 8 * (r >> 2)) * Kp + bn + watom * 32) * (int)sizeof(float);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][r]), rsrc, lane_off, soff, 2 /* nt */);
+        }
+    };
+    // stores number first .. first + cnt - 1 of a tile's 32 (number = 16 * block + accumulator register)
+    auto store_some = [&](f32x16 (&acc)[2], int bn, int first, int cnt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c < cnt) {
+                const int sidx = first + c, i = sidx >> 4, r = sidx & 15;
+                const int soff = ((wsig * 64 + i * 32 + (r & 3) + 8 * (r >> 2)) * Kp + bn + watom * 32) * (int)sizeof(float);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][r]), rsrc, lane_off, soff, 2 /* nt */);
+            }
+        }
+    };
+    int it = 0;
+    auto tile = [&](f32x16 (&cur)[2], f32x16 (&prev)[2], int bn, bool have_prev) __attribute__((always_inline)) {
+        const int buf = it & 1;
+        ++it;
+        stage_b(buf);        // the other buffer is still being read by slower waves of the previous iteration
+        __syncthreads();
+        if (bn + 64 < Kp) fetch(bn + 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cur[i][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                b[pl] = *reinterpret_cast<const bf16x8*>(&Bs[buf * BUF + (pl * 64 + watom * 32 + l31) * B3_LD + ks * 16 + h * 8]);
+            // small terms first; the two signal blocks alternate (a dependent MFMA waits for its predecessor); the
+            // previous tile's stores are spread between the MFMA pairs (a store issues in the shadow of a running MFMA)
+#define B3_ST(k0, cnt) do { if (have_prev) store_some(prev, bn - 64, ks * 8 + (k0), (cnt)); } while (0)
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks][2], b[0], cur[0], 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks][2], b[0], cur[1], 0, 0, 0);
+            B3_ST(0, 1);
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks][0], b[2], cur[0], 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks][0], b[2], cur[1], 0, 0, 0);
+            B3_ST(1, 1);
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks][1], b[1], cur[0], 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks][1], b[1], cur[1], 0, 0, 0);
+            B3_ST(2, 2);
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks][1], b[0], cur[0], 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks][1], b[0], cur[1], 0, 0, 0);
+            B3_ST(4, 1);
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks][0], b[1], cur[0], 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks][0], b[1], cur[1], 0, 0, 0);
+            B3_ST(5, 1);
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks][0], b[0], cur[0], 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks][0], b[0], cur[1], 0, 0, 0);
+            B3_ST(6, 2);
+#undef B3_ST
+        }
+    };
+    bool pending_b = false;
+    for (int bn = 0; bn < Kp; bn += 128) {
+        tile(accA, accB, bn, bn > 0);
+        if (bn + 64 < Kp) {
+            tile(accB, accA, bn + 64, true);
+            pending_b = true;
+        } else {
+            pending_b = false;
+#pragma unroll
+            for (int part = 0; part < 4; ++part) store_part(accA, bn, part);
+        }
+    }
+    if (pending_b) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) store_part(accB, Kp - 64, part);
+    }
+}
+
+size_t alpha0_bf16x3_scratch_bytes(int Kp) { return (size_t)3 * Kp * 64 * sizeof(unsigned short); }
+
+// whole 128-signal tiles through the bf16x3 kernel, the tail through the fp32 kernel; `scratch`: alpha0_bf16x3_scratch_bytes
+int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, int Kp, int64_t N, int n, hipStream_t stream);
+// the dictionary's three bf16 planes, once per dictionary (callers that encode several tiles against one D split once)
+int alpha0_bf16x3_split(const float* D, int ldd, int Kp, int n, void* scratch, hipStream_t stream) {
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((Kp * 32 + 255) / 256)), dim3(256), 0, stream, D, ldd, Kp, n,
+                       static_cast<unsigned*>(scratch));
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// `presplit`: scratch already holds the planes of D (alpha0_bf16x3_split)
+int alpha0_n64_bf16x3(const float* X, int64_t ldx, const float* D, int ldd, float* C, int Kp, int64_t N, int n,
+                      void* scratch, hipStream_t stream, bool presplit) {
+    if (N <= 0) return LYS_OK;
+    const int64_t whole = N / 128, tail = N - whole * 128;
+    if (whole > 0x7fffffffLL) {
+        set_error("alpha0: grid too large");
+        return LYS_ENOSUP;
+    }
+    if (whole) {
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        LYS_CHECK_HIP(hipGetDevice(&dev));
+        const int lds = 2 * 3 * 64 * B3_LD * (int)sizeof(unsigned short);   // two atom-tile buffers (>= the one-off fp32 staging)
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_bf16x3_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set[dev] = true;
+        }
+        unsigned* Dsp = static_cast<unsigned*>(scratch);
+        if (!presplit)
+            hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((Kp * 32 + 255) / 256)), dim3(256), 0, stream, D, ldd, Kp, n, Dsp);
+        hipLaunchKernelGGL(alpha0_n64_bf16x3_kernel, dim3((unsigned)whole), dim3(256), lds, stream, X, ldx, Dsp, C, Kp, n);
+        LYS_LAUNCH_CHECK();
+    }
+    if (tail) return alpha0_n64(X + whole * 128 * ldx, ldx, D, ldd, C + whole * 128 * Kp, Kp, tail, n, stream);
+    return LYS_OK;
+}
+
 bool alpha0_fast_path(int n, int Kp) { return n <= 64 && (Kp % 128) == 0; }
 
 int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, int Kp, int64_t N, int n,

@@ -37,8 +37,10 @@ def test_host_only_entry_points(lib):
     assert [lib.lys_padded_atoms(k) for k in (1, 4, 64, 65, 256, 1000, 1024, 1025, 4096)] == \
         [64, 64, 64, 128, 256, 1024, 1024, 2048, 4096]
     assert [lib.lys_padded_features(n) for n in (1, 8, 10, 64, 65)] == [8, 8, 16, 64, 72]
-    assert lib.lys_bomp_workspace_bytes(64, 1024, 10, 100) == 100 * 1024 * 4
-    assert lib.lys_bomp_workspace_bytes(64, 1024, 10, 10 ** 9) == (1 << 30)
+    planes = 3 * 1024 * 64 * 2            # the dictionary's three bf16 planes (alpha0 on the bf16 matrix cores, n <= 64)
+    assert lib.lys_bomp_workspace_bytes(64, 1024, 10, 100) == 100 * 1024 * 4 + planes
+    assert lib.lys_bomp_workspace_bytes(64, 1024, 10, 10 ** 9) == (1 << 30) + planes
+    assert lib.lys_bomp_workspace_bytes(100, 1024, 10, 100) == 100 * 1024 * 4        # n > 64: fp32 GEMM only
     # argument validation happens before any HIP call
     assert lib.lys_gram(None, 64, 1024, None, None) == -1
     assert b"gram" in lib.lys_last_error()
