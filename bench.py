@@ -195,7 +195,11 @@ def main():
                 "rocprof_avg_launch_ms": rocprof.get("bomp_wave_kernel_avg_ms"),
                 "rocprof_source": rocprof.get("source"),
                 "launches_timed": launches.value,
-                "gemm_stage": {"kernel": "alpha0_n64_kernel (alpha0 = X D, v_mfma_f32_32x32x2_f32, software-pipelined buffer stores)",
+                "gemm_stage": {"kernel": "alpha0_n64_bf16x3_kernel (alpha0 = X D at fp32 accuracy on the bf16 matrix cores: three "
+                                         "bf16 planes per operand, six v_mfma_f32_32x32x16_bf16 products; software-pipelined "
+                                         "buffer stores; fp32-equivalent FLOP against the fp32 matrix peak)"
+                               if os.environ.get("LYS_ALPHA0_BF16X3", "1") != "0" else
+                               "alpha0_n64_kernel (alpha0 = X D, v_mfma_f32_32x32x2_f32, software-pipelined buffer stores)",
                                "achieved": gemm_tf, "frac": gemm_tf / PEAK_FP32_TFLOPS, "flop_per_patch": f_gemm,
                                "avg_launch_ms": gemm_avg_ms,
                                "rocprof_avg_launch_ms": rocprof.get("alpha0_n64_kernel_avg_ms")},

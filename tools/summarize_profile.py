@@ -25,10 +25,12 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         for name, calls, tot, avg, pct in cur.execute(
                 "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 16"):
             print("%-86s %7d %14d %12.0f %7.2f" % (short(name), calls, tot, avg, pct))
-            for key in ("bomp_wave_kernel", "alpha0_n64_kernel", "bksvd_step_kernel"):
-                if key in name and key + "_avg_ms" not in durations:
-                    durations[key + "_avg_ms"] = avg / 1e3   # top_kernels.average is in us
-                    durations[key + "_calls"] = calls
+            for key, field in (("bomp_wave_kernel", "bomp_wave_kernel"), ("alpha0_n64_bf16x3_kernel", "alpha0_n64_kernel"),
+                               ("alpha0_n64_kernel", "alpha0_n64_kernel"), ("bksvd_step_kernel", "bksvd_step_kernel")):
+                if key in name and field + "_avg_ms" not in durations:
+                    durations[field + "_avg_ms"] = avg / 1e3   # top_kernels.average is in us
+                    durations[field + "_calls"] = calls
+                    durations[field + "_name"] = key
         print("\nregister / LDS use per kernel (from the dispatch records):")
         for name, v, a, s, lds, wg, gx in cur.execute(
                 "select name,vgpr_count,accum_vgpr_count,sgpr_count,lds_size,workgroup_x,max(grid_x) from kernels group by name order by sum(duration) desc limit 10"):
