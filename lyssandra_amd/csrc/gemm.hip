@@ -480,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_bf16x3_kernel(const float* 
         }
     };
     fetch(0);
+    stage_b(0);
     f32x16 accA[2], accB[2];
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(C + bm * Kp, 0, 128 * Kp * (int)sizeof(float), 0x00020000);
@@ -507,9 +508,9 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_bf16x3_kernel(const float* 
     auto tile = [&](f32x16 (&cur)[2], f32x16 (&prev)[2], int bn, bool have_prev) __attribute__((always_inline)) {
         const int buf = it & 1;
         ++it;
-        stage_b(buf);        // the other buffer is still being read by slower waves of the previous iteration
-        __syncthreads();
-        if (bn + 64 < Kp) fetch(bn + 64);
+        __syncthreads();     // buffer `buf` was written at the end of the previous iteration; nobody reads buf ^ 1 any more
+        const bool more = bn + 64 < Kp;
+        if (more) fetch(bn + 64);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -543,6 +544,10 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_bf16x3_kernel(const float* 
             B3_ST(6, 2);
 #undef B3_ST
         }
+        // the next tile's planes go to the other LDS buffer HERE, in the block that issued their loads: the loads are
+        // older than this iteration's 32 stores, so waiting for them (vmcnt counts in order) does not wait for the
+        // stores -- a wait carried across the loop back edge is emitted as vmcnt(0..5) and drains the store queue
+        if (more) stage_b(buf ^ 1);
     };
     bool pending_b = false;
     for (int bn = 0; bn < Kp; bn += 128) {
