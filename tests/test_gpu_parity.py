@@ -1208,3 +1208,41 @@ def test_c_abi_context(eng):
     i2, c2, z2 = eng.bomp_encode(torch.from_numpy(Xh).cuda(), dd, k)
     assert np.array_equal(idx, i2.cpu().numpy()) and np.array_equal(nnz, z2.cpu().numpy())
     assert np.array_equal(coef, c2.cpu().numpy())
+
+
+def test_c_abi_context_tiles_and_dictionary_change(eng):
+    """The context across several alpha0 tiles (K = 8192: 32 768 signals per tile, 70 000 signals = 3 tiles incl. a ragged
+    one), then with a different dictionary shape set on the SAME context (buffers re-planned), N = 0, and error codes."""
+    import ctypes
+    import torch
+    from oracle import c_oracle
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    ctx = ctypes.c_void_p()
+    _lib.check(lib.lys_ctx_create(0, ctypes.byref(ctx)), "ctx_create")
+    try:
+        for (n, K, k, N) in [(32, 8192, 4, 70000), (64, 256, 5, 3000), (20, 100, 3, 777)]:
+            rs = np.random.RandomState(K)
+            D = rs.randn(n, K)
+            D = (D / np.linalg.norm(D, axis=0)).astype(np.float32)
+            Xh = c_oracle.synth_signals(K + 1, 5, N, n)
+            _lib.check(lib.lys_ctx_set_dictionary(ctx, P(np.ascontiguousarray(D.T)), n, K), "set_dictionary")
+            idx = np.full((N, k), -9, dtype=np.int32)
+            coef = np.empty((N, k), dtype=np.float32)
+            nnz = np.empty((N,), dtype=np.int32)
+            _lib.check(lib.lys_ctx_bomp_encode(ctx, P(Xh), N, k, P(idx), P(coef), P(nnz)), "encode")
+            dd = eng.DeviceDictionary.from_host(D.astype(np.float64))
+            i2, c2, z2 = eng.bomp_encode(torch.from_numpy(Xh).cuda(), dd, k)
+            assert np.array_equal(nnz, z2.cpu().numpy()) and np.array_equal(idx, i2.cpu().numpy())
+            assert np.array_equal(coef, c2.cpu().numpy())
+        assert lib.lys_ctx_bomp_encode(ctx, None, 0, 3, None, None, None) == 0                     # N = 0: nothing to do
+        assert lib.lys_ctx_bomp_encode(ctx, P(Xh), 10, 0, P(idx), P(coef), P(nnz)) < 0             # k out of range
+        assert b"ctx_bomp_encode" in lib.lys_last_error()
+        assert lib.lys_ctx_set_dictionary(ctx, None, 20, 100) < 0
+    finally:
+        lib.lys_ctx_destroy(ctx)
+    ctx2 = ctypes.c_void_p()
+    _lib.check(lib.lys_ctx_create(0, ctypes.byref(ctx2)), "ctx_create")
+    assert lib.lys_ctx_bomp_encode(ctx2, P(Xh), 10, 3, P(idx), P(coef), P(nnz)) < 0                # no dictionary yet
+    lib.lys_ctx_destroy(ctx2)
