@@ -209,11 +209,18 @@ def main():
         }
     # auxiliary legs (every rank takes part in the collectives; rank 0 reports)
     if not args.no_ksvd:
-        kit = ksvd_iteration(Xs, dd, k, group=(dist.group.WORLD if distributed else None))
+        # the auxiliary legs must never take the contract line down: a failure is reported inside the line
+        try:
+            kit = ksvd_iteration(Xs, dd, k, group=(dist.group.WORLD if distributed else None))
+        except Exception as e:  # pragma: no cover
+            kit = {"error": repr(e)}
         if rank == 0:
             result["ksvd_iteration"] = kit
         if distributed:
-            ob = odl_batch(Xs, dd, k, dist.group.WORLD)
+            try:
+                ob = odl_batch(Xs, dd, k, dist.group.WORLD)
+            except Exception as e:  # pragma: no cover
+                ob = {"error": repr(e)}
             if rank == 0:
                 result["odl_batch"] = ob
     if rank == 0:
