@@ -898,9 +898,11 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
         }
         BK_WSTAMP(2);
     } else {
-        if (have_c) walk(ROLE_COLLECT, c, 1, true);
-        BK_WSTAMP(2);
+        // the apply walk first: its residual-row stores (half of the launch's traffic) start draining while the collect
+        // walk and the slow-path drain still run -- the other order left them all to the end of the kernel
         if (have_p) walk(ROLE_APPLY, p, 0, true);
+        BK_WSTAMP(2);
+        if (have_c) walk(ROLE_COLLECT, c, 1, true);
         drain();
         BK_WSTAMP(3);
     }
