@@ -164,3 +164,18 @@ def test_classifier_harness_matches_reference():
     assert [repr(sorted(d.items())) for d in classify.parameter_grid(grid)] == list(g["grid_order"])
     assert classify.class_accuracy(g["acc_pred"], y) == float(g["acc"])
     assert abs(classify.avg_class_accuracy(g["acc_pred"], y) - float(g["avg_acc"])) < 1e-15
+
+
+def test_c_caller_compiles_and_links(lib):
+    """A plain C translation unit that includes include/lyssa_hip.h and uses the library-owned context compiles with gcc
+    -Wall -Werror (the header is valid C, not only C++) and links against liblyssa_hip.so (run on the GPU by
+    tests/test_gpu_parity.py::test_c_abi_context)."""
+    import subprocess
+    import tempfile
+    libdir = os.path.join(ROOT, "lyssandra_amd")
+    exe = os.path.join(tempfile.mkdtemp(prefix="lys_cabi_"), "c_abi_smoke")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-o", exe, os.path.join(ROOT, "tests", "c_abi_smoke.c"),
+                        "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-llyssa_hip", "-lm", "-Wl,-rpath," + libdir],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert os.path.exists(exe)
