@@ -217,7 +217,7 @@ static int ctx_reserve(lys_ctx* c, int64_t tile, int k) {
 }
 
 static int64_t ctx_tile(const lys_ctx* c, int64_t N) {
-    const int64_t pref = ((int64_t)1 << 30) / ((int64_t)c->Kp * 4);  // one alpha0 tile of the engine (1 GiB)
+    const int64_t pref = ((int64_t)4 << 30) / ((int64_t)c->Kp * 4);  // one alpha0 tile of the engine (4 GiB)
     return N < pref ? (N < 1 ? 1 : N) : pref;
 }
 
