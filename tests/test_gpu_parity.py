@@ -1246,3 +1246,32 @@ def test_c_abi_context_tiles_and_dictionary_change(eng):
     _lib.check(lib.lys_ctx_create(0, ctypes.byref(ctx2)), "ctx_create")
     assert lib.lys_ctx_bomp_encode(ctx2, P(Xh), 10, 3, P(idx), P(coef), P(nnz)) < 0                # no dictionary yet
     lib.lys_ctx_destroy(ctx2)
+
+
+@pytest.mark.parametrize("n,K", [(64, 128), (40, 256), (64, 1024)])
+def test_alpha0_bf16_planes_wide_dynamic_range(eng, n, K):
+    """The alpha0 product of the encode path (n <= 64: three bf16 planes per operand on the bf16 matrix cores) on data
+    with six decades of dynamic range inside a signal and signals from 1e-20 to 1e+20: the 'thresh' encoder returns the
+    correlations themselves, compared with the float64 product under fp32's forward error bound
+    |err| <= c * eps32 * sum_f |x_f| |d_f|."""
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    rs = np.random.RandomState(n + K)
+    N, k = 640, 16
+    D = rs.randn(n, K)
+    D = (D / np.linalg.norm(D, axis=0)).astype(np.float32).astype(np.float64)
+    X = rs.randn(n, N) * 10.0 ** rs.uniform(-3, 3, size=(n, N))
+    X *= 10.0 ** rs.uniform(-20, 20, size=(1, N))
+    X = X.astype(np.float32).astype(np.float64)
+    se = sparse_encoder(algorithm='thresh', params={'n_nonzero_coefs': k}, verbose=False)
+    Z = se.encode(X, D)                                  # k largest signed correlations per signal, value = alpha0
+    A = D.T @ X
+    bound = np.abs(D).T @ np.abs(X)                      # sum_f |x_f| |d_f| per (atom, signal)
+    nz = Z != 0
+    assert nz.sum(axis=0).max() == k
+    err = np.abs(Z - A)[nz] / bound[nz]
+    assert err.max() < 16 * 1.2e-7, err.max()
+    # and the selected atoms are the top-k of the float64 correlations wherever the k-th / (k+1)-th gap is not a tie
+    srt = np.sort(A, axis=0)[::-1]
+    clear = (srt[k - 1] - srt[k]) > 1e-5 * bound.max(axis=0)
+    top = A >= srt[k - 1][None, :]
+    assert np.array_equal(nz[:, clear], top[:, clear])
