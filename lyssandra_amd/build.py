@@ -8,8 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblyssa_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "bomp.hip", "ksvd.hip", "ksvd_block.hip", "odl.hip", "patches.hip", "lasso.hip",
-           "context.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "lyssa_hip.h")]
+           "context.hip", "bomp_wave.hip", "bomp_x.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "bomp_wave2.h"), os.path.join(os.path.dirname(HERE), "include", "lyssa_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 

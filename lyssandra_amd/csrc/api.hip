@@ -50,6 +50,7 @@ int feature_stats(const float*, int64_t, int, int64_t, double*, double*, hipStre
 int feature_affine(float*, int64_t, int, int64_t, const float*, const float*, hipStream_t);
 int covariance(const float*, int64_t, int, int64_t, double*, hipStream_t);
 int bomp_debug_variant(const float*, const float*, int64_t, int, int32_t*, float*, int32_t*, int, int, hipStream_t);
+int bomp_x_variant(const float*, const float*, int64_t, int, int32_t*, float*, int32_t*, int, int, hipStream_t);
 int residual(const float*, int64_t, const float*, int, int, int, int64_t, const int32_t*, const float*, const int32_t*,
              float*, int64_t, double*, hipStream_t);
 size_t csr_workspace_bytes(int, int, int64_t);
@@ -706,6 +707,7 @@ int lys_debug_bomp_variant(const float* alpha0, const float* G, int64_t N, int k
         set_error("lds_bytes > 64 KiB needs the max-dynamic-LDS attribute");
         return LYS_EINVAL;
     }
+    if (variant >= 100) return bomp_x_variant(alpha0, G, N, k, idx, coef, nnz, variant, lds_bytes, STREAM(stream));
     return bomp_debug_variant(alpha0, G, N, k, idx, coef, nnz, variant, lds_bytes, STREAM(stream));
 }
 

@@ -24,6 +24,9 @@
 
 namespace lys {
 
+int bomp_wave2_launch(int Kp, const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef,
+                      int32_t* nnz, hipStream_t stream, int unit_diag);  // bomp_wave.hip
+
 template <int R>
 struct Lay {
     static constexpr int V = (R >= 4) ? 4 : R;
@@ -848,19 +851,8 @@ static int launch_wave(const float* alpha0, const float* G, int64_t N, int k, in
         set_error("bomp: too many signals per launch (%lld)", (long long)N);
         return LYS_ENOSUP;
     }
-    if constexpr (R == 16 && KMAX == 10) {
-        // headline shape: 2 vectors in LDS -> 163 VGPRs (<= 168) -> 3 waves/SIMD (32 KB LDS per 4-wave workgroup).
-        // (3 vectors in LDS were needed while the kernel used more registers; now 2 is 2 % faster: less LDS traffic)
-        if (k == 10 && unit_diag)
-            hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2, 0, 4, true>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                               alpha0, G, N, k, idx, coef, nnz, unit_diag);
-        else
-            hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N,
-                               k, idx, coef, nnz, unit_diag);
-    } else {
-        hipLaunchKernelGGL((bomp_wave_kernel<R, KMAX, W>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N,
-                           k, idx, coef, nnz, unit_diag);
-    }
+    hipLaunchKernelGGL((bomp_wave_kernel<R, KMAX, W>), dim3((unsigned)blocks), dim3(256), 0, stream, alpha0, G, N, k, idx,
+                       coef, nnz, unit_diag);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -868,8 +860,11 @@ static int launch_wave(const float* alpha0, const float* G, int64_t N, int k, in
 template <int R>
 static int dispatch_k(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
                       hipStream_t stream, int unit_diag) {
-    if (k <= 5) return launch_wave<R, 5>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
-    if (k <= 10) return launch_wave<R, 10>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
+    // (R >= 4, k <= 10) is served by the second-generation kernel (bomp_wave.hip) before this dispatch is reached
+    if constexpr (R < 4) {
+        if (k <= 5) return launch_wave<R, 5>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
+        if (k <= 10) return launch_wave<R, 10>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
+    }
     if constexpr (R <= 8) {
         if (k <= 20) return launch_wave<R, 20>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
     }
@@ -879,29 +874,19 @@ static int dispatch_k(const float* alpha0, const float* G, int64_t N, int k, int
     return 1;  // not covered by a register kernel
 }
 
-// timing ablations of the headline shape (Kp = 1024, k <= 10); `lds_bytes` of dynamic LDS throttle blocks per CU
+// A/B reference for tools/omp_ab2.py: variant 0 = the FIRST-generation headline launch (round 1-2 product kernel: 2
+// vectors in LDS, 3 waves/SIMD, compile-time k and unit diagonal).  The round-1 timing ablations (cache-hot Gram rows,
+// no orthogonalisation FMAs, ...; results in profiles/r01_ablations_and_shapes.txt) were removed with their 15
+// instantiations in round 3.
 int bomp_debug_variant(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
                        int variant, int lds_bytes, hipStream_t stream) {
     const dim3 grid((unsigned)((N + 3) / 4)), block(256);
-    switch (variant) {
-        case 0: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 1: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 1>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 2: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 2>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 3: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 0, 3>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 4: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 5: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 6: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 1>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 7: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 2, 3, 0>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 8: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 4>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 9: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 5>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 10: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 6>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 11: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 7>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 12: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 8>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 13: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 1>), dim3((unsigned)N), dim3(64), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 14: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 0, 2>), dim3((unsigned)((N + 1) / 2)), dim3(128), lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        case 15: hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 3, 9>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;
-        default: set_error("unknown variant %d", variant); return LYS_EINVAL;
+    if (variant != 0 || k != 10) {
+        set_error("debug variant %d (k = %d): only variant 0 with k = 10 is built", variant, k);
+        return LYS_EINVAL;
     }
+    hipLaunchKernelGGL((bomp_wave_kernel<16, 10, 3, 2, 0, 4, true>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx,
+                       coef, nnz, 1);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -958,6 +943,10 @@ int bomp_from_alpha0(const float* alpha0, const float* G, int Kp, int k, int64_t
         if (Kp == 4096) return (k <= 10) ? launch_block<16, 10, 2, 256>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
                                          : launch_block<8, 20, 2>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
         return launch_block<16, 10, 2>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
+    }
+    if (Kp <= 1024 && Kp >= 256 && k <= 10) {
+        rc = bomp_wave2_launch(Kp, alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
+        if (rc != 1) return rc;
     }
     if (bomp_has_wave_kernel(Kp, k)) {
         switch (Kp / 64) {

@@ -1,0 +1,495 @@
+// Second-generation single-wave Batch-OMP kernel for gfx950 (restates lyssa/sparse_coding.py:302-367, `batch_omp`).
+//
+// Same progressive (orthogonalised) algebra as the first kernel (header of bomp.hip); what changed is the SHAPE of the
+// per-step instruction chain, because the first kernel turned out to be bound by the LENGTH of one wave's serial chain
+// (argmax -> owner lookup -> extraction -> pivot -> Gram row -> FMAs: ~1800 cycles per step, of which the FMAs are ~250),
+// not by VALU throughput -- removing 80 % of its FMAs bought 10 %, a third wave per SIMD 22 %:
+//
+//   * of the k-1 orthogonalised vectors the NLDS oldest live in LDS, the rest in VGPRs, and (NV = 1) the LAST one is
+//     never stored: its only later use is the single element p_{k-2}[kk] in the last selection, which is
+//         (G[kk_{k-2}][kk] - sum_l L[k-2][l] w_l) / rho_{k-2}
+//     -- one scalar load and k-2 scalar FMAs from values the step already has.  16 VGPRs less.
+//     (A general form that carries several virtual vectors as coefficients over re-read Gram rows was built and
+//     measured in round 3: correct, but it only pays with a fourth wave per SIMD, which LDS capacity rules out.)
+//   * ONE data-dependent exit per step instead of three: the noise-floor, re-selection and pivot tests are folded into
+//     a flag that is tested after the vector update (the update of a stopping signal is wasted and never read), so the
+//     whole step is one basic block and the Gram-row load is issued as soon as kk is known, before the extraction chain.
+//   * ties between lanes resolve through per-group lane masks (v_cmp -> s_ff1), exact lowest-index semantics without the
+//     separate slow path; L (strictly lower triangle, k(k-1)/2 entries) is packed into the lanes of one VGPR.
+#pragma once
+#include "common.h"
+
+namespace lys {
+namespace w2 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float NOISE_REL = 4e-6f;  // see bomp.hip
+
+// Element r = c*4 + e of lane l holds atom c*256 + l*4 + e (one coalesced dwordx4 per chunk c).
+template <int R>
+struct Lay {
+    static_assert(R % 4 == 0, "dwordx4 layout");
+    static constexpr int C = R / 4;
+    static constexpr int Kp = 64 * R;
+};
+
+__device__ __forceinline__ float sgpr_f(float x) {  // force a wave-uniform value into an SGPR
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
+constexpr int tri(int j) { return j * (j - 1) / 2; }
+
+template <int R, int KMAX, int NLDS, int NV>
+struct State {
+    static constexpr int NS = KMAX - 1 - NV;  // stored vectors p_0 .. p_{NS-1}
+    static constexpr int NREG = NS - NLDS;    // of them in VGPRs
+    static_assert(NS >= NLDS && NS >= 0, "more LDS vectors than stored vectors");
+    typedef float pvec_t __attribute__((ext_vector_type(R)));
+    // per-wave LDS scalar area: L[j][i] at j*KMAX+i, t_j at SC_T+j, 1/rho_j at SC_I+j (floats)
+    static constexpr int SC_T = KMAX * KMAX, SC_I = SC_T + KMAX, SC_FLOATS = SC_I + KMAX;
+    pvec_t a;                      // current correlations (a true vector: element rr readable through the index mode)
+    pvec_t p[NREG > 0 ? NREG : 1];
+    int dxv;                       // lane j = Dx[j]
+    unsigned m0;                   // bits of NOISE_REL * max|alpha0|
+    unsigned laneoff;              // LDS byte address of this lane's dwordx4 slot of (vector 0, chunk 0)
+    int nsel;
+    static_assert(NV == 0 || NV == 1, "at most the last vector is virtual");
+    // NV = 1: what the last selection needs of the unstored vector p_{KMAX-2}
+    int kkv;
+    float invv;
+    float wv[KMAX];
+    // STAMP builds only: s_memtime at the last stamp, cycles per phase (argmax+reduce | owner lookup | extraction+pivot |
+    // vector update+commit)
+    unsigned long long tlast;
+    unsigned cyc[4];
+};
+
+// Diagnostic timestamps (STAMP builds): s_memtime ordered against the computation through a register dependency.
+__device__ __forceinline__ unsigned long long stamp_s(unsigned& dep) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+s"(dep));
+    return t;
+}
+__device__ __forceinline__ unsigned long long stamp_v(float& dep) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(dep));
+    return t;
+}
+#define W2_STAMP_S(ph, dep)                                            \
+    if constexpr (STAMP) {                                             \
+        const unsigned long long t_ = stamp_s(dep);                    \
+        s.cyc[ph] += (unsigned)(t_ - s.tlast);                         \
+        s.tlast = t_;                                                  \
+    }
+#define W2_STAMP_V(ph, dep)                                            \
+    if constexpr (STAMP) {                                             \
+        const unsigned long long t_ = stamp_v(dep);                    \
+        s.cyc[ph] += (unsigned)(t_ - s.tlast);                         \
+        s.tlast = t_;                                                  \
+    }
+
+// (bit `pos` of the lane mask set) ? a : b on the scalar unit: s_bitcmp1_b64 + s_cselect_b32 (the C++ form compiles to
+// a 64-bit shift, an and and a compare)
+__device__ __forceinline__ int bit_select(unsigned long long mask, int pos, int a, int b) {
+    int r;
+    asm("s_bitcmp1_b64 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(mask), "s"(pos), "s"(a), "s"(b) : "scc");
+    return r;
+}
+
+// argmax |a| over the wave, first (lowest atom index) maximum wins like np.argmax (sparse_coding.py:322).
+//
+// Every VALU instruction of a wave64 costs the SIMD ~4 cycles whatever it does (PMC: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
+// = 1.05 quad-cycles), so a v_cndmask is as expensive as a v_pk_fma_f32 that does 128 FMAs; the SALU is a separate pipe
+// with headroom, but a chain of VALU -> SGPR -> SALU round trips is the slowest thing a wave can do (the first kernel's
+// readlane / s_cmp / branch-tree lookup: 45 instructions, 700 cycles per step).  Hence: the VALU produces LANE MASKS
+// (one v_cmp each), the SALU only tests bits of them:
+//   E_c   = lanes whose group c (registers 4c..4c+3) holds the lane's own maximum      (independent of the wave maximum:
+//           issued beside the DPP reduction)
+//   bal   = lanes that hold the wave maximum;  first c with E_c & bal != 0 -> chunk, s_ff1 -> owner lane
+//   F_e   = lanes whose element e of the owner's group equals the lane maximum (group read through the index mode)
+// Atom order is (chunk c, lane, element e), so "lowest chunk, then lowest lane, then lowest element" is exactly
+// np.argmax's first maximum, also when several lanes tie (duplicate atoms, zero signals): no separate slow path.
+template <int R, bool STAMP = false, int OPT = 0, class AV>
+__device__ __forceinline__ bool wave_argmax(const AV& a, int& kk, float& akk, int& Lown, int& rown, unsigned& mbits_out,
+                                            unsigned long long* tmid = nullptr) {
+    constexpr int NG = R / 4;
+    float m4[NG];
+#pragma unroll
+    for (int c = 0; c < NG; ++c) {
+        if constexpr (OPT & 2) {
+            // one statement per group: hipcc pads every asm statement with an s_nop before the next VALU reads its output
+            asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32_e64 %0, %0, |%4|"
+                : "=&v"(m4[c])
+                : "v"(a[4 * c]), "v"(a[4 * c + 1]), "v"(a[4 * c + 2]), "v"(a[4 * c + 3]));
+        } else {
+            float t3;
+            asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t3) : "v"(a[4 * c]), "v"(a[4 * c + 1]), "v"(a[4 * c + 2]));
+            asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(m4[c]) : "v"(t3), "v"(a[4 * c + 3]));
+        }
+    }
+    float best = m4[0];
+    if constexpr (NG == 4) {
+        if constexpr (OPT & 2) {
+            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32_e32 %0, %0, %4"
+                : "=&v"(best)
+                : "v"(m4[0]), "v"(m4[1]), "v"(m4[2]), "v"(m4[3]));
+        } else {
+            float t3;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(m4[0]), "v"(m4[1]), "v"(m4[2]));
+            asm("v_max_f32_e32 %0, %1, %2" : "=v"(best) : "v"(t3), "v"(m4[3]));
+        }
+    } else if constexpr (NG == 2) {
+        asm("v_max_f32_e32 %0, %1, %2" : "=v"(best) : "v"(m4[0]), "v"(m4[1]));
+    }
+    unsigned long long E[NG > 1 ? NG - 1 : 1];
+#pragma unroll
+    for (int c = 0; c < NG - 1; ++c) E[c] = __ballot(m4[c] == best);
+    const float m = wave_max_f(best);
+    unsigned mbits = __builtin_bit_cast(unsigned, m);
+    if constexpr (STAMP) *tmid = stamp_s(mbits);
+    mbits_out = mbits;
+    const unsigned long long bal = __ballot(best == m);
+    if (bal == 0ull) return false;  // NaN correlations: nothing sensible to select
+    int Lo = __builtin_ctzll(bal);
+    int csel = NG - 1;
+    if ((OPT & 1) && __popcll(bal) == 1) {
+        // a single lane owns the maximum (all but duplicate-atom / zero-signal cases): its first group
+#pragma unroll
+        for (int c = NG - 2; c >= 0; --c) csel = bit_select(E[c], Lo, c, csel);
+    } else {
+        // several lanes tie: the first chunk that holds the maximum in any of them, then its lowest lane
+        unsigned long long T = bal;
+#pragma unroll
+        for (int c = NG - 2; c >= 0; --c) {
+            const unsigned long long tc = E[c] & bal;
+            const bool ne = tc != 0ull;
+            T = ne ? tc : T;
+            csel = ne ? c : csel;
+        }
+        Lo = __builtin_ctzll(T);
+    }
+    // the owner's group, read with a run-time (wave-uniform) register index
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = a[csel * 4 + e];
+    int q = 3;
+    float val = x[3];
+#pragma unroll
+    for (int e = 2; e >= 0; --e) {
+        const unsigned long long fe = __ballot(fabsf(x[e]) == best);
+        if constexpr (OPT & 1) {
+            q = bit_select(fe, Lo, e, q);
+            val = (fabsf(x[e]) == best) ? x[e] : val;
+        } else {
+            const bool hit = ((fe >> Lo) & 1ull) != 0ull;  // wave-uniform
+            q = hit ? e : q;
+            val = hit ? x[e] : val;
+        }
+    }
+    Lown = Lo;
+    rown = csel * 4 + q;
+    kk = csel * 256 + Lo * 4 + q;
+    akk = readlane_f(val, Lo);
+    return true;
+}
+
+// one Gram / alpha0 row chunk per dwordx4
+template <int R, bool STREAM>
+__device__ __forceinline__ void load_row4(const float* __restrict__ row, int lane, f32x4 (&v)[R / 4]) {
+#pragma unroll
+    for (int c = 0; c < R / 4; ++c) {
+        const f32x4* ptr = reinterpret_cast<const f32x4*>(row) + (c * 64 + lane);
+        v[c] = STREAM ? __builtin_nontemporal_load(ptr) : *ptr;
+    }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+// acc += negw * pv (four lanes of a chunk) as two packed FMAs
+__device__ __forceinline__ void fma4(f32x4& acc, float negw, const f32x4& pv) {
+    const f32x2 ww = {negw, negw};
+    const f32x2 lo = __builtin_elementwise_fma(ww, f32x2{pv.x, pv.y}, f32x2{acc.x, acc.y});
+    const f32x2 hi = __builtin_elementwise_fma(ww, f32x2{pv.z, pv.w}, f32x2{acc.z, acc.w});
+    acc = f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
+// chunk c of LDS-resident vector i through an explicit byte address, so that the moment the read may be issued can be
+// pinned with a fake register dependency on `addr` (the scheduler otherwise hoists all NLDS*C ds_read_b128 of a step to
+// its top: 48 VGPRs of temporaries at NLDS = 3, and the Gram row gets spilled behind an s_waitcnt vmcnt(0))
+template <int C>
+__device__ __forceinline__ f32x4 lds_chunk(unsigned addr, int i, int c) {
+    return *reinterpret_cast<lds_f32x4*>(addr + (unsigned)((i * C + c) * 1024));
+}
+
+// Steps J..KMAX-1 as a compile-time recursion (see bomp.hip: loops with early exits around convergent cross-lane
+// operations are not unrolled, which would push the state to scratch).
+template <int R, int KMAX, int NLDS, int NV, int J, bool FAST, bool STAMP = false, int OPT = 0>
+__device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* __restrict__ G, int k, int lane,
+                                      f32x4* __restrict__ lds /* [NLDS][C][64] of this wave */,
+                                      float* __restrict__ sc /* scalar area of this wave */, int unit_diag_rt) {
+    using L = Lay<R>;
+    using S = State<R, KMAX, NLDS, NV>;
+    constexpr int C = L::C;
+    constexpr int NS = S::NS;
+    const bool unit_diag = FAST ? true : (unit_diag_rt != 0);
+    if constexpr (J < KMAX) {
+        if (!FAST && J >= k) return;
+        int kk, Lown, rown;
+        float akk;
+        unsigned mbits;
+        unsigned long long tmid = 0;
+        if (!wave_argmax<R, STAMP, OPT>(s.a, kk, akk, Lown, rown, mbits, &tmid)) return;
+        if constexpr (STAMP) {
+            s.cyc[0] += (unsigned)(tmid - s.tlast);
+            s.tlast = tmid;
+            unsigned kd = (unsigned)kk;
+            W2_STAMP_S(1, kd);
+            kk = (int)kd;
+        }
+        int stop = 0;
+        // noise floor (see NOISE_REL in bomp.hip): non-negative floats compare like their bit patterns
+        if constexpr (J == 0) {
+            s.m0 = (unsigned)__builtin_amdgcn_readfirstlane(
+                __builtin_bit_cast(int, NOISE_REL * __builtin_bit_cast(float, mbits)));
+        } else {
+            stop = (mbits < s.m0) ? 1 : 0;
+        }
+        // re-selection => stop (sparse_coding.py:323-325); lanes >= J still hold dxv = -1, which never equals kk
+        stop |= (__ballot(s.dxv == kk) != 0ull) ? 1 : 0;
+        // the last selection needs no vector update: the reference's last `a = a0 - G[:,Dx] z` (:359) is never read
+        const bool more = (J + 1 < KMAX) && (FAST || J + 1 < k);
+        constexpr bool VIRT_BEFORE = (NV == 1) && (J == KMAX - 1);  // p_{KMAX-2} exists only as scalars
+        constexpr int NLJ = (J < NLDS ? J : NLDS);                  // LDS-resident vectors this step reads
+        constexpr int NRJ = (J < NS ? J : NS);                      // stored vectors this step reads
+
+        // ---- Gram row of the new atom, and the first two chunks of the LDS-resident vectors: in flight behind the
+        // extraction chain
+        const float* grow = G + (int64_t)kk * L::Kp;
+        f32x4 g[C];
+        f32x4 buf[2][NLJ > 0 ? NLJ : 1];
+        if (more) load_row4<R, false>(grow, lane, g);
+        // the first two chunks of the LDS-resident vectors: ahead of (OPT & 4: behind) the extraction reads
+        if (!(OPT & 4) && more) {
+            if constexpr (NLJ > 0) {
+                asm("" : "+v"(s.laneoff) : "s"(kk));  // not before kk is known (i.e. not above the argmax)
+#pragma unroll
+                for (int i = 0; i < NLJ; ++i) buf[0][i] = lds_chunk<C>(s.laneoff, i, 0);
+                if constexpr (C > 1) {
+#pragma unroll
+                    for (int i = 0; i < NLJ; ++i) buf[1][i] = lds_chunk<C>(s.laneoff, i, 1);
+                }
+            }
+        }
+        float gsv = 0.f;
+        if constexpr (VIRT_BEFORE) gsv = G[(int64_t)s.kkv * L::Kp + kk];  // scalar load through the constant cache
+        const float gkk = unit_diag ? 1.f : grow[kk];
+
+        // ---- w_i = p_i[kk]  (== L^-1 G[Dx,kk], sparse_coding.py:331,341); the row of L goes to the LDS scalar area
+        float w[KMAX];
+        {
+            const float* lf = reinterpret_cast<const float*>(lds);
+            const int eo = ((rown >> 2) * 64 + Lown) * 4 + (rown & 3);
+#pragma unroll
+            for (int i = 0; i < NLJ; ++i) {
+                w[i] = lf[i * C * 256 + eo];  // every lane reads the same word: a broadcast, the value stays in a VGPR
+                sc[J * KMAX + i] = w[i];
+            }
+            float tmp[KMAX];
+#pragma unroll
+            for (int i = NLDS; i < NRJ; ++i) {
+                tmp[i] = s.p[i - NLDS][rown];  // VGPR index mode; lane Lown holds the element we want
+                w[i] = readlane_f(tmp[i], Lown);
+            }
+            if constexpr (NRJ > NLDS) {
+                if (lane == Lown) {
+#pragma unroll
+                    for (int i = NLDS; i < NRJ; ++i) sc[J * KMAX + i] = tmp[i];
+                }
+            }
+            if constexpr (VIRT_BEFORE) {
+                // p_{J-1}[kk] = (G[kk_{J-1}][kk] - sum_l L[J-1][l] w_l) / rho_{J-1}
+                float acc = gsv;
+#pragma unroll
+                for (int l = 0; l < J - 1; ++l) acc = fmaf(-s.wv[l], w[l], acc);
+                w[J - 1] = acc * s.invv;
+                sc[J * KMAX + J - 1] = w[J - 1];
+            }
+        }
+        // the first two chunks of the LDS-resident vectors, queued BEHIND the extraction reads (LDS returns in order)
+        if ((OPT & 4) && more) {
+            if constexpr (NLJ > 0) {
+                asm("" : "+v"(s.laneoff) : "s"(kk));  // not before kk is known (i.e. not above the argmax)
+#pragma unroll
+                for (int i = 0; i < NLJ; ++i) buf[0][i] = lds_chunk<C>(s.laneoff, i, 0);
+                if constexpr (C > 1) {
+#pragma unroll
+                    for (int i = 0; i < NLJ; ++i) buf[1][i] = lds_chunk<C>(s.laneoff, i, 1);
+                }
+            }
+        }
+        // ---- Cholesky pivot: unit Gram diagonal hard-coded by batch_omp (:333-349); 'omp' uses G[kk][kk] (:44-52)
+        float vs = gkk;
+#pragma unroll
+        for (int i = 0; i < J; ++i) vs = fmaf(-w[i], w[i], vs);
+        if (J > 0 || !unit_diag) stop |= (__ballot(vs < EPS32_F * gkk) != 0ull) ? 1 : 0;  // reference: vs < eps (:335,345)
+        const float inv = __builtin_amdgcn_rsqf(vs);  // 1 ulp (see bomp.hip)
+        float t = akk * inv;
+        W2_STAMP_V(2, t);
+        sc[S::SC_T + J] = t;
+        sc[S::SC_I + J] = inv;
+        s.dxv = __builtin_bit_cast(int, writelane_sgpr(__builtin_bit_cast(float, s.dxv), __builtin_bit_cast(float, kk), J));
+
+        // ---- vector update: p_J = (G[kk,:] - sum_i w_i p_i) / rho,  a -= t p_J
+        if constexpr (J + 1 < KMAX) {
+            if (more) {
+                constexpr bool STORE = (J < NS);
+                const float tt = STORE ? t : t * inv;  // an unstored p_J is never scaled: a -= (t / rho) * acc
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    f32x4 acc = g[c];
+#pragma unroll
+                    for (int i = NLDS; i < NRJ; ++i) {
+                        const f32x4 pv = f32x4{s.p[i - NLDS][4 * c], s.p[i - NLDS][4 * c + 1], s.p[i - NLDS][4 * c + 2],
+                                               s.p[i - NLDS][4 * c + 3]};
+                        fma4(acc, -w[i], pv);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NLJ; ++i) fma4(acc, -w[i], buf[c & 1][i]);
+                    if constexpr (STORE) {
+                        acc *= inv;
+                        if constexpr (J < NLDS) {
+                            lds[(J * C + c) * 64 + lane] = acc;
+                        } else {
+                            s.p[J - NLDS][4 * c] = acc.x;
+                            s.p[J - NLDS][4 * c + 1] = acc.y;
+                            s.p[J - NLDS][4 * c + 2] = acc.z;
+                            s.p[J - NLDS][4 * c + 3] = acc.w;
+                        }
+                    }
+                    f32x4 av = {s.a[4 * c], s.a[4 * c + 1], s.a[4 * c + 2], s.a[4 * c + 3]};
+                    fma4(av, -tt, acc);
+                    s.a[4 * c] = av.x;
+                    s.a[4 * c + 1] = av.y;
+                    s.a[4 * c + 2] = av.z;
+                    s.a[4 * c + 3] = av.w;
+                    if constexpr (NLJ > 0) {
+                        if (c + 2 < C) {
+                            // chunk c+2 of the LDS vectors reuses chunk c's buffer: issue once chunk c is done
+                            asm("" : "+v"(s.laneoff) : "v"(av.x));
+#pragma unroll
+                            for (int i = 0; i < NLJ; ++i) buf[c & 1][i] = lds_chunk<C>(s.laneoff, i, c + 2);
+                        }
+                    }
+                }
+                if constexpr (!STORE) {
+                    // the last selection needs p_J[kk]: keep this step's row of L, 1/rho and the atom
+                    s.kkv = kk;
+                    s.invv = inv;
+#pragma unroll
+                    for (int l = 0; l < J; ++l) s.wv[l] = w[l];
+                }
+            }
+        }
+        // keep the update above the exit: without this the optimiser sinks the whole vector update (and the Gram-row
+        // load with it) below the branch, i.e. behind the extraction chain
+        asm volatile("" : "+v"(s.a));
+        if constexpr (STAMP) {
+            float a0 = s.a[0];
+            W2_STAMP_V(3, a0);
+            s.a[0] = a0;
+        }
+        if (stop) return;
+        s.nsel = J + 1;
+        steps<R, KMAX, NLDS, NV, J + 1, FAST, STAMP, OPT>(s, G, k, lane, lds, sc, unit_diag_rt);
+    }
+}
+
+// BW = waves per workgroup, WPS = waves per SIMD the register budget is bounded for
+template <int R, int KMAX, int WPS, int NLDS, int NV, bool FAST, int BW = 4, bool STAMP = false, int OPT = 0>
+__global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* __restrict__ alpha0,
+                                                                  const float* __restrict__ G, int64_t N, int k,
+                                                                  int32_t* __restrict__ idx_out,
+                                                                  float* __restrict__ coef_out,
+                                                                  int32_t* __restrict__ nnz_out, int unit_diag) {
+    using L = Lay<R>;
+    using S = State<R, KMAX, NLDS, NV>;
+    constexpr int C = L::C;
+    __shared__ f32x4 s_p[NLDS > 0 ? BW * NLDS * C * 64 : 1];
+    __shared__ float s_sc[BW * S::SC_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int64_t sig = (int64_t)blockIdx.x * BW + wid;
+    if (sig >= N) return;
+    float* sc = s_sc + wid * S::SC_FLOATS;
+
+    S s;
+    {
+        f32x4 a4[C];
+        load_row4<R, true>(alpha0 + sig * L::Kp, lane, a4);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            s.a[4 * c] = a4[c].x;
+            s.a[4 * c + 1] = a4[c].y;
+            s.a[4 * c + 2] = a4[c].z;
+            s.a[4 * c + 3] = a4[c].w;
+        }
+    }
+    s.m0 = 0u;
+    s.dxv = -1;
+    s.nsel = 0;
+    s.kkv = 0;
+    s.invv = 0.f;
+    s.laneoff = (unsigned)(uintptr_t)((lds_f32x4*)(s_p + wid * (NLDS * C * 64) + lane));  // generic -> LDS address
+    unsigned long long tstart = 0;
+    if constexpr (STAMP) {
+        s.cyc[0] = s.cyc[1] = s.cyc[2] = s.cyc[3] = 0;
+        tstart = __builtin_amdgcn_s_memtime();
+        float a0 = s.a[0];
+        s.tlast = stamp_v(a0);  // alpha0 row has landed
+        s.a[0] = a0;
+    }
+    steps<R, KMAX, NLDS, NV, 0, FAST, STAMP, OPT>(s, G, k, lane, s_p + wid * (NLDS * C * 64), sc, unit_diag);
+    const int nsel = s.nsel;
+
+    // z = L^-T t  (second triangular solve, sparse_coding.py:354), column-oriented over lanes: lane i of zv ends up as
+    // t_i - sum_{j>i} L[j][i] z_j, so z = zv * rinv.  L, t and 1/rho come back from the wave's LDS scalar area with
+    // lane-indexed reads (entries of selections that never happened are garbage and masked out).
+    const int li = lane < KMAX ? lane : KMAX - 1;
+    const float tv = sc[S::SC_T + li];
+    const float rinv = sc[S::SC_I + li];
+    float rows[KMAX];
+#pragma unroll
+    for (int j = 1; j < KMAX; ++j) rows[j] = sc[j * KMAX + li];
+    float zv = lane < nsel ? tv : 0.f;
+#pragma unroll
+    for (int j = KMAX - 1; j >= 1; --j) {
+        if (j < nsel) {
+            const float row = (lane < j) ? rows[j] : 0.f;
+            const float zj = readlane_f(zv * rinv, j);
+            zv = fmaf(-zj, row, zv);
+        }
+    }
+    float zout = zv * rinv;
+    if constexpr (STAMP) {
+        // diagnostics instead of coefficients: slot 0 = cycles waiting for the alpha0 row, 1..4 = the four phases summed
+        // over the steps, 5 = back-substitution
+        const unsigned long long tend = stamp_v(zout);
+        const unsigned c0 = (unsigned)(s.tlast - tstart) - (s.cyc[0] + s.cyc[1] + s.cyc[2] + s.cyc[3]);
+        zout = lane == 0 ? (float)c0 : lane == 1 ? (float)s.cyc[0] : lane == 2 ? (float)s.cyc[1] : lane == 3 ? (float)s.cyc[2]
+               : lane == 4 ? (float)s.cyc[3] : (float)(unsigned)(tend - s.tlast);
+        if (lane < k) coef_out[sig * k + lane] = zout;
+        if (lane < k) idx_out[sig * k + lane] = (lane < nsel) ? s.dxv : -1;
+        if (lane == 0) nnz_out[sig] = nsel;
+        return;
+    }
+    if (lane < k) {
+        idx_out[sig * k + lane] = (lane < nsel) ? s.dxv : -1;
+        coef_out[sig * k + lane] = (lane < nsel) ? zout : 0.f;
+    }
+    if (lane == 0) nnz_out[sig] = nsel;
+}
+
+}  // namespace w2
+}  // namespace lys
