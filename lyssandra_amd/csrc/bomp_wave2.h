@@ -89,14 +89,6 @@ __device__ __forceinline__ unsigned long long stamp_v(float& dep) {
         s.tlast = t_;                                                  \
     }
 
-// (bit `pos` of the lane mask set) ? a : b on the scalar unit: s_bitcmp1_b64 + s_cselect_b32 (the C++ form compiles to
-// a 64-bit shift, an and and a compare)
-__device__ __forceinline__ int bit_select(unsigned long long mask, int pos, int a, int b) {
-    int r;
-    asm("s_bitcmp1_b64 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(mask), "s"(pos), "s"(a), "s"(b) : "scc");
-    return r;
-}
-
 // argmax |a| over the wave, first (lowest atom index) maximum wins like np.argmax (sparse_coding.py:322).
 //
 // Every VALU instruction of a wave64 costs the SIMD ~4 cycles whatever it does (PMC: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
@@ -110,35 +102,22 @@ __device__ __forceinline__ int bit_select(unsigned long long mask, int pos, int 
 //   F_e   = lanes whose element e of the owner's group equals the lane maximum (group read through the index mode)
 // Atom order is (chunk c, lane, element e), so "lowest chunk, then lowest lane, then lowest element" is exactly
 // np.argmax's first maximum, also when several lanes tie (duplicate atoms, zero signals): no separate slow path.
-template <int R, bool STAMP = false, int OPT = 0, class AV>
+template <int R, bool STAMP = false, class AV>
 __device__ __forceinline__ bool wave_argmax(const AV& a, int& kk, float& akk, int& Lown, int& rown, unsigned& mbits_out,
                                             unsigned long long* tmid = nullptr) {
     constexpr int NG = R / 4;
     float m4[NG];
 #pragma unroll
     for (int c = 0; c < NG; ++c) {
-        if constexpr (OPT & 2) {
-            // one statement per group: hipcc pads every asm statement with an s_nop before the next VALU reads its output
-            asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32_e64 %0, %0, |%4|"
-                : "=&v"(m4[c])
-                : "v"(a[4 * c]), "v"(a[4 * c + 1]), "v"(a[4 * c + 2]), "v"(a[4 * c + 3]));
-        } else {
-            float t3;
-            asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t3) : "v"(a[4 * c]), "v"(a[4 * c + 1]), "v"(a[4 * c + 2]));
-            asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(m4[c]) : "v"(t3), "v"(a[4 * c + 3]));
-        }
+        float t3;
+        asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t3) : "v"(a[4 * c]), "v"(a[4 * c + 1]), "v"(a[4 * c + 2]));
+        asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(m4[c]) : "v"(t3), "v"(a[4 * c + 3]));
     }
     float best = m4[0];
     if constexpr (NG == 4) {
-        if constexpr (OPT & 2) {
-            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32_e32 %0, %0, %4"
-                : "=&v"(best)
-                : "v"(m4[0]), "v"(m4[1]), "v"(m4[2]), "v"(m4[3]));
-        } else {
-            float t3;
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(m4[0]), "v"(m4[1]), "v"(m4[2]));
-            asm("v_max_f32_e32 %0, %1, %2" : "=v"(best) : "v"(t3), "v"(m4[3]));
-        }
+        float t3;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(m4[0]), "v"(m4[1]), "v"(m4[2]));
+        asm("v_max_f32_e32 %0, %1, %2" : "=v"(best) : "v"(t3), "v"(m4[3]));
     } else if constexpr (NG == 2) {
         asm("v_max_f32_e32 %0, %1, %2" : "=v"(best) : "v"(m4[0]), "v"(m4[1]));
     }
@@ -151,46 +130,33 @@ __device__ __forceinline__ bool wave_argmax(const AV& a, int& kk, float& akk, in
     mbits_out = mbits;
     const unsigned long long bal = __ballot(best == m);
     if (bal == 0ull) return false;  // NaN correlations: nothing sensible to select
-    int Lo = __builtin_ctzll(bal);
+    // the first chunk that holds the maximum in any lane, then its lowest lane
+    unsigned long long T = bal;
     int csel = NG - 1;
-    if ((OPT & 1) && __popcll(bal) == 1) {
-        // a single lane owns the maximum (all but duplicate-atom / zero-signal cases): its first group
 #pragma unroll
-        for (int c = NG - 2; c >= 0; --c) csel = bit_select(E[c], Lo, c, csel);
-    } else {
-        // several lanes tie: the first chunk that holds the maximum in any of them, then its lowest lane
-        unsigned long long T = bal;
-#pragma unroll
-        for (int c = NG - 2; c >= 0; --c) {
-            const unsigned long long tc = E[c] & bal;
-            const bool ne = tc != 0ull;
-            T = ne ? tc : T;
-            csel = ne ? c : csel;
-        }
-        Lo = __builtin_ctzll(T);
+    for (int c = NG - 2; c >= 0; --c) {
+        const unsigned long long tc = E[c] & bal;
+        const bool ne = tc != 0ull;
+        T = ne ? tc : T;
+        csel = ne ? c : csel;
     }
+    const int Lo = __builtin_ctzll(T);
     // the owner's group, read with a run-time (wave-uniform) register index
-    float x[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = a[csel * 4 + e];
     int q = 3;
-    float val = x[3];
+    float x[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) x[e] = a[csel * 4 + e];
 #pragma unroll
     for (int e = 2; e >= 0; --e) {
         const unsigned long long fe = __ballot(fabsf(x[e]) == best);
-        if constexpr (OPT & 1) {
-            q = bit_select(fe, Lo, e, q);
-            val = (fabsf(x[e]) == best) ? x[e] : val;
-        } else {
-            const bool hit = ((fe >> Lo) & 1ull) != 0ull;  // wave-uniform
-            q = hit ? e : q;
-            val = hit ? x[e] : val;
-        }
+        const bool hit = ((fe >> Lo) & 1ull) != 0ull;  // wave-uniform
+        q = hit ? e : q;
     }
+    // one more indexed read for the signed value (a select chain over x[] costs three VALU instructions: -1.5 %)
+    akk = readlane_f(a[csel * 4 + q], Lo);
     Lown = Lo;
     rown = csel * 4 + q;
     kk = csel * 256 + Lo * 4 + q;
-    akk = readlane_f(val, Lo);
     return true;
 }
 
@@ -225,7 +191,7 @@ __device__ __forceinline__ f32x4 lds_chunk(unsigned addr, int i, int c) {
 
 // Steps J..KMAX-1 as a compile-time recursion (see bomp.hip: loops with early exits around convergent cross-lane
 // operations are not unrolled, which would push the state to scratch).
-template <int R, int KMAX, int NLDS, int NV, int J, bool FAST, bool STAMP = false, int OPT = 0>
+template <int R, int KMAX, int NLDS, int NV, int J, bool FAST, bool STAMP = false>
 __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* __restrict__ G, int k, int lane,
                                       f32x4* __restrict__ lds /* [NLDS][C][64] of this wave */,
                                       float* __restrict__ sc /* scalar area of this wave */, int unit_diag_rt) {
@@ -240,7 +206,7 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
         float akk;
         unsigned mbits;
         unsigned long long tmid = 0;
-        if (!wave_argmax<R, STAMP, OPT>(s.a, kk, akk, Lown, rown, mbits, &tmid)) return;
+        if (!wave_argmax<R, STAMP>(s.a, kk, akk, Lown, rown, mbits, &tmid)) return;
         if constexpr (STAMP) {
             s.cyc[0] += (unsigned)(tmid - s.tlast);
             s.tlast = tmid;
@@ -270,8 +236,9 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
         f32x4 g[C];
         f32x4 buf[2][NLJ > 0 ? NLJ : 1];
         if (more) load_row4<R, false>(grow, lane, g);
-        // the first two chunks of the LDS-resident vectors: ahead of (OPT & 4: behind) the extraction reads
-        if (!(OPT & 4) && more) {
+        // the first two chunks of the LDS-resident vectors (measured: queueing them behind the extraction reads instead
+        // bought nothing)
+        if (more) {
             if constexpr (NLJ > 0) {
                 asm("" : "+v"(s.laneoff) : "s"(kk));  // not before kk is known (i.e. not above the argmax)
 #pragma unroll
@@ -317,18 +284,6 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
                 sc[J * KMAX + J - 1] = w[J - 1];
             }
         }
-        // the first two chunks of the LDS-resident vectors, queued BEHIND the extraction reads (LDS returns in order)
-        if ((OPT & 4) && more) {
-            if constexpr (NLJ > 0) {
-                asm("" : "+v"(s.laneoff) : "s"(kk));  // not before kk is known (i.e. not above the argmax)
-#pragma unroll
-                for (int i = 0; i < NLJ; ++i) buf[0][i] = lds_chunk<C>(s.laneoff, i, 0);
-                if constexpr (C > 1) {
-#pragma unroll
-                    for (int i = 0; i < NLJ; ++i) buf[1][i] = lds_chunk<C>(s.laneoff, i, 1);
-                }
-            }
-        }
         // ---- Cholesky pivot: unit Gram diagonal hard-coded by batch_omp (:333-349); 'omp' uses G[kk][kk] (:44-52)
         float vs = gkk;
 #pragma unroll
@@ -344,6 +299,9 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
         // ---- vector update: p_J = (G[kk,:] - sum_i w_i p_i) / rho,  a -= t p_J
         if constexpr (J + 1 < KMAX) {
             if (more) {
+                // the FMA burst can wait for its issue slots; the chain (argmax -> lookup -> extraction) of another wave cannot:
+                // priority 3 from the end of the update to the start of the next one (measured +1.5 %)
+                __builtin_amdgcn_s_setprio(0);
                 constexpr bool STORE = (J < NS);
                 const float tt = STORE ? t : t * inv;  // an unstored p_J is never scaled: a -= (t / rho) * acc
 #pragma unroll
@@ -358,7 +316,7 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
 #pragma unroll
                     for (int i = 0; i < NLJ; ++i) fma4(acc, -w[i], buf[c & 1][i]);
                     if constexpr (STORE) {
-                        acc *= inv;
+                        if constexpr (!(FAST && J == 0)) acc *= inv;  // J = 0, unit diagonal: vs = 1, rsq(1) = 1 exactly
                         if constexpr (J < NLDS) {
                             lds[(J * C + c) * 64 + lane] = acc;
                         } else {
@@ -395,6 +353,7 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
         // keep the update above the exit: without this the optimiser sinks the whole vector update (and the Gram-row
         // load with it) below the branch, i.e. behind the extraction chain
         asm volatile("" : "+v"(s.a));
+        __builtin_amdgcn_s_setprio(3);
         if constexpr (STAMP) {
             float a0 = s.a[0];
             W2_STAMP_V(3, a0);
@@ -402,46 +361,26 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
         }
         if (stop) return;
         s.nsel = J + 1;
-        steps<R, KMAX, NLDS, NV, J + 1, FAST, STAMP, OPT>(s, G, k, lane, lds, sc, unit_diag_rt);
+        steps<R, KMAX, NLDS, NV, J + 1, FAST, STAMP>(s, G, k, lane, lds, sc, unit_diag_rt);
     }
 }
 
-// BW = waves per workgroup, WPS = waves per SIMD the register budget is bounded for
-template <int R, int KMAX, int WPS, int NLDS, int NV, bool FAST, int BW = 4, bool STAMP = false, int OPT = 0>
-__global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* __restrict__ alpha0,
-                                                                  const float* __restrict__ G, int64_t N, int k,
-                                                                  int32_t* __restrict__ idx_out,
-                                                                  float* __restrict__ coef_out,
-                                                                  int32_t* __restrict__ nnz_out, int unit_diag) {
+// One signal on one wave: `s.a` holds its alpha0 row; greedy steps, back-substitution, outputs.
+template <int R, int KMAX, int NLDS, int NV, bool FAST, bool STAMP>
+__device__ __forceinline__ void run_signal(State<R, KMAX, NLDS, NV>& s, const float* __restrict__ G, int64_t sig, int k,
+                                           int lane, f32x4* __restrict__ lds_wave, float* __restrict__ sc,
+                                           int32_t* __restrict__ idx_out, float* __restrict__ coef_out,
+                                           int32_t* __restrict__ nnz_out, int unit_diag) {
     using L = Lay<R>;
     using S = State<R, KMAX, NLDS, NV>;
     constexpr int C = L::C;
-    __shared__ f32x4 s_p[NLDS > 0 ? BW * NLDS * C * 64 : 1];
-    __shared__ float s_sc[BW * S::SC_FLOATS];
-    const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
-    const int64_t sig = (int64_t)blockIdx.x * BW + wid;
-    if (sig >= N) return;
-    float* sc = s_sc + wid * S::SC_FLOATS;
-
-    S s;
-    {
-        f32x4 a4[C];
-        load_row4<R, true>(alpha0 + sig * L::Kp, lane, a4);
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            s.a[4 * c] = a4[c].x;
-            s.a[4 * c + 1] = a4[c].y;
-            s.a[4 * c + 2] = a4[c].z;
-            s.a[4 * c + 3] = a4[c].w;
-        }
-    }
+    __builtin_amdgcn_s_setprio(3);
     s.m0 = 0u;
     s.dxv = -1;
     s.nsel = 0;
     s.kkv = 0;
     s.invv = 0.f;
-    s.laneoff = (unsigned)(uintptr_t)((lds_f32x4*)(s_p + wid * (NLDS * C * 64) + lane));  // generic -> LDS address
+    s.laneoff = (unsigned)(uintptr_t)((lds_f32x4*)(lds_wave + lane));  // generic -> LDS address
     unsigned long long tstart = 0;
     if constexpr (STAMP) {
         s.cyc[0] = s.cyc[1] = s.cyc[2] = s.cyc[3] = 0;
@@ -450,7 +389,7 @@ __global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* _
         s.tlast = stamp_v(a0);  // alpha0 row has landed
         s.a[0] = a0;
     }
-    steps<R, KMAX, NLDS, NV, 0, FAST, STAMP, OPT>(s, G, k, lane, s_p + wid * (NLDS * C * 64), sc, unit_diag);
+    steps<R, KMAX, NLDS, NV, 0, FAST, STAMP>(s, G, k, lane, lds_wave, sc, unit_diag);
     const int nsel = s.nsel;
 
     // z = L^-T t  (second triangular solve, sparse_coding.py:354), column-oriented over lanes: lane i of zv ends up as
@@ -489,6 +428,41 @@ __global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* _
         coef_out[sig * k + lane] = (lane < nsel) ? zout : 0.f;
     }
     if (lane == 0) nnz_out[sig] = nsel;
+}
+
+// BW = waves per workgroup, WPS = waves per SIMD the register budget is bounded for.
+// (A persistent form -- grid sized to the chip, every wave walking signals wave, wave + #waves, ... with the NEXT
+// signal's alpha0 row fetched by LDS-DMA (global_load_lds_dwordx4) into a 4-KB slot of the wave -- was built and measured
+// in round 3: correct, 13 % SLOWER.  While an LDS-DMA is in flight hipcc turns every counted s_waitcnt vmcnt(N) of the
+// Gram-row loads into vmcnt(0), and the loop costs 4 spilled VGPRs; the ~950 cycles a fresh wave waits for its row
+// (5 % of its life) stay.)
+template <int R, int KMAX, int WPS, int NLDS, int NV, bool FAST, int BW = 4, bool STAMP = false>
+__global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* __restrict__ alpha0,
+                                                                  const float* __restrict__ G, int64_t N, int k,
+                                                                  int32_t* __restrict__ idx_out,
+                                                                  float* __restrict__ coef_out,
+                                                                  int32_t* __restrict__ nnz_out, int unit_diag) {
+    using L = Lay<R>;
+    using S = State<R, KMAX, NLDS, NV>;
+    constexpr int C = L::C;
+    __shared__ f32x4 s_p[NLDS > 0 ? BW * NLDS * C * 64 : 1];
+    __shared__ float s_sc[BW * S::SC_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int64_t sig = (int64_t)blockIdx.x * BW + wid;
+    if (sig >= N) return;
+    S s;
+    f32x4 a4[C];
+    load_row4<R, true>(alpha0 + sig * L::Kp, lane, a4);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        s.a[4 * c] = a4[c].x;
+        s.a[4 * c + 1] = a4[c].y;
+        s.a[4 * c + 2] = a4[c].z;
+        s.a[4 * c + 3] = a4[c].w;
+    }
+    run_signal<R, KMAX, NLDS, NV, FAST, STAMP>(s, G, sig, k, lane, s_p + wid * (NLDS * C * 64), s_sc + wid * S::SC_FLOATS,
+                                               idx_out, coef_out, nnz_out, unit_diag);
 }
 
 }  // namespace w2

@@ -63,14 +63,14 @@ for v in variants:
 order = [-1] + [v for v in variants if v in names]
 times = {v: [] for v in order}
 o = outs()
-for rnd in range(10):
+for rnd in range(24):
     for v in order:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         run(v, o)
         e1.record()
         torch.cuda.synchronize()
-        if rnd >= 2:
+        if rnd >= 4:
             times[v].append(e0.elapsed_time(e1))
 for v in order:
     t = sorted(times[v])
