@@ -12,13 +12,18 @@ its own S patches against the replicated dictionary, no data-path collective (we
 value = N*S*K_steps / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline       -- dominant kernel (greedy/Cholesky stage) priced against the fp32 MFMA/VALU peak with HIP-event
-                    durations taken inside the timed region (and the rocprofv3 average of the same kernel from
-                    profiles/kernel_durations.json beside it); also the GEMM stage and the whole step
+  roofline       -- dominant kernel (greedy/Cholesky stage, a VALU kernel) priced against the fp32 vector peak with
+                    HIP-event durations taken inside the timed region (the rocprofv3 average of the same kernel recorded
+                    in profiles/kernel_durations.json beside it, labelled as recorded); also the GEMM stage (fp32-equivalent
+                    FLOP, bf16-MFMA utilisation and HBM store rate) and the whole step; counter traffic against SURVEY 8(d)
+                    bytes
   cpu_baseline   -- the float64 numpy port of the reference path (oracle/) timed on this host's cores on a bounded
                     sample of the same workload (rank 0, N=1 only); the all-cores figures sit beside it as flat keys
   ksvd_iteration -- auxiliary (not part of `value`): one approx-K-SVD alternation of configs[1] per stage; for N > 1
-                    the sweep runs sharded with its per-block statistics all-reduce and `exchange` is its cost
+                    the sweep runs sharded with its per-block statistics all-reduce and `exchange` is its cost;
+                    `fifty_iterations` = configs[1] as BASELINE.md states it (50 encode + sweep alternations, wall time)
+  config3_shard  -- auxiliary, N = 1: Batch-OMP at configs[2]'s shape (256-dim, 4096 atoms, k = 20) with its own roofline
+  config4_minibatch -- auxiliary, N = 1: one online-DL mini-batch at configs[3]'s shape (128-dim, 8192 atoms, LARS coder)
   odl_batch      -- auxiliary, N > 1 only: one online-DL mini-batch (statistics, [upper(ZZ') | XZ'] all-reduce, update)
 """
 import argparse
@@ -33,7 +38,9 @@ sys.path.insert(0, ROOT)
 
 N_FEATURES, N_ATOMS, K_NNZ = 64, 1024, 10
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
+PEAK_BF16_TFLOPS = 2500.0         # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: aggregate L2 bandwidth
 SEED_SIGNALS, SEED_DICTIONARY = 20260928, 1234
 
 
@@ -50,6 +57,7 @@ def main():
     ap.add_argument("--patches-per-gpu", dest="signals", type=int, default=1 << 20, help="patches per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ksvd", action="store_true", help="skip the auxiliary approx-K-SVD iteration timing")
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary configs[2] / configs[3] legs")
     ap.add_argument("--cpu-sample", type=int, default=8000)
     ap.add_argument("--cpu-pool-workers", type=int, default=-1,
                     help="processes for the all-cores CPU baseline (-1 = min(host cpus, 64), 0 = skip)")
@@ -147,13 +155,18 @@ def main():
         omp_tf = f_omp * sig_per_launch / (omp_avg_ms * 1e-3) / 1e12 if omp_avg_ms > 0 else 0.0
         gemm_tf = f_gemm * sig_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms > 0 else 0.0
         step_tf = (f_gemm + f_omp) * (value / world) / 1e12
-        traffic = None
+        traffic = gemm_traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bomp_wave_kernel_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("bomp_wave_kernel_bytes_per_launch")
+                gemm_traffic = tj.get("alpha0_n64_kernel_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic = gemm_traffic = None
+        bf16x3 = os.environ.get("LYS_ALPHA0_BF16X3", "1") != "0"
+        bytes_8d = 4 * n + 8 * k                                  # patch in, k (index, coefficient) pairs out
+        store_gbs = 4.0 * _lib.padded_atoms(K) * sig_per_launch / (gemm_avg_ms * 1e-3) / 1e9 if gemm_avg_ms > 0 else 0.0
         # rocprofv3 --kernel-trace averages of the same kernels on the same command (tools/profile.sh writes the file,
         # it is committed under profiles/): the HIP-event figure above must agree with it
         rocprof = {}
@@ -174,7 +187,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (alpha0: every fp32 operand split into 3 bf16 planes, 6 products on the bf16 matrix cores, fp32 "
+                     "accumulate = fp32 accuracy; greedy stage: fp32 VALU)"
+                     if os.environ.get("LYS_ALPHA0_BF16X3", "1") != "0" else "f32",
             "data": "synthetic (Philox4x32-10 Gaussian patches, lys_synth_signals; random unit-norm dictionary)",
             "config": {"workload": "Batch-OMP encode step of configs[1] (approx-K-SVD 1M 8x8 patches): n=64, K=1024 "
                                    "atoms, k=10, %d Gaussian patches per GPU per step, device-resident sparse output" % S,
@@ -182,27 +197,42 @@ def main():
                        "sharding": "signals sharded over %d rank(s), dictionary replicated, no data-path collective"
                                    % world},
             "roofline": {
-                "bound": "mfma",
-                "kernel": "bomp_wave_kernel<16,10> (greedy argmax + progressive Cholesky, one wave per signal)",
+                # the contract's vocabulary is "hbm" | "mfma"; this kernel issues no MFMA (SQ_INSTS_MFMA = 0): it is bound by
+                # VALU issue, and the fp32 vector peak equals the fp32 matrix peak (157.3 TFLOP/s)
+                "bound": "valu",
+                "kernel": "w2::bomp_wave2_kernel<16,10,3,2,1> (greedy argmax + progressive Cholesky, one wave per signal; "
+                          "2 vectors in LDS, the last one never stored)",
                 "achieved": omp_tf,
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": omp_tf / PEAK_FP32_TFLOPS,
                 "traffic": traffic,
+                "bytes_8d_per_launch": bytes_8d * sig_per_launch,
+                "traffic_ratio_8d": (traffic / (bytes_8d * sig_per_launch)) if traffic else None,
+                "traffic_ratio_8d_whole_step": ((traffic + gemm_traffic) / (bytes_8d * sig_per_launch))
+                if (traffic and gemm_traffic) else None,
+                "traffic_note": "counter bytes (PMC passes of profiles/, FETCH_SIZE doubled per MI355X_MICROARCH.md) over SURVEY "
+                                "8(d)'s B = 4n + 8k bytes per patch; the alpha0 hand-off (4 KB per patch written by the GEMM and "
+                                "read by this kernel) is what 8(d) does not count",
                 "flop_per_patch": f_omp,
                 "patches_per_launch": sig_per_launch,
                 "avg_launch_ms": omp_avg_ms,
-                "rocprof_avg_launch_ms": rocprof.get("bomp_wave_kernel_avg_ms"),
-                "rocprof_source": rocprof.get("source"),
+                "rocprof_recorded_avg_launch_ms": rocprof.get("bomp_wave_kernel_avg_ms"),
+                "rocprof_recorded_source": rocprof.get("source"),
                 "launches_timed": launches.value,
                 "gemm_stage": {"kernel": "alpha0_n64_bf16x3_kernel (alpha0 = X D at fp32 accuracy on the bf16 matrix cores: three "
                                          "bf16 planes per operand, six v_mfma_f32_32x32x16_bf16 products; software-pipelined "
-                                         "buffer stores; fp32-equivalent FLOP against the fp32 matrix peak)"
-                               if os.environ.get("LYS_ALPHA0_BF16X3", "1") != "0" else
+                                         "buffer stores)"
+                               if bf16x3 else
                                "alpha0_n64_kernel (alpha0 = X D, v_mfma_f32_32x32x2_f32, software-pipelined buffer stores)",
+                               "bound": "hbm (store stream of the alpha0 hand-off)",
+                               "fp32_equivalent_tflops": gemm_tf, "fp32_equivalent_frac": gemm_tf / PEAK_FP32_TFLOPS,
+                               "bf16_mfma_tflops": 6.0 * gemm_tf if bf16x3 else None,
+                               "bf16_mfma_frac": 6.0 * gemm_tf / PEAK_BF16_TFLOPS if bf16x3 else None,
+                               "hbm_store_gbs": store_gbs, "hbm_store_frac": store_gbs / PEAK_HBM_GBS,
                                "achieved": gemm_tf, "frac": gemm_tf / PEAK_FP32_TFLOPS, "flop_per_patch": f_gemm,
                                "avg_launch_ms": gemm_avg_ms,
-                               "rocprof_avg_launch_ms": rocprof.get("alpha0_n64_kernel_avg_ms")},
+                               "rocprof_recorded_avg_launch_ms": rocprof.get("alpha0_n64_kernel_avg_ms")},
                 "whole_step": {"achieved": step_tf, "frac": step_tf / PEAK_FP32_TFLOPS,
                                "flop_per_patch": f_gemm + f_omp},
             },
@@ -223,9 +253,21 @@ def main():
                 ob = {"error": repr(e)}
             if rank == 0:
                 result["odl_batch"] = ob
+    if world == 1 and not args.no_aux:
+        for name, fn in (("config3_shard", config3_shard), ("config4_minibatch", config4_minibatch)):
+            try:
+                result[name] = fn(synth)
+            except Exception as e:  # pragma: no cover
+                result[name] = {"error": repr(e)}
+            engine.release_workspaces()
+            torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(Xs.shape[0], n, Dt, k, args.cpu_sample, args.cpu_pool_workers)
+            try:
+                result["cpu_baseline"].update(cpu_ksvd_sweep(Xs, n, K, k))
+            except Exception as e:  # pragma: no cover
+                result["cpu_baseline"]["ksvd_sweep_error"] = repr(e)
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
@@ -308,6 +350,29 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
                               "traffic_model": "12*n bytes per non-zero: the row is read for the statistics, read and "
                                                "written for the update"},
            "final_error": err}
+    # configs[1] as BASELINE.md states it: 50 alternations (encode, residual, sweep, error -- what ksvd_dict_learn runs per
+    # iteration, ksvd.py:169-229) driven directly on the device-resident batch, one synchronisation at the end
+    try:
+        n50 = 50
+        dd.set(D0.t().contiguous())
+        torch.cuda.synchronize()
+        if ws > 1:
+            torch.distributed.barrier(group=group)
+        t0 = time.perf_counter()
+        e50 = None
+        for it in range(n50):
+            out = engine.bomp_encode(Xs, dd, k, out=out)
+            idx, coef, nnz = out
+            R, _ = engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False, out=R)
+            engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group, buffers=buffers)
+            e50 = engine.approx_error(Xs, dd, idx, coef, nnz)
+        torch.cuda.synchronize()
+        t50 = (time.perf_counter() - t0) * 1e3
+        res["fifty_iterations"] = {"iterations": n50, "ms_total": t50, "ms_per_iteration": t50 / n50,
+                                   "final_error_this_rank": float(e50),
+                                   "note": "error evaluated (and read back) every iteration like the reference does"}
+    except Exception as e:  # pragma: no cover
+        res["fifty_iterations"] = {"error": repr(e)}
     if ws > 1:
         stride = engine.HipBlockKsvdOps(R, dd, idx, coef, nnz, buffers).stride
         res["exchange"] = {"collectives_per_sweep": nb, "bytes_per_collective": stride * 8,
@@ -359,6 +424,151 @@ def odl_batch(Xs, dd0, k, group, iters=3):
     return {"workload": "online-DL mini-batch of %d patches per GPU, K=%d, k=%d" % (Xs.shape[0], K, k),
             "ms": {kk: v / iters for kk, v in acc.items()},
             "exchange_bytes": packed * 4, "dense_bytes": (state.A.numel() + state.B.numel()) * 4}
+
+
+def _profiled_encode(fn, reps):
+    """Run fn() `reps` times with the library's per-stage HIP events on; returns (gemm ms, greedy ms, wall ms) per call."""
+    import torch
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    fn()
+    torch.cuda.synchronize()
+    _lib.check(lib.lys_profile_enable(1), "lys_profile_enable")
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3 / reps
+    g_ms, o_ms = ctypes.c_double(), ctypes.c_double()
+    launches, psig = ctypes.c_int(), ctypes.c_int64()
+    _lib.check(lib.lys_profile_collect(ctypes.byref(g_ms), ctypes.byref(o_ms), ctypes.byref(launches), ctypes.byref(psig)),
+               "lys_profile_collect")
+    _lib.check(lib.lys_profile_enable(0), "lys_profile_enable")
+    return g_ms.value / reps, o_ms.value / reps, wall
+
+
+def config3_shard(synth, N=1 << 17, reps=5):
+    """Auxiliary: Batch-OMP at configs[2]'s shape (16x16 = 256-dim patches, 4096 atoms, k = 20) on a slice of one GPU's
+    shard; the greedy stage is bomp_block_kernel (one 512-thread workgroup per signal), a VALU kernel."""
+    import torch
+    from lyssandra_amd import engine
+    n, K, k = 256, 4096, 20
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(SEED_SIGNALS + 3)
+    Xs = torch.randn((N, n), device=dev, generator=g)
+    D = torch.randn((n, K), device=dev, generator=g)
+    dd = engine.DeviceDictionary(n, K, dev)
+    dd.set(D / D.norm(dim=0, keepdim=True))
+    dd.gram()
+    out = (torch.empty((N, k), dtype=torch.int32, device=dev), torch.empty((N, k), dtype=torch.float32, device=dev),
+           torch.empty((N,), dtype=torch.int32, device=dev))
+    gemm_ms, omp_ms, wall_ms = _profiled_encode(lambda: engine.bomp_encode(Xs, dd, k, out=out), reps)
+    f_gemm, f_omp = flops_per_signal(n, K, k)
+    omp_tf = f_omp * N / (omp_ms * 1e-3) / 1e12
+    gemm_tf = f_gemm * N / (gemm_ms * 1e-3) / 1e12
+    return {"workload": "Batch-OMP encode, %d Gaussian 256-dim patches, 4096 atoms, k=20 (configs[2] per-GPU kernel shape), "
+                        "mean of %d calls" % (N, reps),
+            "value": N / (wall_ms * 1e-3), "unit": "patches/s", "ms_per_call": wall_ms,
+            "roofline": {"bound": "valu", "kernel": "bomp_block_kernel<8,20,2,512> (one 512-thread workgroup per signal)",
+                         "achieved": omp_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": omp_tf / PEAK_FP32_TFLOPS,
+                         "flop_per_patch": f_omp, "avg_launch_ms": omp_ms,
+                         "gemm_stage": {"kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": gemm_tf,
+                                        "frac": gemm_tf / PEAK_FP32_TFLOPS, "flop_per_patch": f_gemm,
+                                        "avg_launch_ms": gemm_ms}}}
+
+
+def config4_minibatch(synth, B=32768, lam=0.2, reps=3):
+    """Auxiliary: one online-DL mini-batch at configs[3]'s shape (unit-norm 128-dim descriptors, 8192 atoms, LARS-lasso
+    coder): the coder (alpha0 GEMM + lasso_lars_kernel + coordinate-descent polish) and the statistics + dictionary
+    update, timed separately with device synchronisation around each."""
+    import torch
+    from lyssandra_amd import engine
+    n, K = 128, 8192
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(SEED_SIGNALS + 4)
+    Xs = torch.randn((B, n), device=dev, generator=g)
+    Xs = Xs / Xs.norm(dim=1, keepdim=True)
+    D = torch.randn((n, K), device=dev, generator=g)
+    dd = engine.DeviceDictionary(n, K, dev)
+    dd.set(D / D.norm(dim=0, keepdim=True))
+    dd.gram()
+    state = engine.OdlState(dd)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, (time.perf_counter() - t0) * 1e3
+    t_code = t_upd = 0.0
+    nnz_mean = br_mean = 0.0
+    for it in range(reps + 1):
+        (idx, coef, nnz, steps, br), t_c = timed(lambda: engine.lasso_encode(Xs, dd, lam, return_steps=True, solver='lars',
+                                                                             return_breakpoints=True))
+        nnz_mean, br_mean = float(nnz.float().mean().item()), float(br.float().mean().item())
+        br_sq = float((br.float() * (br.float() + 1) / 2).mean().item())
+        dd_bak = dd.D.clone()
+        _, t_u = timed(lambda: state.batch_update(Xs, idx, coef, nnz, 0.9 if it else 0.0))
+        dd.D.copy_(dd_bak)          # the same coding problem every repetition
+        dd.invalidate()
+        dd.gram()
+        if it > 0:
+            t_code += t_c
+            t_upd += t_u
+    t_code /= reps
+    t_upd /= reps
+    # the coder's traffic model: every breakpoint re-reads the active Gram rows (Kp * 4 bytes each) out of L2
+    l2_bytes = br_sq * K * 4.0 * B
+    return {"workload": "online-DL mini-batch: %d unit-norm 128-dim descriptors, 8192 atoms, LARS-lasso lambda=%.2f "
+                        "(configs[3] per-GPU shape), mean of %d" % (B, lam, reps),
+            "ms": {"lars_coder": t_code, "statistics_and_update": t_upd},
+            "value": B / (t_code * 1e-3), "unit": "signals/s (coder)",
+            "mean_nnz": nnz_mean, "mean_breakpoints": br_mean,
+            "roofline": {"bound": "l2", "kernel": "lasso_lars_kernel (one workgroup per signal; active Gram rows re-read per "
+                                                  "breakpoint)",
+                         "achieved": l2_bytes / (t_code * 1e-3) / 1e9, "peak": PEAK_L2_GBS, "unit": "GB/s",
+                         "frac": l2_bytes / (t_code * 1e-3) / 1e9 / PEAK_L2_GBS,
+                         "bytes_model": "sum over breakpoints of |A| Gram rows of 4 K bytes = %.3g GB per mini-batch"
+                                        % (l2_bytes / 1e9)}}
+
+
+def cpu_ksvd_sweep(Xs, n, K, k, sample=1 << 17):
+    """The approx-K-SVD atom sweep (lyssa/dict_learning/ksvd.py:98-126) on the host beside the GPU's: float64 C restatement
+    (oracle/bomp_oracle.c::lyso_approx_ksvd, OpenMP inside every atom's accumulate / apply loops) on the first `sample`
+    patches of the batch with the codes the GPU produced for them."""
+    import numpy as np
+    import torch
+    from lyssandra_amd import engine
+    from oracle import c_oracle
+    S = min(sample, Xs.shape[0])
+    dd = engine.DeviceDictionary(n, K, Xs.device)
+    D0 = (Xs[:K] / Xs[:K].norm(dim=1, keepdim=True)).contiguous()
+    dd.set(D0.t().contiguous())
+    idx, coef, nnz = engine.bomp_encode(Xs[:S], dd, k)
+    torch.cuda.synchronize()
+    X = np.ascontiguousarray(c_oracle.synth_signals(SEED_SIGNALS, 0, S, n).T.astype(np.float64))
+    D = D0.t().double().cpu().numpy()
+    hi, hc, hn = idx.cpu().numpy(), coef.double().cpu().numpy(), nnz.cpu().numpy()
+    c_oracle.approx_ksvd_sparse(X[:, :2048], D, hi[:2048], hc[:2048], hn[:2048])     # load + warm the library, untimed
+    t0 = time.perf_counter()
+    c_oracle.approx_ksvd_sparse(X, D, hi, hc, hn)
+    dt = time.perf_counter() - t0
+    # the same sweep on the GPU, same patches
+    R, _ = engine.residual(Xs[:S], dd, idx, coef, nnz, want_R=True, want_err=False)
+    buffers = {}
+    engine.ksvd_cycle(R.clone(), dd, idx, coef.clone(), nnz, buffers=buffers)
+    dd.set(D0.t().contiguous())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    engine.ksvd_cycle(R, dd, idx, coef, nnz, buffers=buffers)
+    torch.cuda.synchronize()
+    dg = time.perf_counter() - t0
+    return {"ksvd_sweep_value": S / dt, "ksvd_sweep_unit": "patches/s through one atom sweep", "ksvd_sweep_cores": os.cpu_count(),
+            "ksvd_sweep_kind": "port",
+            "ksvd_sweep_sample": "first %d patches with the GPU's codes (%d non-zeros), float64 C restatement with OpenMP inside "
+                                 "every atom's loops, %.1f s; the GPU sweep on the same patches: %.2f ms"
+                                 % (S, int(hn.sum()), dt, dg * 1e3),
+            "ksvd_sweep_gpu_value": S / dg}
 
 
 def _cpu_worker(job):

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-ksvd"
+BENCH="python $PWD/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-ksvd --no-aux"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 # PMC passes: counters in their own runs (never combined with sys/hip trace domains)

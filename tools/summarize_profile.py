@@ -7,6 +7,7 @@ import sys
 root = sys.argv[1]
 json_out = sys.argv[2] if len(sys.argv) > 2 else None   # e.g. profiles/kernel_durations.json (read by bench.py)
 durations = {}
+pmc = {}   # kernel field -> counter -> per-dispatch average
 
 
 def short(name):
@@ -25,7 +26,8 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         for name, calls, tot, avg, pct in cur.execute(
                 "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 16"):
             print("%-86s %7d %14d %12.0f %7.2f" % (short(name), calls, tot, avg, pct))
-            for key, field in (("bomp_wave_kernel", "bomp_wave_kernel"), ("alpha0_n64_bf16x3_kernel", "alpha0_n64_kernel"),
+            for key, field in (("bomp_wave2_kernel", "bomp_wave_kernel"), ("bomp_wave_kernel", "bomp_wave_kernel"),
+                               ("alpha0_n64_bf16x3_kernel", "alpha0_n64_kernel"),
                                ("alpha0_n64_kernel", "alpha0_n64_kernel"), ("bksvd_step_kernel", "bksvd_step_kernel")):
                 if key in name and field + "_avg_ms" not in durations:
                     durations[field + "_avg_ms"] = avg / 1e3   # top_kernels.average is in us
@@ -42,6 +44,13 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         rows = {}
         for name, cname, tot, nd, dur in cur.execute(q):
             rows.setdefault(name, {"n": nd, "dur": dur})[cname] = tot / max(1, nd)
+        for name, r in rows.items():
+            for key, field in (("bomp_wave2_kernel", "bomp_wave_kernel"), ("bomp_wave_kernel", "bomp_wave_kernel"),
+                               ("alpha0_n64", "alpha0_n64_kernel"), ("bksvd_step_kernel", "bksvd_step_kernel"),
+                               ("bomp_block_kernel", "bomp_block_kernel"), ("lasso_lars_kernel", "lasso_lars_kernel")):
+                if key in name:
+                    pmc.setdefault(field, {}).update({c: v for c, v in r.items() if c not in ("n", "dur")})
+                    break
         for name in sorted(rows, key=lambda x: -rows[x]["n"])[:8]:
             r = rows[name]
             vals = ", ".join("%s=%.5g" % (c, v) for c, v in sorted(r.items()) if c not in ("n", "dur"))
@@ -49,5 +58,15 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
 
 if json_out:
     import json
+    # HBM bytes per launch from the separate FETCH_SIZE / WRITE_SIZE passes (KB units; FETCH_SIZE doubled: it under-counts wide
+    # coalesced reads by 2x on gfx950, MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated)
+    for field, c in pmc.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            durations[field + "_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            durations[field + "_fetch_size_kb"] = c["FETCH_SIZE"]
+            durations[field + "_write_size_kb"] = c["WRITE_SIZE"]
+        if "TCC_HIT_sum" in c:
+            durations[field + "_tcc_hit"] = c["TCC_HIT_sum"]
+            durations[field + "_tcc_miss"] = c.get("TCC_MISS_sum")
     durations["source"] = "rocprofv3 --kernel-trace --stats of `python bench.py` (tools/profile.sh), averages over all launches"
     json.dump(durations, open(json_out, "w"), indent=1)
