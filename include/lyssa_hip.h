@@ -377,6 +377,49 @@ int lys_ctx_bomp_encode(lys_ctx* ctx, const float* X_sig_major_host, int64_t N, 
                         int32_t* idx_host, float* coef_host, int32_t* nnz_host);
 int lys_ctx_bomp_encode_synthetic(lys_ctx* ctx, uint64_t seed, int64_t first, int64_t N, int k, double* stats4);
 int lys_ctx_timings(const lys_ctx* ctx, double* ms4);
+/*
+ * Several devices in ONE process: the context owns one stream per device and an RCCL communicator (ncclCommInitAll;
+ * librccl is loaded with dlopen on first use, single-device contexts never touch it).  Signals are sharded over the
+ * devices in contiguous equal ranges, the last device taking the remainder -- the column batches of the reference's
+ * `run_parallel(..., n_jobs=N)` / `gen_even_batches` (lyssa/utils/__init__.py:92-153, lyssa/sparse_coding.py:713-724) -- the
+ * dictionary is replicated, encode needs no collective; the dictionary updates below all-reduce their sufficient
+ * statistics.  LYS_CTX_FORCE_RCCL=1 creates the communicator also for one device (tests the RCCL path on a 1-GPU box).
+ */
+int lys_ctx_create_multi(int n_devices, const int* device_ids, lys_ctx** out);
+int lys_ctx_device_count(const lys_ctx* ctx);
+/* dictionary read-back [K][n] (atom-major) / replacement of one atom (unused-atom re-initialisation, ksvd.py:219-229) */
+int lys_ctx_get_dictionary(lys_ctx* ctx, float* D_atom_major_host);
+int lys_ctx_set_atom(lys_ctx* ctx, int atom, const float* column_host);
+/*
+ * Dictionary learning on signals that stay RESIDENT on the device(s) (lyssa/dict_learning/ksvd.py:169-229):
+ *   lys_ctx_set_signals      upload X_sig_major_host [N][n] once (sharded over the devices)
+ *   lys_ctx_encode_resident  Batch-OMP of the resident signals with the current dictionary; the codes stay resident
+ *   lys_ctx_ksvd_sweep       one approx-K-SVD cycle, ksvd.py:98-126: R = X - D Z, atoms 0..K-1 in order (block Gauss-Seidel
+ *                            sweep; per block of atoms ONE all-reduce of the statistics slab over the devices); updates
+ *                            the dictionary and the resident codes; *n_unused_host = atoms no signal uses (ksvd.py:111-115)
+ *   lys_ctx_get_unused       their indices (at most cap)
+ *   lys_ctx_error            ||X - D Z||_F^2 of the resident signals / codes (dict_learning/utils.py:14-19)
+ *   lys_ctx_get_codes        idx/coef [N][k], nnz [N] of the resident codes
+ */
+int lys_ctx_set_signals(lys_ctx* ctx, const float* X_sig_major_host, int64_t N);
+int lys_ctx_encode_resident(lys_ctx* ctx, int k);
+int lys_ctx_ksvd_sweep(lys_ctx* ctx, int* n_unused_host);
+int lys_ctx_get_unused(const lys_ctx* ctx, int32_t* atoms_host, int cap);
+int lys_ctx_error(lys_ctx* ctx, double* err_host);
+int lys_ctx_get_codes(lys_ctx* ctx, int32_t* idx_host, float* coef_host, int32_t* nnz_host);
+/*
+ * Online dictionary learning (lyssa/dict_learning/online_dict_learn.py:78-98):
+ *   lys_ctx_odl_reset        A = 0, B = 0
+ *   lys_ctx_odl_accumulate   one mini-batch X_sig_major_host [Nb][n]: Batch-OMP with k atoms, A = beta A + Z Z',
+ *                            B = beta B + X Z' (:84-85; one all-reduce of [Z Z' | X Z'] over the devices)
+ *   lys_ctx_odl_update       d_k += (B_k - D A_k) / (A_kk + eps), clip (non_neg), normalise (:91-98)
+ *   lys_ctx_get_ab / set_ab  A [K][K], B atom-major [K][n] (the transpose of the reference's (n, K) B): warm start
+ */
+int lys_ctx_odl_reset(lys_ctx* ctx);
+int lys_ctx_odl_accumulate(lys_ctx* ctx, const float* X_sig_major_host, int64_t Nb, int k, float beta);
+int lys_ctx_odl_update(lys_ctx* ctx, int non_neg);
+int lys_ctx_get_ab(lys_ctx* ctx, float* A_host, float* B_atom_major_host);
+int lys_ctx_set_ab(lys_ctx* ctx, const float* A_host, const float* B_atom_major_host);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,21 @@ SIGNATURES = {
     "lys_ctx_bomp_encode": (_I, [_P, _P, _L, _I, _P, _P, _P]),
     "lys_ctx_bomp_encode_synthetic": (_I, [_P, ctypes.c_uint64, _L, _L, _I, ctypes.POINTER(ctypes.c_double)]),
     "lys_ctx_timings": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
+    "lys_ctx_create_multi": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_P)]),
+    "lys_ctx_device_count": (_I, [_P]),
+    "lys_ctx_get_dictionary": (_I, [_P, _P]),
+    "lys_ctx_set_atom": (_I, [_P, _I, _P]),
+    "lys_ctx_set_signals": (_I, [_P, _P, _L]),
+    "lys_ctx_encode_resident": (_I, [_P, _I]),
+    "lys_ctx_ksvd_sweep": (_I, [_P, ctypes.POINTER(_I)]),
+    "lys_ctx_get_unused": (_I, [_P, _P, _I]),
+    "lys_ctx_error": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
+    "lys_ctx_get_codes": (_I, [_P, _P, _P, _P]),
+    "lys_ctx_odl_reset": (_I, [_P]),
+    "lys_ctx_odl_accumulate": (_I, [_P, _P, _L, _I, _F]),
+    "lys_ctx_odl_update": (_I, [_P, _I]),
+    "lys_ctx_get_ab": (_I, [_P, _P, _P]),
+    "lys_ctx_set_ab": (_I, [_P, _P, _P]),
 }
 
 

@@ -109,10 +109,21 @@ int densify_f64(const int32_t*, const float*, const int32_t*, int, int, int64_t,
 // hand-off inside the 256 MiB Infinity Cache (32768-signal tiles) bought nothing because the kernel is bound by
 // the latency of Gram-row fetches that miss L2, not by HBM bandwidth.  4 GiB of alpha0 per tile (2^20 signals at K = 1024;
 // measured against 1 GiB tiles: +1.2 % patches/s -- fewer launch ramps / tails; MI355X has 288 GB).
-static int64_t tile_signals(int Kp) {
+int64_t tile_signals(int Kp) {
     int64_t bytes = 4ll << 30;
     const char* e = getenv("LYS_TILE_MB");
-    if (e && atoi(e) > 0) bytes = (int64_t)atoi(e) << 20;
+    if (e && atoi(e) > 0) {
+        bytes = (int64_t)atoi(e) << 20;
+    } else {
+        // never more than a sixteenth of the device memory per tile (18 GB on a 288 GB MI355X: no effect there; on a
+        // smaller or busier device the 4 GiB default would otherwise pin a large share of it per stream)
+        static int64_t cap = -1;
+        if (cap < 0) {
+            size_t fr = 0, tot = 0;
+            cap = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) ? (int64_t)(tot / 16) : (4ll << 30);
+        }
+        if (bytes > cap) bytes = cap;
+    }
     int64_t t = bytes / ((int64_t)Kp * 4);
     t = (t / 512) * 512;
     return t < 512 ? 512 : t;

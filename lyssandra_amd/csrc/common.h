@@ -50,6 +50,7 @@ inline int padded_atoms(int K) {
 inline int padded_features(int n) { return ((n + 7) / 8) * 8; }
 
 int num_cus();  // CUs of the current device (cached)
+int64_t tile_signals(int Kp);  // signals per alpha0 tile of the encode drivers (api.hip)
 
 // ------------------------------------------------------------------ device helpers
 #if defined(__HIPCC__)

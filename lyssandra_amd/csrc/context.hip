@@ -1,12 +1,18 @@
 // Library-owned context (SURVEY 8b's proposed ABI): a caller with nothing but host arrays -- no PyTorch, no HIP calls of
-// its own -- can set a dictionary, encode signals and read the stage timings.  The context owns the device buffers
-// (packed dictionary, Gram matrix, alpha0 workspace, pinned-free staging of the signal tile and the sparse result) and
-// one stream; every call is synchronous on return.  Also here: the counter-based synthetic signal generator of SURVEY
+// its own -- can set a dictionary, encode signals, run the dictionary updates (approx K-SVD sweep, online-DL statistics
+// and update) on signals that stay resident on the device(s), and read the stage timings.  The context owns the device
+// buffers and one stream PER DEVICE; with several devices (lys_ctx_create_multi) ONE process shards the signals over them
+// exactly like the reference's run_parallel shards column batches over processes (lyssa/utils/__init__.py:92-129,
+// lyssa/sparse_coding.py:713-724), and the dictionary updates all-reduce their sufficient statistics over an RCCL
+// communicator it owns (ncclCommInitAll, loaded with dlopen so that single-device users never touch RCCL).  Every call
+// is synchronous on return.  Also here: the counter-based synthetic signal generator of SURVEY
 // 8(d) (Philox4x32-10 + Box-Muller keyed by (seed, global signal index, feature block)), so that any shard of a
 // benchmark regenerates the same patches on any device -- and, through oracle/bomp_oracle.c's identical generator, on
 // the host for the CPU leg.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "../../include/lyssa_hip.h"
@@ -76,21 +82,103 @@ int synth_signals(uint64_t seed, int64_t first, int64_t N, int n, float* X, int6
 
 }  // namespace lys
 
+// ------------------------------------------------------------------------------------------------ RCCL (dlopen)
+// The five entry points the multi-device context needs, resolved at run time: a process that already carries an RCCL
+// (PyTorch) gets that instance by soname, a plain C program gets /opt/rocm's.
+namespace {
+typedef struct ncclComm* nccl_comm_t;
+struct Rccl {
+    void* h = nullptr;
+    int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_SUM = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+bool rccl_load(Rccl& r) {
+    if (r.h) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        r.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (r.h) break;
+    }
+    if (!r.h) {
+        lys::set_error("multi-device context: cannot load librccl (%s)", dlerror());
+        return false;
+    }
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.h, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.h, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.h, "ncclAllReduce"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.h, "ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.h, "ncclGetErrorString"));
+    if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        lys::set_error("multi-device context: librccl lacks an expected entry point");
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------ context
-struct lys_ctx {
+constexpr int LYS_CTX_MAX_DEV = 16;
+
+struct lys_dev {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int n = 0, K = 0, Kp = 0, ldd = 0;
     float *D = nullptr, *G = nullptr;
+    bool gram_valid = false;
+    // host-pointer encode: one tile of staging
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    float* X = nullptr;  // device signal tile [tile][n]
+    float* X = nullptr;  // [tile][n]
     int32_t *idx = nullptr, *nnz = nullptr;
     float* coef = nullptr;
     int64_t tile = 0;
-    int tile_k = 0;
-    double ms[4] = {0, 0, 0, 0};  // last call: host->device, encode kernels, device->host, wall
+    int tile_k = 0, tile_n = 0, tile_K = 0;
+    // resident signals of this device's shard and their codes
+    float* Xs = nullptr;   // [Ns][n]
+    int64_t Ns = 0, Xs_cap = 0;
+    int32_t *r_idx = nullptr, *r_nnz = nullptr;
+    float* r_coef = nullptr;
+    int r_k = 0;
+    int64_t r_cap = 0;
+    bool codes_valid = false;
+    float* R = nullptr;    // [Ns][ldd]
+    int64_t R_cap = 0;
+    // block K-SVD sweep
+    int32_t *row_ptr = nullptr, *cg_ptr = nullptr, *cg_entry = nullptr;
+    void* erec = nullptr;
+    double* stats = nullptr;
+    float* Dnext = nullptr;
+    void* sweep_ws = nullptr;
+    size_t sweep_ws_bytes = 0, stats_bytes = 0;
+    int64_t sweep_N = -1;
+    int sweep_k = -1;
+    // online DL
+    float *A = nullptr, *B = nullptr, *dA = nullptr, *dB = nullptr, *scratch = nullptr;
+    int32_t *c_row_ptr = nullptr, *c_entry = nullptr;
+    void* csr_ws = nullptr;
+    size_t csr_ws_bytes = 0;
+    int64_t c_cap = 0;
+    double* err_dev = nullptr;
+};
+
+struct lys_ctx {
+    int nd = 1;
+    lys_dev dev[LYS_CTX_MAX_DEV];
+    nccl_comm_t comm[LYS_CTX_MAX_DEV] = {};
+    bool use_rccl = false;
+    Rccl rccl;
+    int n = 0, K = 0, Kp = 0, ldd = 0;
+    int64_t N_res = 0;            // resident signals over all devices
+    double ms[4] = {0, 0, 0, 0};  // last call (device 0): host->device, kernels, device->host, sum
+    int32_t* unused = nullptr;    // host: atoms without a non-zero in the last sweep
+    int n_unused = 0;
 };
 
 using namespace lys;
@@ -103,20 +191,147 @@ using namespace lys;
             return LYS_EHIP;                                                                   \
         }                                                                                      \
     } while (0)
+#define CTX_RC(call)             \
+    do {                         \
+        int rc_ = (call);        \
+        if (rc_) return rc_;     \
+    } while (0)
 
-static void ctx_free_tiles(lys_ctx* c) {
-    if (c->X) (void)hipFree(c->X);
-    if (c->idx) (void)hipFree(c->idx);
-    if (c->coef) (void)hipFree(c->coef);
-    if (c->nnz) (void)hipFree(c->nnz);
-    if (c->ws) (void)hipFree(c->ws);
-    c->X = nullptr;
-    c->idx = c->nnz = nullptr;
-    c->coef = nullptr;
-    c->ws = nullptr;
-    c->tile = 0;
-    c->tile_k = 0;
-    c->ws_bytes = 0;
+template <class T>
+static void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+// the reference's gen_even_batches (lyssa/utils/__init__.py:131-153): equal contiguous shards, the last takes the rest
+static void shard_of(int64_t N, int nd, int i, int64_t* first, int64_t* count) {
+    const int64_t sz = N / nd;
+    *first = sz * i;
+    *count = (i == nd - 1) ? N - sz * i : sz;
+}
+
+static void dev_free_tiles(lys_dev* d) {
+    dfree(d->X);
+    dfree(d->idx);
+    dfree(d->coef);
+    dfree(d->nnz);
+    dfree(d->ws);
+    d->tile = 0;
+    d->tile_k = d->tile_n = d->tile_K = 0;
+    d->ws_bytes = 0;
+}
+
+static void dev_free_learning(lys_dev* d) {
+    dfree(d->Xs);
+    dfree(d->r_idx);
+    dfree(d->r_nnz);
+    dfree(d->r_coef);
+    dfree(d->R);
+    dfree(d->row_ptr);
+    dfree(d->cg_ptr);
+    dfree(d->cg_entry);
+    dfree(d->erec);
+    dfree(d->stats);
+    dfree(d->Dnext);
+    dfree(d->sweep_ws);
+    dfree(d->A);
+    dfree(d->B);
+    dfree(d->dA);
+    dfree(d->dB);
+    dfree(d->scratch);
+    dfree(d->c_row_ptr);
+    dfree(d->c_entry);
+    dfree(d->csr_ws);
+    d->Ns = d->Xs_cap = d->r_cap = d->R_cap = d->c_cap = 0;
+    d->r_k = 0;
+    d->codes_valid = false;
+    d->sweep_N = -1;
+    d->sweep_k = -1;
+    d->sweep_ws_bytes = d->stats_bytes = d->csr_ws_bytes = 0;
+}
+
+static int ctx_sync_all(lys_ctx* c) {
+    for (int i = 0; i < c->nd; ++i) {
+        CTX_HIP(hipSetDevice(c->dev[i].device));
+        CTX_HIP(hipStreamSynchronize(c->dev[i].stream));
+    }
+    return LYS_OK;
+}
+
+// sum over the devices of `count` elements at buf(i), in place, on every device's stream (no-op for one device)
+template <class F>
+static int ctx_allreduce(lys_ctx* c, F buf, size_t count, int dtype) {
+    if (c->nd <= 1 && !c->use_rccl) return LYS_OK;
+    int rc = c->rccl.GroupStart();
+    for (int i = 0; i < c->nd && rc == 0; ++i)
+        rc = c->rccl.AllReduce(buf(i), buf(i), count, dtype, NCCL_SUM, c->comm[i], c->dev[i].stream);
+    const int rc2 = c->rccl.GroupEnd();
+    if (rc == 0) rc = rc2;
+    if (rc != 0) {
+        set_error("ncclAllReduce failed: %s", c->rccl.GetErrorString(rc));
+        return LYS_EHIP;
+    }
+    return LYS_OK;
+}
+
+static int ctx_ensure_gram(lys_ctx* c) {
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        if (d->gram_valid) continue;
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_RC(lys_gram(d->D, c->n, c->K, d->G, d->stream));
+        d->gram_valid = true;
+    }
+    return LYS_OK;
+}
+
+static int ctx_create_impl(int nd, const int* ids, bool force_rccl, lys_ctx** out) {
+    if (!out || nd < 1 || nd > LYS_CTX_MAX_DEV || !ids) {
+        set_error("ctx_create: bad arguments (1 <= n_devices <= %d)", LYS_CTX_MAX_DEV);
+        return LYS_EINVAL;
+    }
+    *out = nullptr;
+    for (int i = 0; i < nd; ++i)
+        for (int j = 0; j < i; ++j)
+            if (ids[i] == ids[j]) {
+                set_error("ctx_create: device %d listed twice", ids[i]);
+                return LYS_EINVAL;
+            }
+    lys_ctx* c = new (std::nothrow) lys_ctx();
+    if (!c) {
+        set_error("ctx_create: out of host memory");
+        return LYS_EINVAL;
+    }
+    c->nd = nd;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < nd && e == hipSuccess; ++i) {
+        lys_dev* d = &c->dev[i];
+        d->device = ids[i];
+        e = hipSetDevice(ids[i]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+        for (int j = 0; j < 4 && e == hipSuccess; ++j) e = hipEventCreate(&d->ev[j]);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->err_dev), sizeof(double));
+    }
+    if (e != hipSuccess) {
+        set_error("ctx_create: %s", hipGetErrorString(e));
+        lys_ctx_destroy(c);
+        return LYS_EHIP;
+    }
+    if (nd > 1 || force_rccl) {
+        if (!rccl_load(c->rccl)) {
+            lys_ctx_destroy(c);
+            return LYS_EHIP;
+        }
+        const int rc = c->rccl.CommInitAll(c->comm, nd, ids);
+        if (rc != 0) {
+            set_error("ncclCommInitAll failed: %s", c->rccl.GetErrorString(rc));
+            lys_ctx_destroy(c);
+            return LYS_EHIP;
+        }
+        c->use_rccl = true;
+    }
+    *out = c;
+    return LYS_OK;
 }
 
 extern "C" {
@@ -129,39 +344,33 @@ int lys_synth_signals(uint64_t seed, int64_t first, int64_t N, int n, float* X, 
     return synth_signals(seed, first, N, n, X, ldx, reinterpret_cast<hipStream_t>(stream));
 }
 
-int lys_ctx_create(int device, lys_ctx** out) {
-    if (!out) {
-        set_error("ctx_create: null pointer");
-        return LYS_EINVAL;
-    }
-    *out = nullptr;
-    CTX_HIP(hipSetDevice(device));
-    lys_ctx* c = new (std::nothrow) lys_ctx();
-    if (!c) {
-        set_error("ctx_create: out of host memory");
-        return LYS_EINVAL;
-    }
-    c->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
-    if (e != hipSuccess) {
-        set_error("ctx_create: %s", hipGetErrorString(e));
-        lys_ctx_destroy(c);
-        return LYS_EHIP;
-    }
-    *out = c;
-    return LYS_OK;
+int lys_ctx_create(int device, lys_ctx** out) { return ctx_create_impl(1, &device, false, out); }
+
+int lys_ctx_create_multi(int n_devices, const int* device_ids, lys_ctx** out) {
+    // LYS_CTX_FORCE_RCCL=1: communicator also for one device (exercises the RCCL path on a single-GPU box)
+    const char* e = getenv("LYS_CTX_FORCE_RCCL");
+    return ctx_create_impl(n_devices, device_ids, e && e[0] == '1', out);
 }
+
+int lys_ctx_device_count(const lys_ctx* c) { return c ? c->nd : 0; }
 
 void lys_ctx_destroy(lys_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    ctx_free_tiles(c);
-    if (c->D) (void)hipFree(c->D);
-    if (c->G) (void)hipFree(c->G);
-    for (int i = 0; i < 4; ++i)
-        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        (void)hipSetDevice(d->device);
+        if (d->stream) (void)hipStreamSynchronize(d->stream);
+        if (c->use_rccl && c->comm[i]) (void)c->rccl.CommDestroy(c->comm[i]);
+        dev_free_tiles(d);
+        dev_free_learning(d);
+        dfree(d->D);
+        dfree(d->G);
+        dfree(d->err_dev);
+        for (int j = 0; j < 4; ++j)
+            if (d->ev[j]) (void)hipEventDestroy(d->ev[j]);
+        if (d->stream) (void)hipStreamDestroy(d->stream);
+    }
+    free(c->unused);
     delete c;
 }
 
@@ -170,106 +379,191 @@ int lys_ctx_set_dictionary(lys_ctx* c, const float* D_atom_major_host, int n, in
         set_error("ctx_set_dictionary: bad arguments");
         return LYS_EINVAL;
     }
-    CTX_HIP(hipSetDevice(c->device));
     const int Kp = lys_padded_atoms(K), ldd = lys_padded_features(n);
-    if (Kp != c->Kp || ldd != c->ldd) {
-        if (c->D) (void)hipFree(c->D);
-        if (c->G) (void)hipFree(c->G);
-        c->D = c->G = nullptr;
-        ctx_free_tiles(c);
-        CTX_HIP(hipMalloc(reinterpret_cast<void**>(&c->D), (size_t)Kp * ldd * sizeof(float)));
-        CTX_HIP(hipMalloc(reinterpret_cast<void**>(&c->G), (size_t)Kp * Kp * sizeof(float)));
+    const bool reshape = (n != c->n || K != c->K);
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        if (reshape) {
+            // any change of n or K re-plans every buffer whose size depends on them (the signal tile is [tile][n]: a larger
+            // n inside the same padded width would otherwise overrun it); the stored shape is cleared first so that a
+            // failed allocation below leaves a context that re-plans again
+            CTX_HIP(hipStreamSynchronize(d->stream));
+            dfree(d->D);
+            dfree(d->G);
+            dev_free_tiles(d);
+            dev_free_learning(d);
+        }
     }
-    c->n = n;
-    c->K = K;
-    c->Kp = Kp;
-    c->ldd = ldd;
-    float* tmp = nullptr;
-    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)K * n * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(tmp, D_atom_major_host, (size_t)K * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    int rc = LYS_OK;
-    if (e == hipSuccess) {
-        rc = lys_pack_dictionary(tmp, n, K, c->D, c->stream);
-        if (!rc) rc = lys_gram(c->D, n, K, c->G, c->stream);
-        e = hipStreamSynchronize(c->stream);
+    if (reshape) {
+        c->n = c->K = c->Kp = c->ldd = 0;
+        c->N_res = 0;
+        free(c->unused);
+        c->unused = static_cast<int32_t*>(malloc(sizeof(int32_t) * (size_t)K));
+        c->n_unused = 0;
+        if (!c->unused) {
+            set_error("ctx_set_dictionary: out of host memory");
+            return LYS_EINVAL;
+        }
+        for (int i = 0; i < c->nd; ++i) {
+            lys_dev* d = &c->dev[i];
+            CTX_HIP(hipSetDevice(d->device));
+            CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->D), (size_t)Kp * ldd * sizeof(float)));
+            CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->G), (size_t)Kp * Kp * sizeof(float)));
+        }
+        c->n = n;
+        c->K = K;
+        c->Kp = Kp;
+        c->ldd = ldd;
     }
-    (void)hipFree(tmp);
-    if (e != hipSuccess) {
-        set_error("ctx_set_dictionary: %s", hipGetErrorString(e));
-        return LYS_EHIP;
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        float* tmp = nullptr;
+        CTX_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)K * n * sizeof(float)));
+        hipError_t e = hipMemcpyAsync(tmp, D_atom_major_host, (size_t)K * n * sizeof(float), hipMemcpyHostToDevice, d->stream);
+        int rc = LYS_OK;
+        if (e == hipSuccess) {
+            rc = lys_pack_dictionary(tmp, n, K, d->D, d->stream);
+            if (!rc) rc = lys_gram(d->D, n, K, d->G, d->stream);
+            e = hipStreamSynchronize(d->stream);
+        }
+        (void)hipFree(tmp);
+        if (e != hipSuccess) {
+            set_error("ctx_set_dictionary: %s", hipGetErrorString(e));
+            return LYS_EHIP;
+        }
+        if (rc) return rc;
+        d->gram_valid = true;
+        d->codes_valid = false;
     }
-    return rc;
+    return LYS_OK;
+}
+
+int lys_ctx_get_dictionary(lys_ctx* c, float* D_atom_major_host) {
+    if (!c || !c->dev[0].D || !D_atom_major_host) {
+        set_error("ctx_get_dictionary: no dictionary / null pointer");
+        return LYS_EINVAL;
+    }
+    lys_dev* d = &c->dev[0];  // the replicas are bit-identical
+    CTX_HIP(hipSetDevice(d->device));
+    CTX_HIP(hipMemcpy2DAsync(D_atom_major_host, (size_t)c->n * sizeof(float), d->D, (size_t)c->ldd * sizeof(float),
+                             (size_t)c->n * sizeof(float), (size_t)c->K, hipMemcpyDeviceToHost, d->stream));
+    CTX_HIP(hipStreamSynchronize(d->stream));
+    return LYS_OK;
+}
+
+int lys_ctx_set_atom(lys_ctx* c, int atom, const float* column_host) {
+    if (!c || !c->dev[0].D || !column_host || atom < 0 || atom >= c->K) {
+        set_error("ctx_set_atom: bad arguments");
+        return LYS_EINVAL;
+    }
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_HIP(hipMemcpyAsync(d->D + (size_t)atom * c->ldd, column_host, (size_t)c->n * sizeof(float), hipMemcpyHostToDevice,
+                               d->stream));
+        CTX_HIP(hipStreamSynchronize(d->stream));
+        d->gram_valid = false;
+        d->codes_valid = false;
+    }
+    return LYS_OK;
 }
 
 // device buffers for tiles of `tile` signals with k coefficient slots
-static int ctx_reserve(lys_ctx* c, int64_t tile, int k) {
-    if (c->tile >= tile && c->tile_k >= k) return LYS_OK;
-    ctx_free_tiles(c);
-    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&c->X), (size_t)tile * c->n * sizeof(float)));
-    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&c->idx), (size_t)tile * k * sizeof(int32_t)));
-    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&c->coef), (size_t)tile * k * sizeof(float)));
-    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&c->nnz), (size_t)tile * sizeof(int32_t)));
-    c->ws_bytes = lys_bomp_workspace_bytes(c->n, c->K, k, tile);
-    CTX_HIP(hipMalloc(&c->ws, c->ws_bytes));
-    c->tile = tile;
-    c->tile_k = k;
+static int dev_reserve(lys_ctx* c, lys_dev* d, int64_t tile, int k) {
+    if (d->tile >= tile && d->tile_k >= k && d->tile_n == c->n && d->tile_K == c->K) return LYS_OK;
+    dev_free_tiles(d);
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->X), (size_t)tile * c->n * sizeof(float)));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->idx), (size_t)tile * k * sizeof(int32_t)));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->coef), (size_t)tile * k * sizeof(float)));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->nnz), (size_t)tile * sizeof(int32_t)));
+    d->ws_bytes = lys_bomp_workspace_bytes(c->n, c->K, k, tile);
+    CTX_HIP(hipMalloc(&d->ws, d->ws_bytes));
+    d->tile = tile;
+    d->tile_k = k;
+    d->tile_n = c->n;
+    d->tile_K = c->K;
     return LYS_OK;
 }
 
 static int64_t ctx_tile(const lys_ctx* c, int64_t N) {
-    const int64_t pref = ((int64_t)4 << 30) / ((int64_t)c->Kp * 4);  // one alpha0 tile of the engine (4 GiB)
+    const int64_t pref = tile_signals(c->Kp);  // one alpha0 tile of the engine
     return N < pref ? (N < 1 ? 1 : N) : pref;
 }
 
 int lys_ctx_bomp_encode(lys_ctx* c, const float* X_sig_major_host, int64_t N, int k, int32_t* idx_host, float* coef_host,
                         int32_t* nnz_host) {
-    if (!c || !c->D || (N > 0 && (!X_sig_major_host || !idx_host || !coef_host || !nnz_host)) || N < 0 || k < 1 || k > 64) {
+    if (!c || !c->dev[0].D || (N > 0 && (!X_sig_major_host || !idx_host || !coef_host || !nnz_host)) || N < 0 || k < 1 ||
+        k > 64) {
         set_error("ctx_bomp_encode: bad arguments (dictionary set? 1 <= k <= 64?)");
         return LYS_EINVAL;
     }
-    CTX_HIP(hipSetDevice(c->device));
     c->ms[0] = c->ms[1] = c->ms[2] = c->ms[3] = 0.0;
     if (N == 0) return LYS_OK;
-    const int64_t tile = ctx_tile(c, N);
-    int rc = ctx_reserve(c, tile, k);
-    if (rc) return rc;
-    for (int64_t s0 = 0; s0 < N; s0 += tile) {
-        const int64_t cnt = (N - s0 < tile) ? N - s0 : tile;
-        CTX_HIP(hipEventRecord(c->ev[0], c->stream));
-        CTX_HIP(hipMemcpyAsync(c->X, X_sig_major_host + s0 * c->n, (size_t)cnt * c->n * sizeof(float), hipMemcpyHostToDevice,
-                               c->stream));
-        CTX_HIP(hipEventRecord(c->ev[1], c->stream));
-        rc = lys_bomp_encode(c->X, c->n, c->D, c->G, c->n, c->K, k, cnt, c->idx, c->coef, c->nnz, c->ws, c->ws_bytes, c->stream);
-        if (rc) return rc;
-        CTX_HIP(hipEventRecord(c->ev[2], c->stream));
-        CTX_HIP(hipMemcpyAsync(idx_host + s0 * k, c->idx, (size_t)cnt * k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        CTX_HIP(hipMemcpyAsync(coef_host + s0 * k, c->coef, (size_t)cnt * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        CTX_HIP(hipMemcpyAsync(nnz_host + s0, c->nnz, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        CTX_HIP(hipEventRecord(c->ev[3], c->stream));
-        CTX_HIP(hipStreamSynchronize(c->stream));
-        float a = 0.f, b = 0.f, d = 0.f;
-        CTX_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
-        CTX_HIP(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
-        CTX_HIP(hipEventElapsedTime(&d, c->ev[2], c->ev[3]));
-        c->ms[0] += a;
-        c->ms[1] += b;
-        c->ms[2] += d;
-        c->ms[3] += a + b + d;
+    CTX_RC(ctx_ensure_gram(c));
+    // every device encodes its contiguous shard, tile by tile; the devices run concurrently (one stream each)
+    int64_t first[LYS_CTX_MAX_DEV], count[LYS_CTX_MAX_DEV], tile[LYS_CTX_MAX_DEV], rounds = 0;
+    for (int i = 0; i < c->nd; ++i) {
+        shard_of(N, c->nd, i, &first[i], &count[i]);
+        tile[i] = ctx_tile(c, count[i]);
+        if (count[i] > 0) {
+            CTX_HIP(hipSetDevice(c->dev[i].device));
+            CTX_RC(dev_reserve(c, &c->dev[i], tile[i], k));
+            const int64_t r = (count[i] + tile[i] - 1) / tile[i];
+            rounds = r > rounds ? r : rounds;
+        }
+    }
+    for (int64_t t = 0; t < rounds; ++t) {
+        for (int i = 0; i < c->nd; ++i) {
+            lys_dev* d = &c->dev[i];
+            const int64_t s0 = t * tile[i];
+            if (s0 >= count[i]) continue;
+            const int64_t cnt = (count[i] - s0 < tile[i]) ? count[i] - s0 : tile[i];
+            const int64_t g0 = first[i] + s0;
+            CTX_HIP(hipSetDevice(d->device));
+            CTX_HIP(hipEventRecord(d->ev[0], d->stream));
+            CTX_HIP(hipMemcpyAsync(d->X, X_sig_major_host + g0 * c->n, (size_t)cnt * c->n * sizeof(float),
+                                   hipMemcpyHostToDevice, d->stream));
+            CTX_HIP(hipEventRecord(d->ev[1], d->stream));
+            CTX_RC(lys_bomp_encode(d->X, c->n, d->D, d->G, c->n, c->K, k, cnt, d->idx, d->coef, d->nnz, d->ws, d->ws_bytes,
+                                   d->stream));
+            CTX_HIP(hipEventRecord(d->ev[2], d->stream));
+            CTX_HIP(hipMemcpyAsync(idx_host + g0 * k, d->idx, (size_t)cnt * k * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+            CTX_HIP(hipMemcpyAsync(coef_host + g0 * k, d->coef, (size_t)cnt * k * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+            CTX_HIP(hipMemcpyAsync(nnz_host + g0, d->nnz, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+            CTX_HIP(hipEventRecord(d->ev[3], d->stream));
+        }
+        CTX_RC(ctx_sync_all(c));
+        if (t * tile[0] < count[0]) {
+            lys_dev* d = &c->dev[0];
+            float a = 0.f, b = 0.f, e = 0.f;
+            CTX_HIP(hipSetDevice(d->device));
+            CTX_HIP(hipEventElapsedTime(&a, d->ev[0], d->ev[1]));
+            CTX_HIP(hipEventElapsedTime(&b, d->ev[1], d->ev[2]));
+            CTX_HIP(hipEventElapsedTime(&e, d->ev[2], d->ev[3]));
+            c->ms[0] += a;
+            c->ms[1] += b;
+            c->ms[2] += e;
+            c->ms[3] += a + b + e;
+        }
     }
     return LYS_OK;
 }
 
 int lys_ctx_bomp_encode_synthetic(lys_ctx* c, uint64_t seed, int64_t first, int64_t N, int k, double* stats4) {
-    if (!c || !c->D || N < 0 || k < 1 || k > 64 || !stats4) {
+    if (!c || !c->dev[0].D || N < 0 || k < 1 || k > 64 || !stats4) {
         set_error("ctx_bomp_encode_synthetic: bad arguments");
         return LYS_EINVAL;
     }
-    CTX_HIP(hipSetDevice(c->device));
+    lys_dev* d = &c->dev[0];  // measurement aid: device 0 only
+    CTX_HIP(hipSetDevice(d->device));
     c->ms[0] = c->ms[1] = c->ms[2] = c->ms[3] = 0.0;
     stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0.0;
     if (N == 0) return LYS_OK;
+    CTX_RC(ctx_ensure_gram(c));
     const int64_t tile = ctx_tile(c, N);
-    int rc = ctx_reserve(c, tile, k);
+    int rc = dev_reserve(c, d, tile, k);
     if (rc) return rc;
     int32_t* hn = static_cast<int32_t*>(malloc((size_t)tile * sizeof(int32_t)));
     if (!hn) {
@@ -279,18 +573,18 @@ int lys_ctx_bomp_encode_synthetic(lys_ctx* c, uint64_t seed, int64_t first, int6
     double nnz_sum = 0.0;
     for (int64_t s0 = 0; s0 < N && !rc; s0 += tile) {
         const int64_t cnt = (N - s0 < tile) ? N - s0 : tile;
-        hipError_t e = hipEventRecord(c->ev[0], c->stream);
-        rc = synth_signals(seed, first + s0, cnt, c->n, c->X, c->n, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
+        hipError_t e = hipEventRecord(d->ev[0], d->stream);
+        rc = synth_signals(seed, first + s0, cnt, c->n, d->X, c->n, d->stream);
+        if (e == hipSuccess) e = hipEventRecord(d->ev[1], d->stream);
         if (!rc)
-            rc = lys_bomp_encode(c->X, c->n, c->D, c->G, c->n, c->K, k, cnt, c->idx, c->coef, c->nnz, c->ws, c->ws_bytes,
-                                 c->stream);
-        if (e == hipSuccess) e = hipEventRecord(c->ev[2], c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(hn, c->nnz, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            rc = lys_bomp_encode(d->X, c->n, d->D, d->G, c->n, c->K, k, cnt, d->idx, d->coef, d->nnz, d->ws, d->ws_bytes,
+                                 d->stream);
+        if (e == hipSuccess) e = hipEventRecord(d->ev[2], d->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hn, d->nnz, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         float a = 0.f, b = 0.f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&a, d->ev[0], d->ev[1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&b, d->ev[1], d->ev[2]);
         if (e != hipSuccess) {
             set_error("ctx_bomp_encode_synthetic: %s", hipGetErrorString(e));
             rc = LYS_EHIP;
@@ -317,6 +611,391 @@ int lys_ctx_timings(const lys_ctx* c, double* ms4) {
     }
     for (int i = 0; i < 4; ++i) ms4[i] = c->ms[i];
     return LYS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- resident learning
+int lys_ctx_set_signals(lys_ctx* c, const float* X_sig_major_host, int64_t N) {
+    if (!c || !c->dev[0].D || N < 0 || (N > 0 && !X_sig_major_host)) {
+        set_error("ctx_set_signals: bad arguments (dictionary set?)");
+        return LYS_EINVAL;
+    }
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        int64_t first, cnt;
+        shard_of(N, c->nd, i, &first, &cnt);
+        CTX_HIP(hipSetDevice(d->device));
+        if (cnt > d->Xs_cap) {
+            dfree(d->Xs);
+            CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->Xs), (size_t)cnt * c->n * sizeof(float)));
+            d->Xs_cap = cnt;
+        }
+        if (cnt > 0)
+            CTX_HIP(hipMemcpyAsync(d->Xs, X_sig_major_host + first * c->n, (size_t)cnt * c->n * sizeof(float),
+                                   hipMemcpyHostToDevice, d->stream));
+        d->Ns = cnt;
+        d->codes_valid = false;
+    }
+    c->N_res = N;
+    return ctx_sync_all(c);
+}
+
+static int dev_reserve_codes(lys_ctx* c, lys_dev* d, int k) {
+    if (d->r_cap >= d->Ns && d->r_k == k) return LYS_OK;
+    dfree(d->r_idx);
+    dfree(d->r_coef);
+    dfree(d->r_nnz);
+    const size_t cap = (size_t)(d->Ns > 0 ? d->Ns : 1);
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->r_idx), cap * k * sizeof(int32_t)));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->r_coef), cap * k * sizeof(float)));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->r_nnz), cap * sizeof(int32_t)));
+    d->r_cap = (int64_t)cap;
+    d->r_k = k;
+    return LYS_OK;
+}
+
+// Batch-OMP of the resident signals against the current dictionary (sparse_coding.py:629-635); the codes stay resident
+int lys_ctx_encode_resident(lys_ctx* c, int k) {
+    if (!c || !c->dev[0].D || k < 1 || k > 64) {
+        set_error("ctx_encode_resident: bad arguments");
+        return LYS_EINVAL;
+    }
+    CTX_RC(ctx_ensure_gram(c));
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_RC(dev_reserve_codes(c, d, k));
+        if (d->Ns > 0) {
+            const size_t need = lys_bomp_workspace_bytes(c->n, c->K, k, d->Ns);
+            if (need > d->ws_bytes) {
+                dev_free_tiles(d);
+                CTX_HIP(hipMalloc(&d->ws, need));
+                d->ws_bytes = need;
+            }
+            if (i == 0) CTX_HIP(hipEventRecord(d->ev[1], d->stream));
+            CTX_RC(lys_bomp_encode(d->Xs, c->n, d->D, d->G, c->n, c->K, k, d->Ns, d->r_idx, d->r_coef, d->r_nnz, d->ws,
+                                   d->ws_bytes, d->stream));
+            if (i == 0) CTX_HIP(hipEventRecord(d->ev[2], d->stream));
+        }
+        d->codes_valid = true;
+    }
+    CTX_RC(ctx_sync_all(c));
+    c->ms[0] = c->ms[2] = 0.0;
+    if (c->dev[0].Ns > 0) {
+        float b = 0.f;
+        CTX_HIP(hipSetDevice(c->dev[0].device));
+        CTX_HIP(hipEventElapsedTime(&b, c->dev[0].ev[1], c->dev[0].ev[2]));
+        c->ms[1] = c->ms[3] = b;
+    }
+    return LYS_OK;
+}
+
+int lys_ctx_get_codes(lys_ctx* c, int32_t* idx_host, float* coef_host, int32_t* nnz_host) {
+    if (!c || !idx_host || !coef_host || !nnz_host) {
+        set_error("ctx_get_codes: null pointer");
+        return LYS_EINVAL;
+    }
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        if (!d->codes_valid) {
+            set_error("ctx_get_codes: no codes (call lys_ctx_encode_resident)");
+            return LYS_EINVAL;
+        }
+        int64_t first, cnt;
+        shard_of(c->N_res, c->nd, i, &first, &cnt);
+        if (cnt == 0) continue;
+        const int k = d->r_k;
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_HIP(hipMemcpyAsync(idx_host + first * k, d->r_idx, (size_t)cnt * k * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+        CTX_HIP(hipMemcpyAsync(coef_host + first * k, d->r_coef, (size_t)cnt * k * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+        CTX_HIP(hipMemcpyAsync(nnz_host + first, d->r_nnz, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+    }
+    return ctx_sync_all(c);
+}
+
+// ||X - D Z||_F^2 of the resident signals and codes (dict_learning/utils.py:14-19), summed over the devices
+int lys_ctx_error(lys_ctx* c, double* err_host) {
+    if (!c || !err_host) {
+        set_error("ctx_error: null pointer");
+        return LYS_EINVAL;
+    }
+    double tot = 0.0;
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        if (!d->codes_valid) {
+            set_error("ctx_error: no codes (call lys_ctx_encode_resident)");
+            return LYS_EINVAL;
+        }
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_HIP(hipMemsetAsync(d->err_dev, 0, sizeof(double), d->stream));
+        if (d->Ns > 0)
+            CTX_RC(lys_residual(d->Xs, c->n, d->D, c->n, c->K, d->r_k, d->Ns, d->r_idx, d->r_coef, d->r_nnz, nullptr, 0,
+                                d->err_dev, d->stream));
+    }
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        double e = 0.0;
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_HIP(hipMemcpyAsync(&e, d->err_dev, sizeof(double), hipMemcpyDeviceToHost, d->stream));
+        CTX_HIP(hipStreamSynchronize(d->stream));
+        tot += e;
+    }
+    *err_host = tot;
+    return LYS_OK;
+}
+
+static int dev_reserve_sweep(lys_ctx* c, lys_dev* d, int B) {
+    const int k = d->r_k;
+    if (d->R_cap < d->Ns) {
+        dfree(d->R);
+        CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->R), (size_t)(d->Ns > 0 ? d->Ns : 1) * c->ldd * sizeof(float)));
+        d->R_cap = d->Ns > 0 ? d->Ns : 1;
+    }
+    if (d->sweep_N == d->Ns && d->sweep_k == k && d->row_ptr) return LYS_OK;
+    dfree(d->row_ptr);
+    dfree(d->cg_ptr);
+    dfree(d->cg_entry);
+    dfree(d->erec);
+    dfree(d->stats);
+    dfree(d->Dnext);
+    dfree(d->sweep_ws);
+    const int nb = (c->K + B - 1) / B;
+    const size_t nk = (size_t)(d->Ns > 0 ? d->Ns : 1) * k;
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->row_ptr), (size_t)(c->K + 1) * sizeof(int32_t)));
+    CTX_HIP(hipMalloc(&d->erec, nk * 16));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->cg_ptr), ((size_t)nb * ((size_t)1 << B) + 1) * sizeof(int32_t)));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->cg_entry), (nk / 2 + 1) * sizeof(int32_t)));
+    d->stats_bytes = lys_bksvd_stats_bytes(c->n, c->K, B);
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->stats), d->stats_bytes));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->Dnext), (size_t)c->Kp * c->ldd * sizeof(float)));
+    CTX_HIP(hipMemsetAsync(d->Dnext, 0, (size_t)c->Kp * c->ldd * sizeof(float), d->stream));
+    d->sweep_ws_bytes = lys_bksvd_index_workspace_bytes(c->K, k, d->Ns > 0 ? d->Ns : 1, B);
+    if (d->sweep_ws_bytes < 16) d->sweep_ws_bytes = 16;
+    CTX_HIP(hipMalloc(&d->sweep_ws, d->sweep_ws_bytes));
+    d->sweep_N = d->Ns;
+    d->sweep_k = k;
+    return LYS_OK;
+}
+
+// One dictionary-update cycle of approx K-SVD (lyssa/dict_learning/ksvd.py:98-126) on the resident signals and codes:
+// R = X - D Z, then the block Gauss-Seidel sweep (atoms 0..K-1 in order; csrc/ksvd_block.hip).  With several devices every
+// block's statistics slab is all-reduced over the communicator before the block's atoms are updated (replicated, bit-
+// identical on every device).  Codes and dictionary are updated in place; *n_unused_host = atoms without a non-zero
+// (ksvd.py:111-115; list through lys_ctx_get_unused).
+int lys_ctx_ksvd_sweep(lys_ctx* c, int* n_unused_host) {
+    if (!c || !c->dev[0].D) {
+        set_error("ctx_ksvd_sweep: no dictionary");
+        return LYS_EINVAL;
+    }
+    const int B = lys_bksvd_block_size(c->n);
+    const int k = c->dev[0].r_k;
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        if (!d->codes_valid || d->r_k != k) {
+            set_error("ctx_ksvd_sweep: no codes (call lys_ctx_encode_resident)");
+            return LYS_EINVAL;
+        }
+        if (c->n > 256 || k > 64 || d->Ns * (int64_t)c->ldd * 4 >= ((int64_t)1 << 32) || d->Ns * (int64_t)k * 4 >= ((int64_t)1 << 32)) {
+            set_error("ctx_ksvd_sweep: shape outside the block sweep (n <= 256, k <= 64, < 2^32 bytes of residual per device)");
+            return LYS_ENOSUP;
+        }
+    }
+    int32_t lay[6];
+    CTX_RC(lys_bksvd_layout(c->n, B, lay));
+    const int stride = lay[0], nb = (c->K + B - 1) / B;
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_RC(dev_reserve_sweep(c, d, B));
+        if (i == 0) CTX_HIP(hipEventRecord(d->ev[1], d->stream));
+        CTX_RC(lys_residual(d->Xs, c->n, d->D, c->n, c->K, k, d->Ns, d->r_idx, d->r_coef, d->r_nnz, d->R, c->ldd, nullptr,
+                            d->stream));
+        CTX_RC(lys_bksvd_index(d->r_idx, d->r_coef, d->r_nnz, c->K, k, d->Ns, B, d->row_ptr, d->erec, d->cg_ptr, d->cg_entry,
+                               d->sweep_ws, d->sweep_ws_bytes, d->stream));
+        CTX_HIP(hipMemsetAsync(d->stats, 0, d->stats_bytes, d->stream));
+    }
+    for (int cb = 0; cb <= nb; ++cb) {
+        for (int i = 0; i < c->nd; ++i) {
+            lys_dev* d = &c->dev[i];
+            CTX_HIP(hipSetDevice(d->device));
+            CTX_RC(lys_bksvd_step(0, cb, B, d->R, c->ldd, c->n, c->K, k, d->row_ptr, d->erec, d->cg_ptr, d->cg_entry, d->r_idx,
+                                  d->r_coef, d->D, d->Dnext, d->stats, d->stream));
+            if (cb >= 1)
+                CTX_RC(lys_bksvd_step(1, cb, B, d->R, c->ldd, c->n, c->K, k, d->row_ptr, d->erec, d->cg_ptr, d->cg_entry,
+                                      d->r_idx, d->r_coef, d->D, d->Dnext, d->stats, d->stream));
+        }
+        if (cb < nb && c->use_rccl)
+            CTX_RC(ctx_allreduce(c, [&](int i) { return static_cast<void*>(c->dev[i].stats + (size_t)cb * stride); },
+                                 (size_t)stride, NCCL_FLOAT64));
+    }
+    // counts travel inside the (reduced) slabs: slab cb, atom t: [sum x R (n) | sum x^2 | count] at t * (n + 2)
+    double* hstats = static_cast<double*>(malloc(c->dev[0].stats_bytes));
+    if (!hstats) {
+        set_error("ctx_ksvd_sweep: out of host memory");
+        return LYS_EINVAL;
+    }
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_HIP(hipMemcpyAsync(d->D, d->Dnext, (size_t)c->K * c->ldd * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+        if (i == 0) {
+            CTX_HIP(hipEventRecord(d->ev[2], d->stream));
+            CTX_HIP(hipMemcpyAsync(hstats, d->stats, d->stats_bytes, hipMemcpyDeviceToHost, d->stream));
+        }
+        d->gram_valid = false;
+    }
+    const int rcs = ctx_sync_all(c);
+    if (rcs) {
+        free(hstats);
+        return rcs;
+    }
+    c->n_unused = 0;
+    for (int a = 0; a < c->K; ++a) {
+        const double cnt = hstats[(size_t)(a / B) * stride + (size_t)(a % B) * (c->n + 2) + c->n + 1];
+        if (cnt < 0.5) c->unused[c->n_unused++] = a;
+    }
+    free(hstats);
+    float b = 0.f;
+    CTX_HIP(hipSetDevice(c->dev[0].device));
+    CTX_HIP(hipEventElapsedTime(&b, c->dev[0].ev[1], c->dev[0].ev[2]));
+    c->ms[0] = c->ms[2] = 0.0;
+    c->ms[1] = c->ms[3] = b;
+    if (n_unused_host) *n_unused_host = c->n_unused;
+    return LYS_OK;
+}
+
+int lys_ctx_get_unused(const lys_ctx* c, int32_t* atoms_host, int cap) {
+    if (!c || (cap > 0 && !atoms_host)) {
+        set_error("ctx_get_unused: null pointer");
+        return LYS_EINVAL;
+    }
+    const int m = c->n_unused < cap ? c->n_unused : cap;
+    for (int i = 0; i < m; ++i) atoms_host[i] = c->unused[i];
+    return LYS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- online DL
+static int dev_reserve_odl(lys_ctx* c, lys_dev* d) {
+    if (d->A) return LYS_OK;
+    const size_t kk = (size_t)c->Kp * c->Kp, kn = (size_t)c->Kp * c->ldd;
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->A), kk * sizeof(float)));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->dA), (kk + kn) * sizeof(float)));  // dA | dB contiguous: one all-reduce
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->B), kn * sizeof(float)));
+    d->dB = d->dA + kk;
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->scratch), 2 * kn * sizeof(float)));
+    CTX_HIP(hipMemsetAsync(d->A, 0, kk * sizeof(float), d->stream));
+    CTX_HIP(hipMemsetAsync(d->B, 0, kn * sizeof(float), d->stream));
+    return LYS_OK;
+}
+
+int lys_ctx_odl_reset(lys_ctx* c) {
+    if (!c || !c->dev[0].D) {
+        set_error("ctx_odl_reset: no dictionary");
+        return LYS_EINVAL;
+    }
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_RC(dev_reserve_odl(c, d));
+        CTX_HIP(hipMemsetAsync(d->A, 0, (size_t)c->Kp * c->Kp * sizeof(float), d->stream));
+        CTX_HIP(hipMemsetAsync(d->B, 0, (size_t)c->Kp * c->ldd * sizeof(float), d->stream));
+    }
+    return ctx_sync_all(c);
+}
+
+// One mini-batch of online_dict_learn (lyssa/dict_learning/online_dict_learn.py:78-85): the batch is sharded over the
+// devices, Batch-OMP coded with k atoms, and A = beta A + Z Z', B = beta B + X Z' (the increments all-reduced over the
+// devices as ONE buffer [dA | dB]).  The codes of the batch become the context's resident signals / codes.
+int lys_ctx_odl_accumulate(lys_ctx* c, const float* X_sig_major_host, int64_t Nb, int k, float beta) {
+    if (!c || !c->dev[0].D || Nb < 1 || !X_sig_major_host || k < 1 || k > 64) {
+        set_error("ctx_odl_accumulate: bad arguments");
+        return LYS_EINVAL;
+    }
+    CTX_RC(lys_ctx_set_signals(c, X_sig_major_host, Nb));
+    CTX_RC(lys_ctx_encode_resident(c, k));
+    const size_t kk = (size_t)c->Kp * c->Kp, kn = (size_t)c->Kp * c->ldd;
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_RC(dev_reserve_odl(c, d));
+        if (d->Ns == 0) {
+            CTX_HIP(hipMemsetAsync(d->dA, 0, (kk + kn) * sizeof(float), d->stream));  // empty shard: zeros into the sum
+            continue;
+        }
+        if (d->c_cap < d->Ns * k) {
+            dfree(d->c_row_ptr);
+            dfree(d->c_entry);
+            dfree(d->csr_ws);
+            CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->c_row_ptr), (size_t)(c->K + 1) * sizeof(int32_t)));
+            CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->c_entry), (size_t)d->Ns * k * sizeof(int32_t)));
+            d->csr_ws_bytes = lys_csr_workspace_bytes(c->K, k, d->Ns);
+            CTX_HIP(hipMalloc(&d->csr_ws, d->csr_ws_bytes ? d->csr_ws_bytes : 16));
+            d->c_cap = d->Ns * k;
+        }
+        CTX_RC(lys_csr_by_atom(d->r_idx, d->r_coef, d->r_nnz, c->K, k, d->Ns, d->c_row_ptr, d->c_entry, d->csr_ws,
+                               d->csr_ws_bytes, d->stream));
+        CTX_RC(lys_odl_increments(d->Xs, c->n, c->n, c->K, k, d->r_idx, d->r_coef, d->r_nnz, d->c_row_ptr, d->c_entry, d->dA,
+                                  d->dB, d->stream));
+    }
+    if (c->use_rccl)
+        CTX_RC(ctx_allreduce(c, [&](int i) { return static_cast<void*>(c->dev[i].dA); }, kk + kn, NCCL_FLOAT32));
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_RC(lys_axpby(d->A, beta, d->dA, (int64_t)kk, d->stream));
+        CTX_RC(lys_axpby(d->B, beta, d->dB, (int64_t)kn, d->stream));
+    }
+    return ctx_sync_all(c);
+}
+
+// The dictionary update of the mini-batch (online_dict_learn.py:91-98), replicated on every device
+int lys_ctx_odl_update(lys_ctx* c, int non_neg) {
+    if (!c || !c->dev[0].D || !c->dev[0].A) {
+        set_error("ctx_odl_update: nothing accumulated");
+        return LYS_EINVAL;
+    }
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_RC(lys_odl_update(d->D, d->A, d->B, c->n, c->K, non_neg, d->scratch, d->stream));
+        d->gram_valid = false;
+        d->codes_valid = false;
+    }
+    return ctx_sync_all(c);
+}
+
+// A [K][K] and B atom-major [K][n] (the reference's B is (n, K): its transpose), dense host arrays
+int lys_ctx_get_ab(lys_ctx* c, float* A_host, float* B_atom_major_host) {
+    if (!c || !c->dev[0].A || !A_host || !B_atom_major_host) {
+        set_error("ctx_get_ab: nothing accumulated / null pointer");
+        return LYS_EINVAL;
+    }
+    lys_dev* d = &c->dev[0];
+    CTX_HIP(hipSetDevice(d->device));
+    CTX_HIP(hipMemcpy2DAsync(A_host, (size_t)c->K * sizeof(float), d->A, (size_t)c->Kp * sizeof(float),
+                             (size_t)c->K * sizeof(float), (size_t)c->K, hipMemcpyDeviceToHost, d->stream));
+    CTX_HIP(hipMemcpy2DAsync(B_atom_major_host, (size_t)c->n * sizeof(float), d->B, (size_t)c->ldd * sizeof(float),
+                             (size_t)c->n * sizeof(float), (size_t)c->K, hipMemcpyDeviceToHost, d->stream));
+    CTX_HIP(hipStreamSynchronize(d->stream));
+    return LYS_OK;
+}
+
+int lys_ctx_set_ab(lys_ctx* c, const float* A_host, const float* B_atom_major_host) {
+    if (!c || !c->dev[0].D || !A_host || !B_atom_major_host) {
+        set_error("ctx_set_ab: no dictionary / null pointer");
+        return LYS_EINVAL;
+    }
+    for (int i = 0; i < c->nd; ++i) {
+        lys_dev* d = &c->dev[i];
+        CTX_HIP(hipSetDevice(d->device));
+        CTX_RC(dev_reserve_odl(c, d));
+        CTX_HIP(hipMemsetAsync(d->A, 0, (size_t)c->Kp * c->Kp * sizeof(float), d->stream));
+        CTX_HIP(hipMemsetAsync(d->B, 0, (size_t)c->Kp * c->ldd * sizeof(float), d->stream));
+        CTX_HIP(hipMemcpy2DAsync(d->A, (size_t)c->Kp * sizeof(float), A_host, (size_t)c->K * sizeof(float),
+                                 (size_t)c->K * sizeof(float), (size_t)c->K, hipMemcpyHostToDevice, d->stream));
+        CTX_HIP(hipMemcpy2DAsync(d->B, (size_t)c->ldd * sizeof(float), B_atom_major_host, (size_t)c->n * sizeof(float),
+                                 (size_t)c->n * sizeof(float), (size_t)c->K, hipMemcpyHostToDevice, d->stream));
+    }
+    return ctx_sync_all(c);
 }
 
 }  // extern "C"

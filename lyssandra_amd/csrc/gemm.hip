@@ -385,7 +385,12 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 // three bf16 planes of two floats (packed lo | hi << 16 per plane)
 __device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
     p1 = cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    // a leading plane that is not finite (x = +-inf, or |x| above bf16's largest finite 3.39e38, which rounds to inf)
+    // carries the whole value: its residual planes are flushed to zero instead of becoming inf - inf = NaN.  The product
+    // is then +-inf (or NaN against a zero, like any inf) where the fp32 MFMA kernel would return the same for x = inf
+    // and a finite 3.4e38-sized number for 3.39e38 < |x| <= FLT_MAX: saturation, documented in DESIGN.md 3.1.
+    const float ha = __uint_as_float(p1 << 16), hb = __uint_as_float(p1 & 0xffff0000u);
+    const float ra = (fabsf(ha) < __builtin_inff()) ? a - ha : 0.f, rb = (fabsf(hb) < __builtin_inff()) ? b - hb : 0.f;
     p2 = cvt_pk_bf16(ra, rb);
     const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xffff0000u);
     p3 = cvt_pk_bf16(sa, sb);

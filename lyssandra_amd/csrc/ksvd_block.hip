@@ -259,15 +259,17 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     BK_NSTAMP(2);
     // the atom loop runs on 4 waves (one per SIMD, 16 teams): with more waves the redundant per-team normalisation
     // below, not the group evaluation, is most of an atom's time.  The other waves were only needed to stage the slab.
+    // Those waves stay alive and idle at the barriers below (a barrier that not every thread of the workgroup reaches is
+    // undefined in the HIP model, whatever gfx9's s_barrier does about terminated waves).
     constexpr int NT = 16;  // teams in the atom loop
-    if (tid >= 16 * NT) return;
+    const bool active = tid < 16 * NT;
     for (int t = 0; t < B; ++t) {
         const int a = c * B + t;
         if (a >= K) break;
         if (s_cnt[t] == 0.f) continue;  // unused atom keeps its column (ksvd.py:112-115): dnew[t] == dold[t]; uniform
         // groups with target t: team j evaluates list entries gfirst[t] + j, + NT, ..
         const int lbeg = gfirst[t], lend = gfirst[t + 1];
-        for (int li = lbeg + team; li < lend; li += NT) {
+        for (int li = lbeg + team; active && li < lend; li += NT) {
             const int g = glist[li];
             const int sl = gslot[g];
             const unsigned pi = (unsigned)(g - ((1 << t) - 1 - t)) + 1u;
@@ -331,7 +333,8 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
                 }
             }
         }
-        if (lend > lbeg) __syncthreads();  // uniform; waves 4.. have exited: the barrier counts the live waves only
+        if (lend > lbeg) __syncthreads();  // uniform over the workgroup
+        if (!active) continue;
         // every team: s = S_t + d_old sum x^2 + groups, d_new = s / (||s|| + eps)  (utils/math.py:61-62; eps only matters
         // for s = 0, where the result is the zero vector either way)
         float4 sv[FB];
@@ -372,7 +375,7 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     __syncthreads();
     // the new atoms leave LDS once, at the end: a global store inside the loop would put a fabric write-acknowledge
     // (the fence of __syncthreads) on every atom's critical path
-    for (int i = tid; i < B * ldd; i += 16 * NT) {
+    for (int i = tid; i < B * ldd; i += NTH) {
         const int t = i / ldd, f = i % ldd, a = c * B + t;
         if (a < K) Dnext[(int64_t)a * ldd + f] = (f < n) ? dnew[t * NF + f] : 0.f;
     }

@@ -36,7 +36,11 @@ def world(group=None):
 def allreduce_sum_(t, group=None):
     """In-place sum over ranks of a torch tensor (no-op without an initialised process group)."""
     dist = _dist()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    # LYS_DIST_FORCE=1: issue the collective also in a world of one rank (a self-reduction = identity) -- lets a single-GPU box
+    # execute the RCCL branch below (tests/test_gpu_parity.py::test_rccl_backend_world_of_one)
+    import os
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1
+                                                          or os.environ.get("LYS_DIST_FORCE") == "1"):
         if not t.is_cuda and dist.get_backend(group) == "nccl":
             import torch
             d = t.to(torch.device("cuda", torch.cuda.current_device()))  # RCCL only moves device memory

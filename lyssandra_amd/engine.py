@@ -120,6 +120,7 @@ class DeviceDictionary(object):
 
 
 _ws_cache = {}
+_WS_CACHE_MAX = 8
 
 
 def _workspace(nbytes, device, tag):
@@ -129,6 +130,10 @@ def _workspace(nbytes, device, tag):
     key = (str(device), tag, int(torch.cuda.current_stream(device).cuda_stream))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        # a handful of live (device, tag, stream) entries at most: streams come and go (thread pools, per-call streams),
+        # and every entry can hold a multi-GiB alpha0 tile -- the oldest entries are dropped first
+        while len(_ws_cache) >= _WS_CACHE_MAX:
+            _ws_cache.pop(next(iter(_ws_cache)))
         buf = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
@@ -670,6 +675,11 @@ class OdlState(object):
         dd = self.dd
         Xs, idx, coef, nnz = self._batch
         k = int(idx.shape[1])
+        if int(idx.shape[0]) == 0:
+            # an empty local shard of a mini-batch (fewer signals than ranks): contribute zeros, still join the all-reduce
+            self.dA.zero_()
+            self.dB.zero_()
+            return self.dA, self.dB
         row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
         _lib.check(lib.lys_odl_increments(_ptr(Xs), _ld(Xs), dd.n, dd.K, k, _ptr(idx), _ptr(coef), _ptr(nnz),
                                           _ptr(row_ptr), _ptr(entry), _ptr(self.dA), _ptr(self.dB), _stream()),

@@ -172,10 +172,13 @@ def test_c_caller_compiles_and_links(lib):
     tests/test_gpu_parity.py::test_c_abi_context)."""
     import subprocess
     import tempfile
-    libdir = os.path.join(ROOT, "lyssandra_amd")
+    from oracle import c_oracle
+    c_oracle.build()   # the program grades its K-SVD cycle against the float64 C restatement
+    libdir, oradir = os.path.join(ROOT, "lyssandra_amd"), os.path.join(ROOT, "oracle")
     exe = os.path.join(tempfile.mkdtemp(prefix="lys_cabi_"), "c_abi_smoke")
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-o", exe, os.path.join(ROOT, "tests", "c_abi_smoke.c"),
-                        "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-llyssa_hip", "-lm", "-Wl,-rpath," + libdir],
+                        "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-llyssa_hip", "-L" + oradir, "-lbomp_oracle", "-lm",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath," + oradir],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     assert os.path.exists(exe)

@@ -627,16 +627,22 @@ def test_online_dict_learn_golden(eng):
 
 
 # ------------------------------------------------------------------------------------------------ sharded (N > 1) path
-def _sharded_worker(rank, world, port, out):
-    """Two ranks share cuda:0 (gloo moves the CUDA tensors): the product protocol code + HIP kernels on shards."""
+def _sharded_worker(rank, world, port, out, backend="gloo"):
+    """gloo: two ranks share cuda:0 (gloo moves the CUDA tensors); nccl: one rank per GPU over RCCL.  Either way the
+    product protocol code + HIP kernels on shards."""
     import os
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(rank if backend == "nccl" else 0)
         from lyssandra_amd import engine as eng, dist as ld
         g = load_golden("F5")
         X, D0, k = g["X"].astype(np.float64), g["D0"].astype(np.float64), int(g["k"])
@@ -678,13 +684,97 @@ def _sharded_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
+def _free_port():
     import socket
-    import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def _rccl_world1_worker(rank, port, out):
+    """One rank, backend nccl (= RCCL), LYS_DIST_FORCE=1: every statistics exchange of the sharded protocols is issued as
+    an RCCL all-reduce over a world of one (identity), so the nccl branch of lyssandra_amd/dist.py runs on a 1-GPU box."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["LYS_DIST_FORCE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from lyssandra_amd import engine as eng
+        g = load_golden("F5")
+        X, D0, k = g["X"].astype(np.float64), g["D0"].astype(np.float64), int(g["k"])
+        Xs = eng.signals_to_device(X)
+        dd = eng.DeviceDictionary.from_host(D0)
+        idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+        R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+        unused = eng.ksvd_cycle(R, dd, idx, coef, nnz, group=dist.group.WORLD)
+        D1 = dd.to_host()
+        state = eng.OdlState(dd)
+        state.batch_update(Xs, idx, coef, nnz, 0.0, group=dist.group.WORLD)
+        t = torch.ones(8, device="cuda")
+        dist.all_reduce(t)
+        out[0] = dict(D=D1, unused=unused, coef=coef.cpu().numpy(), A=state.A_host(), D_odl=dd.to_host(),
+                      backend=dist.get_backend(), ones=float(t.sum().item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_world_of_one(eng):
+    """The `nccl` (RCCL) backend executes: a one-rank process group whose collectives are forced (LYS_DIST_FORCE=1) must
+    reproduce the single-GPU K-SVD cycle and online-DL batch."""
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_world1_worker, args=(_free_port(), out), nprocs=1, join=True)
+    r = out[0]
+    assert r["backend"] == "nccl" and r["ones"] == 8.0
+    g = load_golden("F5")
+    X, D0, k = g["X"].astype(np.float64), g["D0"].astype(np.float64), int(g["k"])
+    Xs = eng.signals_to_device(X)
+    dd = eng.DeviceDictionary.from_host(D0)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+    unused = eng.ksvd_cycle(R, dd, idx, coef, nnz)
+    assert unused == r["unused"]
+    assert _atom_err(r["D"], dd.to_host()) < 2e-6
+    assert np.max(np.abs(r["coef"] - coef.cpu().numpy())) < 1e-5 * np.abs(r["coef"]).max()
+    st = eng.OdlState(dd)
+    st.batch_update(Xs, idx, coef, nnz, 0.0)
+    assert np.max(np.abs(st.A_host() - r["A"])) < 1e-5 * np.abs(r["A"]).max()
+    assert _atom_err(r["D_odl"], dd.to_host()) < 1e-5
+
+
+def test_sharded_ksvd_and_odl_two_gpus_rccl(eng):
+    """The sharded protocols over RCCL on two GPUs, one rank per GPU (skipped on a single-GPU box: the first multi-GPU box
+    that runs the suite exercises it)."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    out = mp.Manager().dict()
+    mp.spawn(_sharded_worker, args=(2, _free_port(), out, "nccl"), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert np.array_equal(r0["D"], r1["D"]) and np.array_equal(r0["D_odl"], r1["D_odl"])
+    assert np.array_equal(r0["Dk"], r1["Dk"]) and np.array_equal(r0["Do"], r1["Do"])
+    g = load_golden("F5")
+    X, D0, k = g["X"].astype(np.float64), g["D0"].astype(np.float64), int(g["k"])
+    Xs = eng.signals_to_device(X)
+    dd = eng.DeviceDictionary.from_host(D0)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+    unused = eng.ksvd_cycle(R, dd, idx, coef, nnz)
+    assert unused == r0["unused"] == r1["unused"]
+    assert _atom_err(r0["D"], dd.to_host()) < 2e-6
+
+
+def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
+    import torch.multiprocessing as mp
+    port = _free_port()
     out = mp.Manager().dict()
     mp.spawn(_sharded_worker, args=(2, port, out), nprocs=2, join=True)
     r0, r1 = out[0], out[1]
@@ -1164,7 +1254,9 @@ def test_synth_signals_match_host_generator(eng):
 
 def test_c_abi_context(eng):
     """The library-owned context of include/lyssa_hip.h: (i) a plain C program compiled with gcc -- no
-    PyTorch, no HIP calls of its own -- sets a dictionary, encodes host arrays and reads the timings; (ii) through
+    PyTorch, no HIP calls of its own -- sets a dictionary, encodes host arrays and reads the timings, then runs one
+    approx-K-SVD cycle on resident signals (graded inside the program against the float64 C restatement from the same
+    codes), the same cycle through the RCCL path (communicator over one device) and one online-DL mini-batch; (ii) through
     ctypes, the context's host-pointer encode equals the engine's device-resident encode on the same signals."""
     import ctypes
     import subprocess
@@ -1175,8 +1267,11 @@ def test_c_abi_context(eng):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     libdir = os.path.join(root, "lyssandra_amd")
     exe = os.path.join(tempfile.mkdtemp(prefix="lys_cabi_"), "c_abi_smoke")
-    subprocess.run(["gcc", "-O1", "-o", exe, os.path.join(root, "tests", "c_abi_smoke.c"), "-I" + os.path.join(root, "include"),
-                    "-L" + libdir, "-llyssa_hip", "-lm", "-Wl,-rpath," + libdir], check=True)
+    oradir = os.path.join(root, "oracle")
+    c_oracle.build()
+    subprocess.run(["gcc", "-O1", "-std=c99", "-Wall", "-Werror", "-o", exe, os.path.join(root, "tests", "c_abi_smoke.c"),
+                    "-I" + os.path.join(root, "include"), "-L" + libdir, "-llyssa_hip", "-L" + oradir, "-lbomp_oracle", "-lm",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath," + oradir], check=True)
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout
     # (ii)
@@ -1246,6 +1341,94 @@ def test_c_abi_context_tiles_and_dictionary_change(eng):
     _lib.check(lib.lys_ctx_create(0, ctypes.byref(ctx2)), "ctx_create")
     assert lib.lys_ctx_bomp_encode(ctx2, P(Xh), 10, 3, P(idx), P(coef), P(nnz)) < 0                # no dictionary yet
     lib.lys_ctx_destroy(ctx2)
+
+
+def test_c_abi_context_same_padded_shape_larger_n(eng):
+    """n = 57 and n = 64 share ldd = 64 and (K = 200 / 256) Kp = 256: replacing the dictionary on ONE context must re-plan the
+    [tile][n] signal staging (round 2 kept the n = 57 buffer and overran it)."""
+    import ctypes
+    import torch
+    from oracle import c_oracle
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    ctx = ctypes.c_void_p()
+    _lib.check(lib.lys_ctx_create(0, ctypes.byref(ctx)), "ctx_create")
+    try:
+        for (n, K, k, N) in [(57, 200, 4, 6000), (64, 256, 4, 6000), (57, 256, 4, 6000)]:
+            rs = np.random.RandomState(n + K)
+            D = rs.randn(n, K)
+            D = (D / np.linalg.norm(D, axis=0)).astype(np.float32)
+            Xh = c_oracle.synth_signals(n, 9, N, n)
+            _lib.check(lib.lys_ctx_set_dictionary(ctx, P(np.ascontiguousarray(D.T)), n, K), "set_dictionary")
+            idx = np.full((N, k), -9, dtype=np.int32)
+            coef = np.empty((N, k), dtype=np.float32)
+            nnz = np.empty((N,), dtype=np.int32)
+            _lib.check(lib.lys_ctx_bomp_encode(ctx, P(Xh), N, k, P(idx), P(coef), P(nnz)), "encode")
+            dd = eng.DeviceDictionary.from_host(D.astype(np.float64))
+            i2, c2, z2 = eng.bomp_encode(torch.from_numpy(Xh).cuda(), dd, k)
+            assert np.array_equal(idx, i2.cpu().numpy()) and np.array_equal(coef, c2.cpu().numpy())
+    finally:
+        lib.lys_ctx_destroy(ctx)
+
+
+def test_ctx_learning_matches_engine(eng):
+    """The context's resident-signal learning calls against the engine's device-resident path on the same data: codes,
+    one K-SVD cycle (dictionary to 1e-6: statistics are summed with atomics), error; unused-atom list; set_atom."""
+    import ctypes
+    import torch
+    from oracle import c_oracle
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    n, K, k, N = 64, 300, 5, 30000
+    rs = np.random.RandomState(11)
+    D = rs.randn(n, K)
+    D[:, 17] = 1e-3 * D[:, 18]          # a nearly useless direction: still normalised, rarely (never) selected
+    D = (D / np.linalg.norm(D, axis=0)).astype(np.float32)
+    Xh = c_oracle.synth_signals(21, 0, N, n)
+    ctx = ctypes.c_void_p()
+    _lib.check(lib.lys_ctx_create(0, ctypes.byref(ctx)), "ctx_create")
+    try:
+        _lib.check(lib.lys_ctx_set_dictionary(ctx, P(np.ascontiguousarray(D.T)), n, K), "set_dictionary")
+        _lib.check(lib.lys_ctx_set_signals(ctx, P(Xh), N), "set_signals")
+        _lib.check(lib.lys_ctx_encode_resident(ctx, k), "encode_resident")
+        idx = np.empty((N, k), dtype=np.int32)
+        coef = np.empty((N, k), dtype=np.float32)
+        nnz = np.empty((N,), dtype=np.int32)
+        _lib.check(lib.lys_ctx_get_codes(ctx, P(idx), P(coef), P(nnz)), "get_codes")
+        e0 = ctypes.c_double()
+        _lib.check(lib.lys_ctx_error(ctx, ctypes.byref(e0)), "error")
+        nu = ctypes.c_int(-1)
+        _lib.check(lib.lys_ctx_ksvd_sweep(ctx, ctypes.byref(nu)), "ksvd_sweep")
+        Dn = np.empty((K, n), dtype=np.float32)
+        _lib.check(lib.lys_ctx_get_dictionary(ctx, P(Dn)), "get_dictionary")
+        un = np.full((K,), -1, dtype=np.int32)
+        _lib.check(lib.lys_ctx_get_unused(ctx, P(un), K), "get_unused")
+        e1 = ctypes.c_double()
+        _lib.check(lib.lys_ctx_error(ctx, ctypes.byref(e1)), "error")
+        # the engine on the same signals
+        Xs = torch.from_numpy(Xh).cuda()
+        dd = eng.DeviceDictionary.from_host(D.astype(np.float64))
+        i2, c2, z2 = eng.bomp_encode(Xs, dd, k)
+        assert np.array_equal(idx, i2.cpu().numpy()) and np.array_equal(coef, c2.cpu().numpy())
+        R, err0 = eng.residual(Xs, dd, i2, c2, z2)
+        assert abs(err0 - e0.value) <= 1e-9 * err0
+        unused = eng.ksvd_cycle(R, dd, i2, c2, z2)
+        assert sorted(unused) == sorted(un[:nu.value].tolist())
+        D2 = dd.to_host().T.astype(np.float32)
+        assert np.abs(D2 - Dn).max() < 1e-6
+        err1 = eng.approx_error(Xs, dd, i2, c2, z2)
+        assert abs(err1 - e1.value) <= 1e-6 * err1 and e1.value < e0.value
+        # replace an atom, codes become invalid until the next encode
+        col = Xh[5] / np.linalg.norm(Xh[5])
+        _lib.check(lib.lys_ctx_set_atom(ctx, 17, P(np.ascontiguousarray(col))), "set_atom")
+        assert lib.lys_ctx_error(ctx, ctypes.byref(e1)) < 0
+        _lib.check(lib.lys_ctx_encode_resident(ctx, k), "encode_resident")
+        _lib.check(lib.lys_ctx_get_dictionary(ctx, P(Dn)), "get_dictionary")
+        assert np.array_equal(Dn[17], col)
+    finally:
+        lib.lys_ctx_destroy(ctx)
 
 
 @pytest.mark.parametrize("n,K", [(64, 128), (40, 256), (64, 1024)])
