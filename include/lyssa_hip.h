@@ -84,6 +84,13 @@ int lys_thresh_encode(const float* X, int64_t ldx, const float* D_packed,
                       int n, int K, int k, int64_t N,
                       int32_t* idx, float* coef, int32_t* nnz,
                       void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * Which kernel computes alpha0 for n <= 64: 1 = three bf16 planes per operand on the bf16 matrix cores (fp32 accuracy, the
+ * default), 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products), -1 = follow LYS_ALPHA0_BF16X3 again.  Process-wide, takes
+ * effect at the next encode call; returns the previously effective mode (0 / 1).  Both produce `fast_dot(D.T, X)` of
+ * lyssa/sparse_coding.py:631 to fp32 rounding.
+ */
+int lys_set_alpha0_bf16x3(int mode);
 /* Only the alpha0 = X D GEMM of the above (timing / MFMA-stage measurement). alpha0 is [N][Kp]. */
 int lys_alpha0(const float* X, int64_t ldx, const float* D_packed, int n, int K, int64_t N,
                float* alpha0, void* stream);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "lys_norm_atoms": (_I, [_P, _I, _I, _P]),
     "lys_densify_f64": (_I, [_P, _P, _P, _I, _I, _L, _P, _P]),
     "lys_debug_bomp_variant": (_I, [_P, _P, _L, _I, _P, _P, _P, _I, _I, _P]),
+    "lys_set_alpha0_bf16x3": (_I, [_I]),
     "lys_profile_enable": (_I, [_I]),
     "lys_profile_collect": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(_I), ctypes.POINTER(_L)]),

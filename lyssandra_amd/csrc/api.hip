@@ -132,7 +132,9 @@ int64_t tile_signals(int Kp) {
 // alpha0 = X D: signal-tile-stationary kernel for n <= 64, generic NT GEMM otherwise
 // `split_scratch` (alpha0_bf16x3_scratch_bytes, or null): room for the dictionary's three bf16 planes -- with it the
 // n <= 64 product runs on the bf16 matrix cores at fp32 accuracy (gemm.hip, "bf16x3"); LYS_ALPHA0_BF16X3=0 disables it.
+static int g_alpha0_override = -1;  // lys_set_alpha0_bf16x3: -1 = follow the environment
 static bool alpha0_bf16x3_enabled() {
+    if (g_alpha0_override >= 0) return g_alpha0_override == 1;
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("LYS_ALPHA0_BF16X3");
@@ -720,6 +722,12 @@ int lys_debug_bomp_variant(const float* alpha0, const float* G, int64_t N, int k
     }
     if (variant >= 100) return bomp_x_variant(alpha0, G, N, k, idx, coef, nnz, variant, lds_bytes, STREAM(stream));
     return bomp_debug_variant(alpha0, G, N, k, idx, coef, nnz, variant, lds_bytes, STREAM(stream));
+}
+
+int lys_set_alpha0_bf16x3(int mode) {
+    const int prev = alpha0_bf16x3_enabled() ? 1 : 0;
+    g_alpha0_override = (mode < 0) ? -1 : (mode ? 1 : 0);
+    return prev;
 }
 
 int lys_profile_enable(int on) {

@@ -30,7 +30,7 @@ _REFERENCE_ALGORITHMS = ('omp', 'bomp', 'thresh', 'nnomp', 'group_omp', 'sparse_
 class sparse_encoder(object):
     """MI355X implementation of the reference's sparse_encoder (only ``algorithm='bomp'`` is accelerated)."""
 
-    def __init__(self, algorithm='omp', params=None, n_jobs=1, verbose=True, mmap=False, name='sparse_coder'):
+    def __init__(self, algorithm='omp', params=None, n_jobs=1, verbose=True, mmap=False, name='sparse_coder', n_gpus=1):
         # lyssa/sparse_coding.py:587-598
         self.name = name
         self.algorithm = algorithm
@@ -44,6 +44,11 @@ class sparse_encoder(object):
         self.verbose = verbose
         self.mmap = mmap
         self.device = None        # None => current HIP device
+        # n_gpus > 1 (or -1 = every visible device): ONE process shards the columns of X over the devices the way the
+        # reference's run_parallel(n_jobs=N) shards them over worker processes (lyssa/sparse_coding.py:713-724,
+        # lyssa/utils/__init__.py:92-129) -- through the library-owned multi-device context (lys_ctx_create_multi)
+        self.n_gpus = n_gpus
+        self._ctx_devices = None  # test hook: explicit device list for the context path (also with one device)
         self._dd = None           # cached DeviceDictionary (re-packed on every call: D may have changed)
 
     # -- reference API ---------------------------------------------------------------------------------
@@ -57,9 +62,56 @@ class sparse_encoder(object):
         if self.params.get('lambda') is not None:
             assert self.params.get('lambda') <= n_atoms
         self._check_algorithm()
+        devs = self._multi_devices()
+        if devs is not None:
+            return self._encode_multi(X, D, devs)
         idx, coef, nnz = self.encode_sparse(X, D)
         out = _empty_mmap((n_atoms, n_samples)) if self.mmap else None
         return engine.densify(idx, coef, nnz, n_atoms, out=out)
+
+    def _multi_devices(self):
+        if self._ctx_devices is not None:
+            return list(self._ctx_devices)
+        if self.n_gpus in (None, 0, 1) or self.algorithm != 'bomp':
+            return None
+        import torch
+        n_dev = torch.cuda.device_count()
+        want = n_dev if self.n_gpus == -1 else int(self.n_gpus)
+        if want > n_dev:
+            raise ValueError("n_gpus=%d but only %d HIP device(s) are visible" % (want, n_dev))
+        return list(range(want)) if want > 1 else None
+
+    def _encode_multi(self, X, D, devices):
+        """'bomp' over several devices in this one process: host arrays in, dense float64 (K, N) out."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        engine.require_gpu()
+        n, N = X.shape
+        K = D.shape[1]
+        k = self._k(K)
+        Xh = np.ascontiguousarray(np.asarray(X).T, dtype=np.float32)       # signal-major [N][n]
+        Dh = np.ascontiguousarray(np.asarray(D).T, dtype=np.float32)       # atom-major [K][n]
+        idx = np.empty((N, k), dtype=np.int32)
+        coef = np.empty((N, k), dtype=np.float32)
+        nnz = np.empty((N,), dtype=np.int32)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        ids = (ctypes.c_int * len(devices))(*devices)
+        ctx = ctypes.c_void_p()
+        _lib.check(lib.lys_ctx_create_multi(len(devices), ids, ctypes.byref(ctx)), "lys_ctx_create_multi")
+        try:
+            _lib.check(lib.lys_ctx_set_dictionary(ctx, P(Dh), n, K), "lys_ctx_set_dictionary")
+            _lib.check(lib.lys_ctx_bomp_encode(ctx, P(Xh), N, k, P(idx), P(coef), P(nnz)), "lys_ctx_bomp_encode")
+        finally:
+            lib.lys_ctx_destroy(ctx)
+        Z = _empty_mmap((K, N)) if self.mmap else np.zeros((K, N))
+        if self.mmap:
+            Z[:] = 0.0
+        cols = np.arange(N)
+        for j in range(k):
+            m = nnz > j
+            Z[idx[m, j], cols[m]] = coef[m, j]
+        return Z
 
     # -- extended API ----------------------------------------------------------------------------------
     def encode_sparse(self, X, D):

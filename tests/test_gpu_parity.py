@@ -59,10 +59,22 @@ def _compare_supports(idx, coef, nnz, g_idx, g_coef, g_nnz, gap, label):
     assert not bad_coef, "%s: coefficient mismatch %s" % (label, bad_coef[:10])
 
 
+@pytest.fixture(params=[1, 0], ids=["alpha0_bf16x3", "alpha0_fp32_mfma"])
+def alpha0_mode(request):
+    """Both alpha0 kernels of the n <= 64 encode path in ONE process: the bf16-plane kernel (default) and the fp32 MFMA
+    kernel it replaced (lys_set_alpha0_bf16x3; the LYS_ALPHA0_BF16X3=0 fallback)."""
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    prev = lib.lys_set_alpha0_bf16x3(request.param)
+    yield request.param
+    lib.lys_set_alpha0_bf16x3(-1)
+    assert prev in (0, 1)
+
+
 # ------------------------------------------------------------------------------------------------ GEMMs
 @pytest.mark.parametrize("n,K,N", [(64, 1024, 300), (64, 256, 129), (17, 100, 33), (256, 512, 64), (10, 4, 100),
                                    (128, 4096, 70)])
-def test_gram_and_alpha0(eng, n, K, N):
+def test_gram_and_alpha0(eng, n, K, N, alpha0_mode):
     import ctypes
     import torch
     from lyssandra_amd import _lib
@@ -1123,7 +1135,7 @@ def test_empty_and_ragged_batches(eng):
 
 
 # ------------------------------------------------------------------------------------------------ large direct parity
-def test_bomp_direct_parity_262144_signals(eng):
+def test_bomp_direct_parity_262144_signals(eng, alpha0_mode):
     """SURVEY 8(d) parity protocol at scale: 2^18 seeded Gaussian patches at the metric shape, GPU supports / order /
     coefficients against the float64 C restatement of the oracle (oracle/bomp_oracle.c, pinned to the reference)."""
     import torch
@@ -1183,7 +1195,7 @@ _SWEEP = [(n, K, k) for (n, K) in [(8, 40), (17, 64), (24, 100), (32, 128), (50,
 
 
 @pytest.mark.parametrize("n,K,k", _SWEEP)
-def test_bomp_template_sweep(eng, n, K, k):
+def test_bomp_template_sweep(eng, n, K, k, alpha0_mode):
     """Every kernel family (atoms per lane 1..16, k templates 5/10/20/32, multi-wave kernels above K = 1024, generic
     fallback) against the float64 C oracle on 1500 seeded signals: identical supports and order on no-tie signals,
     coefficients within 1e-5 of max|z|."""
@@ -1196,6 +1208,8 @@ def test_bomp_template_sweep(eng, n, K, k):
     Xs = torch.randn((N, n), device="cuda", generator=gen)
     dd = eng.DeviceDictionary(n, K)
     dd.set(Dt)
+    if alpha0_mode == 0 and n > 64:
+        pytest.skip("n > 64 has one alpha0 kernel (gemm_nt_f32_kernel): covered by the other parameter")
     idx, coef, nnz = _host_triplet(eng.bomp_encode(Xs, dd, k))
     D = dd.D[:K, :n].t().contiguous().double().cpu().numpy()
     X = Xs.t().contiguous().double().cpu().numpy()
@@ -1372,6 +1386,30 @@ def test_c_abi_context_same_padded_shape_larger_n(eng):
         lib.lys_ctx_destroy(ctx)
 
 
+def test_sparse_encoder_n_gpus_context_path(eng):
+    """`sparse_encoder(..., n_gpus=N)`: one process, columns sharded over the devices by the multi-device context.  On a
+    one-GPU box the context path runs over the single device (test hook) and must equal the engine path bit for bit; with
+    two or more GPUs n_gpus=-1 is compared as well."""
+    import torch
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    rs = np.random.RandomState(5)
+    n, K, k, N = 64, 256, 5, 10001
+    D = rs.randn(n, K)
+    D /= np.linalg.norm(D, axis=0)
+    X = rs.randn(n, N)
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    Z0 = se.encode(X, D)
+    se1 = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    se1._ctx_devices = [0]
+    Z1 = se1.encode(X, D)
+    assert Z1.dtype == np.float64 and Z1.shape == (K, N) and np.array_equal(Z0, Z1)
+    if torch.cuda.device_count() >= 2:
+        Z2 = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False, n_gpus=-1).encode(X, D)
+        assert np.array_equal(Z0, Z2)
+    with pytest.raises(ValueError):
+        sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, n_gpus=torch.cuda.device_count() + 1).encode(X, D)
+
+
 def test_ctx_learning_matches_engine(eng):
     """The context's resident-signal learning calls against the engine's device-resident path on the same data: codes,
     one K-SVD cycle (dictionary to 1e-6: statistics are summed with atomics), error; unused-atom list; set_atom."""
@@ -1432,10 +1470,10 @@ def test_ctx_learning_matches_engine(eng):
 
 
 @pytest.mark.parametrize("n,K", [(64, 128), (40, 256), (64, 1024)])
-def test_alpha0_bf16_planes_wide_dynamic_range(eng, n, K):
-    """The alpha0 product of the encode path (n <= 64: three bf16 planes per operand on the bf16 matrix cores) on data
-    with six decades of dynamic range inside a signal and signals from 1e-20 to 1e+20: the 'thresh' encoder returns the
-    correlations themselves, compared with the float64 product under fp32's forward error bound
+def test_alpha0_bf16_planes_wide_dynamic_range(eng, n, K, alpha0_mode):
+    """The alpha0 product of the encode path (n <= 64: three bf16 planes per operand on the bf16 matrix cores, or the fp32
+    MFMA kernel) on data with six decades of dynamic range inside a signal and signals from 1e-20 to 1e+20: the 'thresh'
+    encoder returns the correlations themselves, compared with the float64 product under fp32's forward error bound
     |err| <= c * eps32 * sum_f |x_f| |d_f|."""
     from lyssandra_amd.sparse_coding import sparse_encoder
     rs = np.random.RandomState(n + K)
@@ -1458,3 +1496,69 @@ def test_alpha0_bf16_planes_wide_dynamic_range(eng, n, K):
     clear = (srt[k - 1] - srt[k]) > 1e-5 * bound.max(axis=0)
     top = A >= srt[k - 1][None, :]
     assert np.array_equal(nz[:, clear], top[:, clear])
+
+
+@pytest.mark.parametrize("n,K", [(64, 256), (48, 128)])
+def test_alpha0_every_correlation_1e36_range_and_non_finite_policy(eng, n, K, alpha0_mode):
+    """ALL K correlations of every signal (lys_alpha0, not the top-k) over signal scales 1e-36 .. 1e+36, against the float64
+    product under fp32's forward bound.  Policy pinned here:
+      * finite results whose exact value is a NORMAL fp32 number: within the bound (the third bf16 plane of an operand below
+        ~1e-30 is denormal in fp32 -- it is kept, not flushed: hipcc's default kernel mode preserves fp32 denormals);
+      * results below fp32's normal range: absolute error <= 2^-126 (a few denormal ulps of the planes), never NaN;
+      * an operand above bf16's largest finite value (3.39e38) or infinite: the bf16-plane kernel returns +-inf or NaN, never a
+        finite wrong number; the fp32 MFMA kernel returns the fp32 product (finite or inf)."""
+    import ctypes
+    import torch
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(3 * n + K)
+    N = 512
+    D = rs.randn(n, K)
+    D = (D / np.linalg.norm(D, axis=0)).astype(np.float32)
+    X = rs.randn(N, n) * 10.0 ** rs.uniform(-2, 2, size=(N, n))
+    X *= 10.0 ** rs.uniform(-36, 36, size=(N, 1))
+    with np.errstate(over='ignore'):
+        X = X.astype(np.float32)
+    X[~np.isfinite(X)] = 1.0
+    dd = eng.DeviceDictionary.from_host(D.astype(np.float64))
+    Xs = torch.from_numpy(X).cuda()
+    a0 = torch.empty((N, dd.Kp), dtype=torch.float32, device=dd.device)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.lys_alpha0(ctypes.c_void_p(Xs.data_ptr()), Xs.stride(0), ctypes.c_void_p(dd.D.data_ptr()), n, K, N,
+                              ctypes.c_void_p(a0.data_ptr()), st), "lys_alpha0")
+    A = a0.cpu().numpy()[:, :K].astype(np.float64)
+    Aref = X.astype(np.float64) @ D.astype(np.float64)
+    bound = np.abs(X.astype(np.float64)) @ np.abs(D.astype(np.float64))
+    tiny = 2.0 ** -126
+    fits = np.abs(Aref) + 32 * 1.2e-7 * bound < 3.0e38           # the fp32 result cannot overflow
+    assert np.isfinite(A[fits]).all()
+    normal = fits & (bound > 64 * tiny)
+    assert (np.abs(A - Aref)[normal] <= 16 * 1.2e-7 * bound[normal] + 4 * tiny).all()
+    assert (np.abs(A - Aref)[fits & ~normal] <= 64 * tiny).all()
+    assert not np.isnan(A[~fits]).any()                          # overflow gives inf, not NaN
+    # non-finite / above-bf16-range operands
+    Xn = rs.randn(8, n).astype(np.float32)
+    Xn[0, 3] = np.float32(3.4e38)        # finite in fp32, above bf16's largest finite value
+    Xn[1, 5] = np.inf
+    Xn[2, 7] = -np.inf
+    Xn[3, 1] = np.nan
+    Xs = torch.from_numpy(Xn).cuda()
+    a1 = torch.empty((8, dd.Kp), dtype=torch.float32, device=dd.device)
+    _lib.check(lib.lys_alpha0(ctypes.c_void_p(Xs.data_ptr()), Xs.stride(0), ctypes.c_void_p(dd.D.data_ptr()), n, K, 8,
+                              ctypes.c_void_p(a1.data_ptr()), st), "lys_alpha0")
+    B = a1.cpu().numpy()[:, :K]
+    with np.errstate(all='ignore'):
+        Bref = Xn.astype(np.float64) @ D.astype(np.float64)
+    ok_rows = B[4:]
+    assert np.isfinite(ok_rows).all() and np.abs(ok_rows - Bref[4:]).max() < 1e-4      # rows without special values
+    assert np.isnan(B[3]).all()                                                         # NaN in, NaN out
+    for r in (1, 2):                                                                    # +-inf: inf of the right sign (NaN
+        hit = np.abs(D[:, :].T[:, [5, 7][r - 1]]) > 1e-3                                 # only against a ~zero weight)
+        assert (np.isinf(B[r][hit]) & (np.sign(B[r][hit]) == np.sign(Bref[r][hit]))).all()
+    big = np.abs(D.T[:, 3]) > 1e-3
+    if alpha0_mode == 1:
+        assert (~np.isfinite(B[0][big])).all() or (np.abs(B[0][big] - Bref[0][big]) <= 1e-5 * np.abs(Bref[0][big])).all()
+        assert not (np.isfinite(B[0]) & (np.abs(B[0] - Bref[0]) > 1e-3 * np.abs(Bref[0]) + 1e30)).any()
+    else:
+        fin = np.abs(Bref[0]) < 3.0e38
+        assert (np.abs(B[0][fin] - Bref[0][fin]) <= 1e-5 * np.abs(Bref[0][fin]) + 1e31).all()
