@@ -435,7 +435,8 @@ __device__ __forceinline__ void run_signal(State<R, KMAX, NLDS, NV>& s, const fl
 // signal's alpha0 row fetched by LDS-DMA (global_load_lds_dwordx4) into a 4-KB slot of the wave -- was built and measured
 // in round 3: correct, 13 % SLOWER.  While an LDS-DMA is in flight hipcc turns every counted s_waitcnt vmcnt(N) of the
 // Gram-row loads into vmcnt(0), and the loop costs 4 spilled VGPRs; the ~950 cycles a fresh wave waits for its row
-// (5 % of its life) stay.)
+// (5 % of its life) stay.  Touching the row of a workgroup 384 / 768 / 1536 places ahead with one strided load per signal
+// -- an L2 / Infinity-Cache prefetch -- was 8 % slower as well.)
 template <int R, int KMAX, int WPS, int NLDS, int NV, bool FAST, int BW = 4, bool STAMP = false>
 __global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* __restrict__ alpha0,
                                                                   const float* __restrict__ G, int64_t N, int k,
@@ -454,13 +455,6 @@ __global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* _
     S s;
     f32x4 a4[C];
     load_row4<R, true>(alpha0 + sig * L::Kp, lane, a4);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        s.a[4 * c] = a4[c].x;
-        s.a[4 * c + 1] = a4[c].y;
-        s.a[4 * c + 2] = a4[c].z;
-        s.a[4 * c + 3] = a4[c].w;
-    }
     run_signal<R, KMAX, NLDS, NV, FAST, STAMP>(s, G, sig, k, lane, s_p + wid * (NLDS * C * 64), s_sc + wid * S::SC_FLOATS,
                                                idx_out, coef_out, nnz_out, unit_diag);
 }
