@@ -455,6 +455,13 @@ __global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* _
     S s;
     f32x4 a4[C];
     load_row4<R, true>(alpha0 + sig * L::Kp, lane, a4);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        s.a[4 * c] = a4[c].x;
+        s.a[4 * c + 1] = a4[c].y;
+        s.a[4 * c + 2] = a4[c].z;
+        s.a[4 * c + 3] = a4[c].w;
+    }
     run_signal<R, KMAX, NLDS, NV, FAST, STAMP>(s, G, sig, k, lane, s_p + wid * (NLDS * C * 64), s_sc + wid * S::SC_FLOATS,
                                                idx_out, coef_out, nnz_out, unit_diag);
 }

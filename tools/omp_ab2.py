@@ -38,11 +38,13 @@ def run(var, o):
         _lib.check(lib.lys_debug_bomp_variant(P(a0), P(G), N, k, P(o[0]), P(o[1]), P(o[2]), var, 0, st))
 
 
+# reference for the parity check: the FIRST-generation kernel (debug variant 0), an independent implementation -- comparing
+# against the product launch would compare the new kernel with itself
 ref = outs()
-run(-1, ref)
+run(0, ref)
 torch.cuda.synchronize()
-names = {-1: "product"}
-for v in variants:
+names = {-1: "product", 0: "gen-1 kernel"}
+for v in [-1] + variants:
     o = outs()
     try:
         run(v, o)
@@ -55,12 +57,12 @@ for v in variants:
     scale = ref[1].abs().amax(dim=1).clamp_min(1e-30)
     rel = ((o[1] - ref[1]).abs().amax(dim=1) / scale)
     rel_ok = rel[same_idx]
-    print("variant %d vs product: idx rows equal %d / %d, nnz equal %d, max rel coef diff on equal rows %.3e, nan %d"
+    print("variant %d vs gen-1: idx rows equal %d / %d, nnz equal %d, max rel coef diff on equal rows %.3e, nan %d"
           % (v, int(same_idx.sum()), N, int(same_nnz.sum()), float(rel_ok.max()) if rel_ok.numel() else -1.0,
              int(torch.isnan(o[1]).sum())))
-    names[v] = "variant %d" % v
+    names.setdefault(v, "variant %d" % v)
 
-order = [-1] + [v for v in variants if v in names]
+order = [0, -1] + [v for v in variants if v in names]
 times = {v: [] for v in order}
 o = outs()
 for rnd in range(24):
