@@ -269,6 +269,15 @@ int lys_bksvd_index(const int32_t* idx, const float* coef, const int32_t* nnz, i
 int lys_bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int k,
                    const int32_t* row_ptr, const void* entry_records, const int32_t* cg_ptr, const int32_t* cg_entry,
                    const int32_t* idx, float* coef, const float* D_packed, float* D_next, double* stats, void* stream);
+/*
+ * LAZY schedule (k <= 16, K <= 8192; lys_bksvd_is_lazy; LYS_BKSVD_LAZY=0 disables): Y(c) no longer applies block c-1 to all
+ * of its signals -- an update stays pending until the signal's next atom is visited (the index record names the pending
+ * atom) -- so every visit reads and writes the residual row once, and the pending update of every signal's LAST block is
+ * applied by lys_bksvd_finish: call it once after X(nb), before D_packed <- D_next (a no-op for the eager schedule).
+ */
+int lys_bksvd_is_lazy(int k, int K);
+int lys_bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
+                     const float* D_packed, const float* D_next, int B, void* stream);
 /* one whole cycle on one GPU: index (workspace: lys_bksvd_index_workspace_bytes) + all launches + D_packed <- D_next */
 int lys_bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
                     const int32_t* nnz, int B, int32_t* row_ptr, void* entry_records, int32_t* cg_ptr,

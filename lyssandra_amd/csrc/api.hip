@@ -89,6 +89,8 @@ struct BkLayout {
 BkLayout bk_layout(int n, int B);
 int bksvd_step(int, int, int, float*, int64_t, int, int, int, const int32_t*, const void*, const int32_t*, const int32_t*,
                const int32_t*, float*, const float*, float*, double*, hipStream_t);
+int bksvd_finish(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const float*, const float*, int, hipStream_t);
+int bksvd_lazy(int, int);
 int bksvd_sweep(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const int32_t*, int, int32_t*, void*,
                 int32_t*, int32_t*, void*, size_t, double*, float*, float*, hipStream_t);
 int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const float*, const int32_t*, const int32_t*,
@@ -612,6 +614,15 @@ int lys_bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, 
     return bksvd_step(mode, c, B, R, ldr, n, K, k, row_ptr, entry_records, cg_ptr, cg_entry, idx, coef, D_packed, D_next,
                       stats, STREAM(stream));
 }
+
+int lys_bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
+                     const float* D_packed, const float* D_next, int B, void* stream) {
+    LYS_REQUIRE(R && idx && coef && D_packed && D_next && n > 0 && K > 0 && k > 0 && N >= 0 && ldr >= n && (ldr % 4) == 0,
+                "bksvd_finish: bad arguments");
+    return bksvd_finish(R, ldr, n, K, k, N, idx, coef, D_packed, D_next, B, STREAM(stream));
+}
+
+int lys_bksvd_is_lazy(int k, int K) { return bksvd_lazy(k, K); }
 
 int lys_bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
                     const int32_t* nnz, int B, int32_t* row_ptr, void* entry_records, int32_t* cg_ptr, int32_t* cg_entry,

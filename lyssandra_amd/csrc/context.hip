@@ -836,6 +836,7 @@ int lys_ctx_ksvd_sweep(lys_ctx* c, int* n_unused_host) {
     for (int i = 0; i < c->nd; ++i) {
         lys_dev* d = &c->dev[i];
         CTX_HIP(hipSetDevice(d->device));
+        CTX_RC(lys_bksvd_finish(d->R, c->ldd, c->n, c->K, k, d->Ns, d->r_idx, d->r_coef, d->D, d->Dnext, B, d->stream));
         CTX_HIP(hipMemcpyAsync(d->D, d->Dnext, (size_t)c->K * c->ldd * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
         if (i == 0) {
             CTX_HIP(hipEventRecord(d->ev[2], d->stream));

@@ -265,17 +265,35 @@ template <int L>
 __device__ __forceinline__ int csr_row_bcast(int x) {  // lane L of every 16-lane row, in all lanes of that row
     return __builtin_amdgcn_update_dpp(0, x, 0x150 + L, 0xf, 0xf, true);
 }
+// Predecessor of an entry for the LAZY block sweep (ksvd_block.hip): the signal's atoms in the last block BEFORE this
+// entry's block -- the update of those atoms is still pending when the sweep reaches this entry.  pb = that block (-1:
+// none), pa / ps / pc = atom, slot and coefficient of its first atom, pn = how many atoms of the signal it holds.
+struct CsrPred {
+    int pb, pa, ps, pn;
+    float pc;
+};
 template <int J>
-__device__ __forceinline__ void csr_flag_step(int a, int blk, int k, int logb, unsigned& msk, int& meta) {
+__device__ __forceinline__ void csr_flag_step(int a, float cv, int blk, int k, int logb, unsigned& msk, int& meta,
+                                              CsrPred& pr) {
     if constexpr (J < 16) {
         if (J < k) {  // uniform
             const int aj = csr_row_bcast<J>(a);
+            const float cj = __builtin_bit_cast(float, csr_row_bcast<J>(__builtin_bit_cast(int, cv)));
             const int bj = aj >> logb;
             const bool on = aj >= 0;
             msk |= (on && bj == blk) ? (1u << (aj & ((1 << logb) - 1))) : 0u;
             meta |= (on && bj == blk - 1) ? 0x200 : 0;
             meta |= (on && bj == blk + 1) ? 0x400 : 0;
-            csr_flag_step<J + 1>(a, blk, k, logb, msk, meta);
+            const bool before = on && bj < blk;
+            const bool newer = before && bj > pr.pb;
+            const bool same = before && bj == pr.pb;
+            const bool first = newer || (same && aj < pr.pa);   // the block's smallest atom leads (any one would do)
+            pr.pn = newer ? 1 : (same ? pr.pn + 1 : pr.pn);
+            pr.pa = first ? aj : pr.pa;
+            pr.ps = first ? J : pr.ps;
+            pr.pc = first ? cj : pr.pc;
+            pr.pb = newer ? bj : pr.pb;
+            csr_flag_step<J + 1>(a, cv, blk, k, logb, msk, meta, pr);
         }
     }
 }
@@ -314,7 +332,17 @@ __global__ __launch_bounds__(64) void bksvd_index_kernel(const int32_t* __restri
             const int blk = a >> logb;
             unsigned msk = 0;
             int meta = j;
-            csr_flag_step<0>(a, blk, k, logb, msk, meta);
+            CsrPred pr{-1, -1, 63, 0, 0.f};
+            csr_flag_step<0>(a, live ? cv[u] : 0.f, blk, k, logb, msk, meta, pr);
+            // bits 12-17: predecessor slot (63 = none), 18-30: predecessor atom (K <= 8192), 31: the predecessor block holds
+            // several atoms of the signal (slow path); word 3 of the record: the predecessor's coefficient
+            if (pr.pb >= 0 && K <= 8192) {
+                meta |= (pr.ps & 63) << 12;
+                meta |= (pr.pa & 0x1fff) << 18;
+                meta |= (pr.pn > 1) ? (int)0x80000000 : 0;
+            } else {
+                meta |= 63 << 12;
+            }
             const bool coupled = (msk & (msk - 1)) != 0;
             const bool leader = live && ((a & (bsz - 1)) == __ffs(msk) - 1);
             meta |= coupled ? 0x100 : 0;
@@ -328,7 +356,7 @@ __global__ __launch_bounds__(64) void bksvd_index_kernel(const int32_t* __restri
                 const int pos = atomicAdd(&s_cnt[a], 1);
                 // one 16-byte record per entry {signal, slot | flags, coefficient bits, 0}: one scattered store here, one
                 // coalesced load in the sweep (three separate 4-byte stores made this pass twice as long)
-                if (FILL) erec[pos] = make_int4((int)sig, meta, __builtin_bit_cast(int, cv[u]), 0);
+                if (FILL) erec[pos] = make_int4((int)sig, meta, __builtin_bit_cast(int, cv[u]), __builtin_bit_cast(int, pr.pc));
             }
         }
     }

@@ -173,6 +173,8 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     __shared__ short glist[G > 0 ? G : 1];  // non-empty groups in ascending order (grouped by target)
     __shared__ int gfirst[B + 1];           // first entry of glist per target
     __shared__ float s_cnt[B];
+    __shared__ int s_arrive_v;
+    int* s_arrive = &s_arrive_v;
     float* fm = reinterpret_cast<float*>(sm);
     float* dold = fm;
     float* dnew = dold + (size_t)B * NF;
@@ -199,6 +201,7 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
         stot[i] = 0.f;
     }
     if (tid < B) s_cnt[tid] = (float)bb[(int64_t)tid * (n + 2) + n + 1];
+    if (tid == 0) s_arrive_v = 0;
     if (tid < 64) {  // wave 0: ordered compaction of the non-empty groups (all count loads first, then ballots)
         constexpr int NW = (G + 63) / 64;
         bool ne[NW];
@@ -259,17 +262,20 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     BK_NSTAMP(2);
     // the atom loop runs on 4 waves (one per SIMD, 16 teams): with more waves the redundant per-team normalisation
     // below, not the group evaluation, is most of an atom's time.  The other waves were only needed to stage the slab.
-    // Those waves stay alive and idle at the barriers below (a barrier that not every thread of the workgroup reaches is
-    // undefined in the HIP model, whatever gfx9's s_barrier does about terminated waves).
+    // Those waves skip the loop and wait at the workgroup barrier behind it; inside the loop the four active waves
+    // synchronise among themselves through an LDS arrival counter (a __syncthreads() that not every thread of the workgroup
+    // reaches is undefined in the HIP model; letting the 12 idle waves take part in the in-loop barriers instead made the
+    // sweep 4x slower).
     constexpr int NT = 16;  // teams in the atom loop
     const bool active = tid < 16 * NT;
-    for (int t = 0; t < B; ++t) {
+    int arrivals = 0;  // in-loop rendezvous taken so far (uniform over the active waves)
+    for (int t = 0; active && t < B; ++t) {
         const int a = c * B + t;
         if (a >= K) break;
         if (s_cnt[t] == 0.f) continue;  // unused atom keeps its column (ksvd.py:112-115): dnew[t] == dold[t]; uniform
         // groups with target t: team j evaluates list entries gfirst[t] + j, + NT, ..
         const int lbeg = gfirst[t], lend = gfirst[t + 1];
-        for (int li = lbeg + team; active && li < lend; li += NT) {
+        for (int li = lbeg + team; li < lend; li += NT) {
             const int g = glist[li];
             const int sl = gslot[g];
             const unsigned pi = (unsigned)(g - ((1 << t) - 1 - t)) + 1u;
@@ -333,8 +339,16 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
                 }
             }
         }
-        if (lend > lbeg) __syncthreads();  // uniform over the workgroup
-        if (!active) continue;
+        if (lend > lbeg) {  // uniform over the active waves: every team's slots are written before any team sums them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            arrivals += NT / 4;
+            if ((tid & 63) == 0) {
+                atomicAdd(s_arrive, 1);
+                while (__hip_atomic_load(s_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < arrivals)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         // every team: s = S_t + d_old sum x^2 + groups, d_new = s / (||s|| + eps)  (utils/math.py:61-62; eps only matters
         // for s = 0, where the result is the zero vector either way)
         float4 sv[FB];
@@ -405,11 +419,17 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                                                                 const int32_t* __restrict__ idx,
                                                                 float* __restrict__ coef, const float* __restrict__ D,
                                                                 float* __restrict__ Dnext, int ldd,
-                                                                double* __restrict__ bbuf, BkLayout lay) {
+                                                                double* __restrict__ bbuf, BkLayout lay, int lazy_rt) {
+    // lazy != 0 (k <= 16, see bksvd_lazy): the update of a finished block is NOT applied by a pass of its own (the
+    // ROLE_APPLY walk of Y) but by whoever touches the signal next -- the entry of the signal's next atom, whose index
+    // record names the pending atom (predecessor), or bksvd_final_kernel for the signal's last block.  Every visit then
+    // reads and writes the residual row ONCE (SURVEY 8(d)'s 8n bytes per non-zero instead of 12n), and Y(c) shrinks to the
+    // ~8 % of block c's entries whose pending block is c-1.
     constexpr int B = 1 << LOGB;
     constexpr int G = (1 << B) - 1 - B;
     constexpr int U = (FB == 1) ? 8 : 4;  // signals in flight per team
     constexpr int NTH = 16 * TEAMS;
+    const bool lazy = (SL == 1) && (lazy_rt != 0);  // k <= 16 only: the other instantiations carry none of the lazy code
     extern __shared__ double sm[];  // narrow step only
     // The narrow step is workgroup 0: with ~100 KB of dynamic LDS only one workgroup fits a CU, a launch of 257 on 256 CUs
     // leaves one waiting, and the serial narrow step -- the launch's critical path -- must not be the one that waits.
@@ -506,6 +526,8 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
             const int f = 64 * b + 4 * q;
             if (FULL || f < n)
                 *reinterpret_cast<float4*>(reinterpret_cast<char*>(R) + (sig * rsz + 4u * f)) = r[b];
+            // (write-through sc1 stores for X(c)'s rows in lazy mode -- so that they drain behind the narrow step instead of at
+            // the kernel boundary -- were measured: X 24 -> 36 us)
         }
     };
     // the finished block p on a signal whose support is loaded, in-block atoms in ascending order
@@ -522,7 +544,72 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
         }
         store_row(r, sig);
     };
-    auto flush = [&]() {  // team accumulator -> workgroup accumulators (fp64 LDS atomics), uniform per team
+    // the same update with the atom's old / new column gathered from D / Dnext (L2-resident): lazy mode, any earlier atom
+    auto apply_atom_rows = [&](float4 (&r)[FB], const float4 (&d0)[FB], const float4 (&dn)[FB], float xo) -> float {
+        float dot = 0.f;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            r[b].x = fmaf(d0[b].x, xo, r[b].x);
+            r[b].y = fmaf(d0[b].y, xo, r[b].y);
+            r[b].z = fmaf(d0[b].z, xo, r[b].z);
+            r[b].w = fmaf(d0[b].w, xo, r[b].w);
+            dot = fmaf(r[b].x, dn[b].x, dot);
+            dot = fmaf(r[b].y, dn[b].y, dot);
+            dot = fmaf(r[b].z, dn[b].z, dot);
+            dot = fmaf(r[b].w, dn[b].w, dot);
+        }
+        const float xn = bk_row16_sum(dot);
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            r[b].x = fmaf(-dn[b].x, xn, r[b].x);
+            r[b].y = fmaf(-dn[b].y, xn, r[b].y);
+            r[b].z = fmaf(-dn[b].z, xn, r[b].z);
+            r[b].w = fmaf(-dn[b].w, xn, r[b].w);
+        }
+        return xn;
+    };
+    auto load_atom = [&](const float* __restrict__ Dm, int atom, float4 (&d)[FB]) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            d[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL || f < ldd) d[b] = *reinterpret_cast<const float4*>(Dm + (int64_t)atom * ldd + f);
+        }
+    };
+    // lazy mode, support loaded: the signal's pending block = the last block before c that holds one of its atoms; its
+    // atoms are applied in ascending order (ksvd.py:116-123) and the row / the new coefficients are stored
+    auto apply_pending = [&](float4 (&r)[FB], const int (&a)[SL], const float (&x)[SL], unsigned sig) {
+        int pb = -1;
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            const int blk = a[s] >> LOGB;  // -1 for a dropped slot
+            pb = (a[s] >= 0 && blk < c && blk > pb) ? blk : pb;
+        }
+        pb = max(pb, bk_dpp_i<0xB1>(pb));   // row maximum (rotations inside the 16-lane row: every source lane is valid)
+        pb = max(pb, bk_dpp_i<0x4E>(pb));
+        pb = max(pb, bk_dpp_i<0x124>(pb));
+        pb = max(pb, bk_dpp_i<0x128>(pb));
+        if (pb < 0) return;  // uniform per team: first visit of this signal, nothing pending
+        unsigned m = 0;
+#pragma unroll
+        for (int s = 0; s < SL; ++s) m |= (a[s] >= 0 && (a[s] >> LOGB) == pb) ? (1u << (a[s] & (B - 1))) : 0u;
+        m = bk_row16_or(m);
+        while (m) {
+            const int t = __ffs(m) - 1;
+            m &= m - 1;
+            const int atom = pb * B + t;
+            float4 d0[FB], dn[FB];
+            load_atom(D, atom, d0);
+            load_atom(Dnext, atom, dn);
+            const float xn = apply_atom_rows(r, d0, dn, value_of(a, x, atom));
+#pragma unroll
+            for (int s = 0; s < SL; ++s)
+                if (a[s] == atom)
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(coef) + (sig * ksz + 4u * (q + 16 * s))) = xn;
+        }
+        store_row(r, sig);
+    };
+    auto flush = [&]() __attribute__((always_inline)) {  // team accumulator -> workgroup accumulators (fp64 LDS atomics), uniform per team
         if (cur >= 0) {
 #pragma unroll
             for (int b = 0; b < FB; ++b) {
@@ -640,20 +727,33 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     //   ROLE_APPLY    Y(c), list p : NEXT -> nothing (its list-c entry is PREV, queued above); COUPLED -> queue; else
     //                                apply the entry's atom (fast: coefficient and slot came with the index)
     constexpr int ROLE_ACC = 0, ROLE_COLLECT = 1, ROLE_APPLY = 2;
-    auto run_fast = [&](int role, int ent, int emt, float ecf, int j0, int e_base) {
+    auto run_fast = [&](int role, int ent, int emt, float ecf, float epc, int j0, int e_base) __attribute__((always_inline)) {
         float4 rr[U][FB];
         unsigned sg[U];
         int mt[U];  // slot, bit 31 = nothing to do, bit 30 = queue
         float xe[U];
+        int pa[U];  // lazy: pending atom of the signal (-1: none), its slot in bits 24-29
+        float xp[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned sig = (unsigned)bk_row_bcast_dyn(ent, j0 + u);
             int m = bk_row_bcast_dyn(emt, j0 + u);
             xe[u] = __builtin_bit_cast(float, bk_row_bcast_dyn(__builtin_bit_cast(int, ecf), j0 + u));
+            xp[u] = __builtin_bit_cast(float, bk_row_bcast_dyn(__builtin_bit_cast(int, epc), j0 + u));
+            pa[u] = -1;
             bool skip, slow;
             if (role == ROLE_ACC) {
-                skip = ((m & F_PREV) && p >= 0) || ((m & F_COUPLED) && !(m & F_LEADER));
-                slow = false;
+                if (lazy) {
+                    // coupled signals (any entry) belong to the group phase, which has the support and applies the pending
+                    // block itself; a single pending atom is applied right here, several go to the slow path
+                    skip = ((m & F_PREV) && p >= 0) || (m & F_COUPLED);
+                    const int ps = (m >> 12) & 63;
+                    slow = (ps != 63) && (m < 0);
+                    pa[u] = (ps != 63 && !slow) ? (((m >> 18) & 0x1fff) | (ps << 24)) : -1;
+                } else {
+                    skip = ((m & F_PREV) && p >= 0) || ((m & F_COUPLED) && !(m & F_LEADER));
+                    slow = false;
+                }
             } else if (role == ROLE_COLLECT) {
                 slow = (m & F_PREV) != 0;
                 skip = !slow;
@@ -688,7 +788,7 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                     s_q[slot][0] = (int)sg[u];
                     s_q[slot][1] = tpos;
                     s_q[slot][2] = __builtin_bit_cast(int, xe[u]);
-                    s_q[slot][3] = (role == ROLE_APPLY) ? 1 : 0;
+                    s_q[slot][3] = (role == ROLE_APPLY) ? 1 : (role == ROLE_ACC) ? 2 : 0;
                 }
                 continue;
             }
@@ -698,12 +798,22 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                 if (q == 0)
                     *reinterpret_cast<float*>(reinterpret_cast<char*>(coef) + (sg[u] * ksz + 4u * (unsigned)(mt[u] & 63))) = xn;
             } else {
+                if (pa[u] >= 0) {  // lazy: the pending atom first (uniform per team)
+                    float4 d0[FB], dn[FB];
+                    load_atom(D, pa[u] & 0x1fff, d0);
+                    load_atom(Dnext, pa[u] & 0x1fff, dn);
+                    const float xn = apply_atom_rows(rr[u], d0, dn, xp[u]);
+                    store_row(rr[u], sg[u]);
+                    if (q == 0)
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(coef) + (sg[u] * ksz + 4u * (unsigned)((pa[u] >> 24) & 63))) = xn;
+                }
                 accumulate_one(rr[u], xe[u], tpos);
             }
         }
     };
     // slow path: support loaded, leader test, in-block atoms sequentially, tuple moments
-    auto run_slow = [&](unsigned sig, int tp, float x1, bool is_apply) {
+    auto run_slow = [&](unsigned sig, int tp, float x1, int kind) __attribute__((always_inline)) {
+        const bool is_apply = kind == 1;
         float4 r[FB];
         int a[SL];
         float x[SL];
@@ -730,7 +840,11 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
         }
         m = bk_row16_or(m);  // masks of block p (bits 0-7) and block c (8-15)
         const unsigned mp = m & 0xffu, mc = m >> 8;
-        if (is_apply) {
+        if (kind == 2) {
+            // X(c), lazy: an uncoupled entry whose pending block holds several atoms of the signal
+            apply_pending(r, a, x, sig);
+            accumulate_one(r, x1, tp);
+        } else if (is_apply) {
             if (__ffs(mp) - 1 != tp) return;  // not the signal's leader entry in block p
             if (mc) return;                   // also in block c: its list-c entry was collected as PREV
             apply_block(r, a, x, sig, mp);
@@ -745,17 +859,17 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     // walk of one block's entry range with a role; the batch count is uniform per workgroup (every team has the same
     // chunk size, teams past the end of the list idle) because the queued entries of a batch are drained by ALL teams
     // between two workgroup barriers
-    auto drain = [&]() {  // all teams take queued slow-path entries between two workgroup barriers
+    auto drain = [&]() __attribute__((always_inline)) {  // all teams take queued slow-path entries between two workgroup barriers
         __syncthreads();
         const int nq = s_qn;
         for (int i = team; i < nq; i += TEAMS)  // uniform per team
-            run_slow((unsigned)s_q[i][0], s_q[i][1], __builtin_bit_cast(float, s_q[i][2]), s_q[i][3] != 0);
+            run_slow((unsigned)s_q[i][0], s_q[i][1], __builtin_bit_cast(float, s_q[i][2]), s_q[i][3]);
         __syncthreads();
         if (tid == 0) s_qn = 0;
     };
     // `defer`: leave the queued entries for a later drain (Y(c) drains the entries of both its walks in ONE round: a
     // drain is a dependent load round trip) unless the queue could overflow in the next batch
-    auto walk = [&](int role, int blk_id, int w, bool defer) {
+    auto walk = [&](int role, int blk_id, int w, bool defer) __attribute__((always_inline)) {
         which = w;
         const int lbeg = s_rp[w][0];
         const int a_hi = (blk_id * B + B < K) ? B : K - blk_id * B;
@@ -774,13 +888,14 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                 const int ent = rec.x;
                 const int emt = rec.y;
                 const float ecf = __builtin_bit_cast(float, rec.z);
+                const float epc = __builtin_bit_cast(float, rec.w);  // coefficient of the pending atom (lazy mode)
                 const int left = __builtin_amdgcn_readfirstlane(tend - e0);  // team 0 of a wave: longest remainder
 #pragma unroll
                 for (int j0 = 0; j0 < 16; j0 += U)
-                    if (left > j0) run_fast(role, ent, emt, ecf, j0, e0 + j0);
+                    if (left > j0) run_fast(role, ent, emt, ecf, epc, j0, e0 + j0);
             }
             if (bo == 0 && role != ROLE_COLLECT) BK_WSTAMP(6);
-            if (role == ROLE_ACC) continue;  // X(c) queues nothing
+            if (role == ROLE_ACC && !lazy) continue;  // X(c) queues nothing (lazy: entries with several pending atoms)
             const bool last = bo + 16 >= chunk;
             if (!(defer && last)) {
                 drain();
@@ -794,7 +909,8 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     };
 
     if (mode == 0) {
-        walk(ROLE_ACC, c, 1, false);
+        walk(ROLE_ACC, c, 1, true);
+        if (lazy) drain();
         BK_WSTAMP(3);
         // ---- group phase: tuple moments of the coupled signals of block c (their leaders, sorted by in-block mask).
         // Workgroup w takes the entries [w * GCH, (w + 1) * GCH) of the block's range, 2 per team (loaded together).
@@ -879,7 +995,14 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                     const unsigned m2 = mk[u] & (mk[u] - 1);
                     if (m2) {
                         const int t1 = __ffs(mk[u]) - 1;
-                        coupled_grouped(r[u], a[u], x[u], t1, value_of(a[u], x[u], c * B + t1), m2, gq, s_gslot);
+                        const float x1 = value_of(a[u], x[u], c * B + t1);
+                        if (lazy) {
+                            // the fast walk left the coupled signals alone: pending block first, then the leader's own sum
+                            const int e = lo + team * GPT + u;
+                            apply_pending(r[u], a[u], x[u], (unsigned)cg_entry[e]);
+                            accumulate_one(r[u], x1, t1);
+                        }
+                        coupled_grouped(r[u], a[u], x[u], t1, x1, m2, gq, s_gslot);
                     }
                 }
             }
@@ -903,7 +1026,7 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     } else {
         // the apply walk first: its residual-row stores (half of the launch's traffic) start draining while the collect
         // walk and the slow-path drain still run -- the other order left them all to the end of the kernel
-        if (have_p) walk(ROLE_APPLY, p, 0, true);
+        if (have_p && !lazy) walk(ROLE_APPLY, p, 0, true);
         BK_WSTAMP(2);
         if (have_c) walk(ROLE_COLLECT, c, 1, true);
         drain();
@@ -923,6 +1046,97 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     if (stamp0 >= 0 && tid == 0)
         for (int i = 0; i < 8; ++i) g_bk_stamp[stamp0 + i] = ts[i];
 #undef BK_WSTAMP
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lazy mode, after X(nb): every signal still carries the pending update of its LAST block.  Signal-major: one team per
+// signal loads the support and the residual row, applies the block's atoms in ascending order (ksvd.py:116-123) with the
+// atoms' old / new columns from D / Dnext, stores the row and the new coefficients.
+// ---------------------------------------------------------------------------------------------
+template <int FB, int LOGB, int SL, bool FULL>
+__global__ __launch_bounds__(256) void bksvd_final_kernel(int64_t N, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                          const int32_t* __restrict__ idx, float* __restrict__ coef,
+                                                          const float* __restrict__ D, const float* __restrict__ Dnext,
+                                                          int ldd) {
+    constexpr int B = 1 << LOGB;
+    const int tid = threadIdx.x, team = tid >> 4, q = tid & 15;
+    const int64_t nteams = (int64_t)gridDim.x * 16;
+    for (int64_t sig = (int64_t)blockIdx.x * 16 + team; sig < N; sig += nteams) {
+        float4 r[FB];
+        int a[SL];
+        float x[SL];
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            r[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL || f < n) r[b] = *reinterpret_cast<const float4*>(R + sig * ldr + f);
+        }
+        int lb = -1;
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            const int j = q + 16 * s;
+            const int64_t off = sig * k + ((j < k) ? j : k - 1);
+            const int av = idx[off];
+            x[s] = coef[off];
+            const bool live = (j < k) && (x[s] != 0.f) && av >= 0;
+            a[s] = live ? av : -1;
+            lb = (a[s] >= 0 && (a[s] >> LOGB) > lb) ? (a[s] >> LOGB) : lb;
+        }
+        lb = max(lb, bk_dpp_i<0xB1>(lb));
+        lb = max(lb, bk_dpp_i<0x4E>(lb));
+        lb = max(lb, bk_dpp_i<0x124>(lb));
+        lb = max(lb, bk_dpp_i<0x128>(lb));
+        if (lb < 0) continue;  // uniform per team: the signal uses no atom
+        unsigned m = 0;
+#pragma unroll
+        for (int s = 0; s < SL; ++s) m |= (a[s] >= 0 && (a[s] >> LOGB) == lb) ? (1u << (a[s] & (B - 1))) : 0u;
+        m = bk_row16_or(m);
+        while (m) {
+            const int t = __ffs(m) - 1;
+            m &= m - 1;
+            const int atom = lb * B + t;
+            float xo = 0.f;
+#pragma unroll
+            for (int s = 0; s < SL; ++s) xo += (a[s] == atom) ? x[s] : 0.f;
+            xo = bk_row16_sum(xo);
+            float4 dn[FB];
+            float dot = 0.f;
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                const int f = 64 * b + 4 * q;
+                float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                dn[b] = d0;
+                if (FULL || f < ldd) {
+                    d0 = *reinterpret_cast<const float4*>(D + (int64_t)atom * ldd + f);
+                    dn[b] = *reinterpret_cast<const float4*>(Dnext + (int64_t)atom * ldd + f);
+                }
+                r[b].x = fmaf(d0.x, xo, r[b].x);
+                r[b].y = fmaf(d0.y, xo, r[b].y);
+                r[b].z = fmaf(d0.z, xo, r[b].z);
+                r[b].w = fmaf(d0.w, xo, r[b].w);
+                dot = fmaf(r[b].x, dn[b].x, dot);
+                dot = fmaf(r[b].y, dn[b].y, dot);
+                dot = fmaf(r[b].z, dn[b].z, dot);
+                dot = fmaf(r[b].w, dn[b].w, dot);
+            }
+            const float xn = bk_row16_sum(dot);
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                r[b].x = fmaf(-dn[b].x, xn, r[b].x);
+                r[b].y = fmaf(-dn[b].y, xn, r[b].y);
+                r[b].z = fmaf(-dn[b].z, xn, r[b].z);
+                r[b].w = fmaf(-dn[b].w, xn, r[b].w);
+            }
+#pragma unroll
+            for (int s = 0; s < SL; ++s)
+                if (a[s] == atom) coef[sig * k + q + 16 * s] = xn;
+        }
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (FULL || f < n) *reinterpret_cast<float4*>(R + sig * ldr + f) = r[b];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -946,6 +1160,17 @@ static size_t narrow_lds_bytes(int n, int B) {
     return ((size_t)4 * B * nf + (size_t)bk_maxg(B) * (nf + B)) * sizeof(float);
 }
 
+// The lazy schedule needs the predecessor fields of the index records, which only the k <= 16 index builder writes
+// (13-bit atom field: K <= 8192).  LYS_BKSVD_LAZY=0 restores the eager apply pass of round 2.
+int bksvd_lazy(int k, int K) {
+    static int env = -1;
+    if (env < 0) {
+        const char* e = getenv("LYS_BKSVD_LAZY");
+        env = (e && e[0] == '0') ? 0 : 1;
+    }
+    return (env && k <= 16 && K <= 8192) ? 1 : 0;
+}
+
 template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
 static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ldr, int n, int k, const BkIndex& ix,
                             const int32_t* idx, float* coef, const float* D, float* Dnext, double* bbuf,
@@ -967,7 +1192,7 @@ static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ld
     const int grid = (mode == 0 && c >= nb) ? 1 : BK_WBLOCKS;
     hipLaunchKernelGGL((bksvd_step_kernel<FB, LOGB, SL, TEAMS, FULL>), dim3(grid), dim3(16 * TEAMS), lds, stream, mode,
                        c, nb, K, R, ldr, n, k, ix.row_ptr, ix.erec, ix.cg_ptr, ix.cg_entry, idx, coef, D, Dnext,
-                       padded_features(n), bbuf, lay);
+                       padded_features(n), bbuf, lay, bksvd_lazy(k, K));
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -1011,6 +1236,41 @@ int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int 
 #undef BK_ARGS
 }
 
+// Lazy schedule: the pending update of every signal's last block (no-op for the eager schedule).  Call once after X(nb).
+int bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef, const float* D,
+                 const float* Dnext, int B, hipStream_t stream) {
+    if (!bksvd_lazy(k, K) || N <= 0) return LYS_OK;
+    if (n > 256 || (B != 4 && B != 8) || (B == 8 && n > 128)) {
+        set_error("bksvd_finish: unsupported shape n=%d k=%d B=%d", n, k, B);
+        return LYS_ENOSUP;
+    }
+    const int fb = (n <= 64) ? 1 : (n <= 128) ? 2 : 4;
+    const bool full = (n == 64 * fb);
+    const int ldd = padded_features(n);
+    int64_t blocks = (N + 15) / 16;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+#define BK_FIN(FBv, LOGBv)                                                                                             \
+    do {                                                                                                               \
+        if (full)                                                                                                      \
+            hipLaunchKernelGGL((bksvd_final_kernel<FBv, LOGBv, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, N, R, \
+                               ldr, n, k, idx, coef, D, Dnext, ldd);                                                   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((bksvd_final_kernel<FBv, LOGBv, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, N, R, \
+                               ldr, n, k, idx, coef, D, Dnext, ldd);                                                   \
+    } while (0)
+    if (fb == 1) {
+        if (B == 8) BK_FIN(1, 3); else BK_FIN(1, 2);
+    } else if (fb == 2) {
+        if (B == 8) BK_FIN(2, 3); else BK_FIN(2, 2);
+    } else {
+        BK_FIN(4, 2);
+    }
+#undef BK_FIN
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 int bk_debug_timestamps(unsigned long long* out64) {
     LYS_CHECK_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_bk_stamp), 64 * sizeof(unsigned long long)));
     return LYS_OK;
@@ -1043,7 +1303,7 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
     if (rc) return rc;
     LYS_CHECK_HIP(hipMemsetAsync(bbuf, 0, bksvd_stats_doubles(n, K, B) * sizeof(double), stream));
     const int nb = (K + B - 1) / B;
-    auto steps = [&](hipStream_t st) -> int {
+    auto steps = [&](hipStream_t st) __attribute__((always_inline)) -> int {
         for (int c = 0; c <= nb; ++c) {
             int r = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, st);
             if (r) return r;
@@ -1052,7 +1312,7 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
                 if (r) return r;
             }
         }
-        return LYS_OK;
+        return bksvd_finish(R, ldr, n, K, k, N, idx, coef, D, Dnext, B, st);
     };
     // LYS_BKSVD_GRAPH=1: the 2 K/B + 1 dependent launches replayed as one hipGraph while the buffers stay the same (the
     // learners allocate them once per fit).  The first sweep on a device always runs eagerly (function attributes).

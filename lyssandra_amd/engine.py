@@ -530,6 +530,11 @@ class HipBlockKsvdOps(object):
         return self.stats[c]
 
     def finish(self):
+        dd = self.dd
+        # lazy schedule: the pending update of every signal's last block (a no-op for the eager schedule)
+        _lib.check(self.lib.lys_bksvd_finish(_ptr(self.R), _ld(self.R), dd.n, dd.K, self.k, self.N, _ptr(self.idx),
+                                             _ptr(self.coef), _ptr(dd.D), _ptr(self.Dnext), self.B, _stream()),
+                   "lys_bksvd_finish")
         self.dd.D[:self.dd.K].copy_(self.Dnext[:self.dd.K])
         self.dd.invalidate()
         return self.unused()
