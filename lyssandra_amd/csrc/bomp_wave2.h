@@ -436,7 +436,8 @@ __device__ __forceinline__ void run_signal(State<R, KMAX, NLDS, NV>& s, const fl
 // in round 3: correct, 13 % SLOWER.  While an LDS-DMA is in flight hipcc turns every counted s_waitcnt vmcnt(N) of the
 // Gram-row loads into vmcnt(0), and the loop costs 4 spilled VGPRs; the ~950 cycles a fresh wave waits for its row
 // (5 % of its life) stay.  Touching the row of a workgroup 384 / 768 / 1536 places ahead with one strided load per signal
-// -- an L2 / Infinity-Cache prefetch -- was 8 % slower as well.)
+// -- an L2 / Infinity-Cache prefetch -- was 8 % slower as well; the persistent loop with the next row loaded into the
+// dead correlation registers behind the back-substitution (ordinary loads, no LDS-DMA): 8 spilled VGPRs, 20 % slower.)
 template <int R, int KMAX, int WPS, int NLDS, int NV, bool FAST, int BW = 4, bool STAMP = false>
 __global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* __restrict__ alpha0,
                                                                   const float* __restrict__ G, int64_t N, int k,
