@@ -923,8 +923,9 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
         __shared__ int s_nslot;
         const int kb = c << B;  // first key of the block
         const int cgb = cg_ptr[kb], cge = cg_ptr[kb + (1 << B)];
-        const int lo = cgb + bx * GCH;
-        if (lo < cge) {  // uniform per workgroup
+        // chunks of GCH entries round-robin over the workgroups: a block whose coupled signals outnumber nwg * GCH (small
+        // dictionaries with many signals: K = 64, k = 8, 4e5 signals have 1.2e5 per block) takes several rounds
+        for (int lo = cgb + bx * GCH; lo < cge; lo += nwg * GCH) {  // uniform per workgroup
             const int hi = (lo + GCH < cge) ? lo + GCH : cge;
             double* gq = sm;
             for (int i = tid; i < G; i += NTH) s_gslot[i] = -1;
@@ -1021,6 +1022,7 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                     }
                 }
             }
+            __syncthreads();  // the slots are re-initialised by the next round
         }
         BK_WSTAMP(2);
     } else {

@@ -66,6 +66,42 @@ def test_approx_ksvd_sweep_config2_size(eng, N, cycles):
     assert err_dev < err0                                             # the sweep lowers the objective
 
 
+@pytest.mark.parametrize("n,K,k,N", [(32, 64, 8, 400000), (64, 256, 10, 1 << 20)])
+def test_approx_ksvd_sweep_dense_coupling_many_signals(eng, n, K, k, N, monkeypatch):
+    """Small dictionaries with many signals: most signals use SEVERAL atoms of a block of 8 (1.2e5 coupled signals per block
+    at K = 64), more than one round of the group phase holds (a round is 255 workgroups x 128 entries; the entries past it
+    were dropped before round 3: atoms off by 1e-2, residual no longer X - DZ).  Both schedules, against the float64 C
+    restatement (lyssa/dict_learning/ksvd.py:98-126)."""
+    import torch
+    from oracle import c_oracle
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    Dt = torch.randn((n, K), device="cuda", generator=gen)
+    Dt = Dt / Dt.norm(dim=0, keepdim=True)
+    Xs = torch.randn((N, n), device="cuda", generator=gen)
+    X = Xs.t().contiguous().double().cpu().numpy()
+    ref = None
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("LYS_BKSVD_LAZY", lazy)
+        dd = eng.DeviceDictionary(n, K)
+        dd.set(Dt)
+        idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+        if ref is None:
+            D0 = dd.D[:K, :n].t().contiguous().double().cpu().numpy()
+            ref = c_oracle.approx_ksvd_sparse(X, D0, idx.cpu().numpy(), coef.double().cpu().numpy(), nnz.cpu().numpy(), n_cycles=1)
+        Do, co, uo, err_o = ref
+        R, err0 = eng.residual(Xs, dd, idx, coef, nnz)
+        unused = eng.ksvd_cycle(R, dd, idx, coef, nnz, buffers={})
+        err_dev = eng.approx_error(Xs, dd, idx, coef, nnz)
+        R2, _ = eng.residual(Xs, dd, idx, coef, nnz)
+        drift = (R[:, :n] - R2[:, :n]).abs().max().item()
+        ae = _atom_err(dd.to_host(), Do)
+        ce = np.max(np.abs(coef.double().cpu().numpy() - co)) / np.abs(co).max()
+        print("lazy=%s n=%d K=%d N=%d: atom err %.3g, code err %.3g, drift %.3g" % (lazy, n, K, N, ae, ce, drift))
+        assert unused == uo
+        assert drift < 2e-5 * Xs.abs().max().item(), drift
+        assert ae < 1e-5 and ce < 1e-5 and abs(err_dev - err_o) / err_o < 1e-5
+
+
 def test_ksvd_alternation_config2_shape_five_iterations(eng):
     """configs[1] as a CHAIN (lyssa/dict_learning/ksvd.py:169-229: encode -> approx_ksvd -> unused-atom replacement -> encode
     ...), 5 iterations at 2^18 patches, K = 1024, k = 10, every link graded against the float64 C restatement:
