@@ -89,6 +89,22 @@ __device__ __forceinline__ unsigned long long stamp_v(float& dep) {
         s.tlast = t_;                                                  \
     }
 
+// Element r (wave-uniform, run-time) of a register vector.  R >= 8: the VGPR index mode (one indexed v_mov).  R = 4: LLVM
+// serves a dynamic index into a 4-element vector from SCRATCH (160-256 B per lane; K = 256 ran 2-3x slower than the first
+// kernel), so a three-select chain instead.
+template <int R, class V>
+__device__ __forceinline__ float elem_dyn(const V& v, int r) {
+    if constexpr (R == 4) {
+        float x = v[3];
+        x = (r == 2) ? v[2] : x;
+        x = (r == 1) ? v[1] : x;
+        x = (r == 0) ? v[0] : x;
+        return x;
+    } else {
+        return v[r];
+    }
+}
+
 // argmax |a| over the wave, first (lowest atom index) maximum wins like np.argmax (sparse_coding.py:322).
 //
 // Every VALU instruction of a wave64 costs the SIMD ~4 cycles whatever it does (PMC: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
@@ -153,7 +169,7 @@ __device__ __forceinline__ bool wave_argmax(const AV& a, int& kk, float& akk, in
         q = hit ? e : q;
     }
     // one more indexed read for the signed value (a select chain over x[] costs three VALU instructions: -1.5 %)
-    akk = readlane_f(a[csel * 4 + q], Lo);
+    akk = readlane_f(elem_dyn<R>(a, csel * 4 + q), Lo);
     Lown = Lo;
     rown = csel * 4 + q;
     kk = csel * 256 + Lo * 4 + q;
@@ -266,7 +282,7 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
             float tmp[KMAX];
 #pragma unroll
             for (int i = NLDS; i < NRJ; ++i) {
-                tmp[i] = s.p[i - NLDS][rown];  // VGPR index mode; lane Lown holds the element we want
+                tmp[i] = elem_dyn<R>(s.p[i - NLDS], rown);  // VGPR index mode; lane Lown holds the element we want
                 w[i] = readlane_f(tmp[i], Lown);
             }
             if constexpr (NRJ > NLDS) {
