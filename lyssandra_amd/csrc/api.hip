@@ -6,6 +6,7 @@
 #include "common.h"
 
 namespace lys {
+int bomp_debug_timeline(unsigned long long* out);
 
 static thread_local char g_err[512] = "";
 
@@ -723,6 +724,8 @@ int lys_densify_f64(const int32_t* idx, const float* coef, const int32_t* nnz, i
     LYS_REQUIRE(idx && coef && nnz && Z, "densify: null pointer");
     return densify_f64(idx, coef, nnz, K, k, N, Z, STREAM(stream));
 }
+
+int lys_debug_blk_timeline(unsigned long long* out) { return bomp_debug_timeline(out); }
 
 int lys_debug_bomp_variant(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef,
                            int32_t* nnz, int variant, int lds_bytes, void* stream) {

@@ -537,32 +537,43 @@ int thresh_from_alpha0(const float* alpha0, int K, int Kp, int k, int64_t N, int
 // ------------------------------------------------------------------------------------------------
 template <int R, int KMAX>
 struct BlkState {
-    float a[R];
-    float p[KMAX - 1][R];
+    typedef float vec_t __attribute__((ext_vector_type(R)));  // true vectors: element r (run-time) through the VGPR index mode
+    vec_t a;
+    vec_t p[KMAX - 1];
+    int dxv;  // lane i (of every wave): Dx[i], -1 while unset
+#ifdef LYS_BLK_STAMPS
+    unsigned ph[8];
+#endif
 };
 
-template <int R, int KMAX, int J, int RR>
-__device__ __forceinline__ void blk_publish(const BlkState<R, KMAX>& s, int r, float* s_w, float* s_akk) {
-    // owner thread only: element r (run-time) of every vector -> LDS.  A recursive if/else with an opaque asm on
-    // every value keeps the register indices static (the optimiser otherwise folds the chain into a dynamic
-    // index and the whole state lands in scratch).
-    if constexpr (RR < R) {
-        if (r == RR) {
-            float v = s.a[RR];
-            asm volatile("" : "+v"(v));
-            *s_akk = v;
-#pragma unroll
-            for (int i = 0; i < J; ++i) {
-                float u = s.p[i][RR];
-                asm volatile("" : "+v"(u));
-                s_w[i] = u;
-            }
-        } else {
-            blk_publish<R, KMAX, J, RR + 1>(s, r, s_w, s_akk);
-        }
+// Element r (wave-uniform, run-time) of a register vector: the VGPR index mode for R >= 8; LLVM serves a dynamic index into
+// a 4-element vector from scratch, so a select chain there.
+template <int R, class V>
+__device__ __forceinline__ float blk_elem(const V& v, int r) {
+    if constexpr (R == 4) {
+        float x = v[3];
+        x = (r == 2) ? v[2] : x;
+        x = (r == 1) ? v[1] : x;
+        x = (r == 0) ? v[0] : x;
+        return x;
+    } else {
+        return v[r];
     }
 }
 
+// Development instrumentation of bomp_block_kernel (build with -DLYS_BLK_STAMPS, e.g. lyssandra_amd.build.build(True,
+// extra_flags=["-DLYS_BLK_STAMPS"]); tools/blk_timeline.py reads it): with LYS_ABL=<Kp> in the environment every workgroup
+// runs all k steps (exits disabled, pivots forced to 1) and accumulates 100 MHz wall-clock ticks per phase of a step in
+// registers; start / end / hardware id of every workgroup go to g_blk_tl.  The product build carries none of it.
+#ifdef LYS_BLK_STAMPS
+__device__ unsigned long long g_blk_ph[8];
+__device__ unsigned long long g_blk_tl[4 * 16384];
+#define BLK_ABL ((unit_diag >> 8) != 0)
+#define BLK_ST(i) do { if (unit_diag >> 8) { const unsigned long long t_ = wall_clock64(); s.ph[i] += (unsigned)(t_ - tl); tl = t_; } } while (0)
+#else
+#define BLK_ABL false
+#define BLK_ST(i) do { } while (0)
+#endif
 template <int R, int KMAX, int J, int T>
 __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __restrict__ G, int Kp, int k, int tid,
                                           float* s_max, int* s_idx, float* s_w, float* s_akk, float* s_L, float* s_t,
@@ -570,6 +581,9 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
     if constexpr (J < KMAX) {
         if (J >= k) return;
         const int lane = tid & 63, wid = tid >> 6;
+#ifdef LYS_BLK_STAMPS
+        unsigned long long tl = wall_clock64();
+#endif
         // ---- block-wide argmax |a|, lowest index wins
         float best = fabsf(s.a[0]);
 #pragma unroll
@@ -585,26 +599,44 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
             smx[wid] = mw;
             six[wid] = cw;
         }
+        BLK_ST(0);
         __syncthreads();
-        float m = smx[0];
-        int kk = six[0];
+        BLK_ST(1);
+        // the T/64 per-wave candidates, one per lane (replicated over the wave), reduced like the per-wave search: maximum,
+        // then the lowest atom among its holders.  (A scalar loop over the candidates compiles into T/64 serialised
+        // [ds_read -> s_waitcnt -> v_cmp -> v_readfirstlane -> branch] round trips: 0.47 of the 1.6 us of a step at k = 20.)
+        float m;
+        int kk;
+        if constexpr (T / 64 >= 4) {
+            const float vq = smx[lane & (T / 64 - 1)];
+            const int cq = six[lane & (T / 64 - 1)];
+            m = wave_max_f(vq);
+            kk = wave_min_i((vq == m) ? cq : 0x7fffffff);
+        } else {  // two waves: the scalar compare is cheaper than two wave reductions
+            m = smx[0];
+            kk = six[0];
 #pragma unroll
-        for (int q = 1; q < T / 64; ++q) {
-            const float v = smx[q];
-            const int c = six[q];
-            const bool better = (v > m) || (v == m && c < kk);
-            m = better ? v : m;
-            kk = better ? c : kk;
+            for (int q = 1; q < T / 64; ++q) {
+                const float v = smx[q];
+                const int c = six[q];
+                const bool better = (v > m) || (v == m && c < kk);
+                m = better ? v : m;
+                kk = better ? c : kk;
+            }
         }
-        if (!(m == m) || kk == 0x7fffffff) return;  // NaN correlations
+        const bool abl = BLK_ABL;
+        if (!abl && (!(m == m) || kk == 0x7fffffff)) return;  // NaN correlations
+        if (abl) kk &= (Kp - 1);
         if constexpr (J == 0) {
             m0 = m;
         } else {
-            if (m < NOISE_REL * m0) return;
+            if (!abl && m < NOISE_REL * m0) return;
         }
-#pragma unroll
-        for (int i = 0; i < J; ++i)
-            if (s_dx[i] == kk) return;  // re-selection => stop (sparse_coding.py:323-325)
+        // re-selection => stop (sparse_coding.py:323-325).  Lane i of every wave holds Dx[i]: one compare + ballot (a loop of
+        // J dependent LDS reads with an exit each was the longest phase of a step: 0.47 of 1.6 us at k = 20)
+        if (!abl && __ballot(s.dxv == kk) != 0ull) return;
+        s.dxv = (lane == J) ? kk : s.dxv;
+        BLK_ST(2);
         const bool more = (J + 1 < KMAX) && (J + 1 < k);
         float g[R];
         if (!more) {
@@ -622,8 +654,25 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
             }
         }
         // ---- owner publishes a[kk] and w_i = p_i[kk]
-        if (tid == ((kk % (4 * T)) >> 2)) blk_publish<R, KMAX, J, 0>(s, (kk / (4 * T)) * 4 + (kk & 3), s_w, s_akk);
+        // the owner's WAVE reads element r of every vector (r is wave-uniform: one indexed v_mov per vector), the owner lane
+        // stores them (before: a branch tree over the register slots on one thread while 511 waited at the barrier)
+        {
+            const int owner = (kk % (4 * T)) >> 2, rown = (kk / (4 * T)) * 4 + (kk & 3);
+            if (wid == (owner >> 6)) {  // wave-uniform
+                const float va = blk_elem<R>(s.a, rown);
+                float tmp[J > 0 ? J : 1];
+#pragma unroll
+                for (int i = 0; i < J; ++i) tmp[i] = blk_elem<R>(s.p[i], rown);
+                if (tid == owner) {
+                    *s_akk = va;
+#pragma unroll
+                    for (int i = 0; i < J; ++i) s_w[i] = tmp[i];
+                }
+            }
+        }
+        BLK_ST(3);
         __syncthreads();
+        BLK_ST(4);
         float w[KMAX];
         const float gkk = unit_diag ? 1.f : G[(int64_t)kk * Kp + kk];
         float vs = gkk;
@@ -632,9 +681,11 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
             w[i] = s_w[i];
             vs = fmaf(-w[i], w[i], vs);
         }
-        if ((J > 0 || !unit_diag) && vs < EPS32_F * gkk) return;
+        if (!abl && (J > 0 || !unit_diag) && vs < EPS32_F * gkk) return;
+        if (abl) vs = 1.f + 1e-30f * vs;
         const float inv = __builtin_amdgcn_rsqf(vs);  // 1 ulp, like the single-wave kernel
-        const float t = (*s_akk) * inv;
+        const float t = abl ? 1e-3f * inv : (*s_akk) * inv;
+        BLK_ST(5);
         if constexpr (J + 1 < KMAX) {
             if (more) {
 #pragma unroll
@@ -656,6 +707,10 @@ __device__ __forceinline__ void blk_steps(BlkState<R, KMAX>& s, const float* __r
             s_dx[J] = kk;
             *s_nsel = J + 1;
         }
+#ifdef LYS_BLK_STAMPS
+        { float dep = s.a[0]; asm volatile("" : "+v"(dep)); s.a[0] = dep; }
+#endif
+        BLK_ST(6);
         // s_dx[J] is read by every thread in the next step only after that step's first barrier
         blk_steps<R, KMAX, J + 1, T>(s, G, Kp, k, tid, s_max, s_idx, s_w, s_akk, s_L, s_t, s_rinv, s_dx, s_nsel, m0,
                                   unit_diag);
@@ -674,14 +729,21 @@ __global__ __launch_bounds__(T, W) void bomp_block_kernel(const float* __restric
     __shared__ float s_w[KMAX];
     __shared__ float s_akk;
     __shared__ float s_L[KMAX * KMAX];
-    __shared__ float s_t[KMAX], s_rinv[KMAX], s_z[KMAX];
+    __shared__ float s_t[KMAX], s_rinv[KMAX];
     __shared__ int s_dx[KMAX];
     __shared__ int s_nsel;
     const int tid = threadIdx.x;
     const int64_t sig = blockIdx.x;
+#ifdef LYS_BLK_STAMPS
+    const unsigned long long t_wg0 = wall_clock64();
+#endif
     if (tid == 0) s_nsel = 0;
     if (tid < KMAX) s_dx[tid] = -1;
     BlkState<R, KMAX> s;
+#ifdef LYS_BLK_STAMPS
+    for (int i = 0; i < 8; ++i) s.ph[i] = 0;
+#endif
+    s.dxv = -1;
 #pragma unroll
     for (int c = 0; c < R / 4; ++c) {
         const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(alpha0 + sig * Kp) + c * T + tid);
@@ -692,23 +754,50 @@ __global__ __launch_bounds__(T, W) void bomp_block_kernel(const float* __restric
     }
     __syncthreads();
     float m0 = 0.f;
+#ifdef LYS_BLK_STAMPS
+    const unsigned long long t_wg1 = wall_clock64();
+#endif
     blk_steps<R, KMAX, 0, T>(s, G, Kp, k, tid, s_max, s_idx, s_w, &s_akk, s_L, s_t, s_rinv, s_dx, &s_nsel, m0, unit_diag);
     __syncthreads();
+#ifdef LYS_BLK_STAMPS
+    const unsigned long long t_wg2 = wall_clock64();
+#endif
     const int nsel = s_nsel;
-    if (tid == 0) {
-        // z = L^-T t (sparse_coding.py:354): k <= 20, a couple of hundred FMAs
+    if (tid < 64) {
+        // z = L^-T t (sparse_coding.py:354) on wave 0, column by column: lane q holds t_q, every solved z_i is broadcast and
+        // subtracted from the lanes below it (row i of L is contiguous in LDS).  The former single-thread double loop --
+        // k^2/2 dependent LDS round trips -- took a quarter of the kernel at k = 20.
+        float tq = (tid < nsel) ? s_t[tid] : 0.f;
+        const float rq = (tid < nsel) ? s_rinv[tid] : 0.f;
+        float zq = 0.f;
         for (int i = nsel - 1; i >= 0; --i) {
-            float zi = s_t[i];
-            for (int mI = i + 1; mI < nsel; ++mI) zi = fmaf(-s_L[mI * KMAX + i], s_z[mI], zi);
-            s_z[i] = zi * s_rinv[i];
+            const float zi = readlane_f(tq * rq, i);
+            zq = (tid == i) ? zi : zq;
+            const float Liq = (tid < i) ? s_L[i * KMAX + tid] : 0.f;
+            tq = fmaf(-Liq, zi, tq);
         }
-        nnz_out[sig] = nsel;
+        if (tid == 0) nnz_out[sig] = nsel;
+        if (tid < k) {
+            idx_out[sig * k + tid] = (tid < nsel) ? s_dx[tid] : -1;
+            coef_out[sig * k + tid] = (tid < nsel) ? zq : 0.f;
+        }
     }
-    __syncthreads();
-    if (tid < k) {
-        idx_out[sig * k + tid] = (tid < nsel) ? s_dx[tid] : -1;
-        coef_out[sig * k + tid] = (tid < nsel) ? s_z[tid] : 0.f;
+#ifdef LYS_BLK_STAMPS
+    if ((unit_diag >> 8) && tid == 0) {
+        const unsigned long long t_wg3 = wall_clock64();
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_blk_ph[i], (unsigned long long)s.ph[i]);
+        atomicAdd(&g_blk_ph[7], t_wg3 - t_wg0);
+        if (blockIdx.x < 16384) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_blk_tl[4 * blockIdx.x] = t_wg0;
+            g_blk_tl[4 * blockIdx.x + 1] = t_wg3;
+            g_blk_tl[4 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+            g_blk_tl[4 * blockIdx.x + 3] = t_wg2 - t_wg1;
+        }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -881,6 +970,20 @@ static int dispatch_k(const float* alpha0, const float* G, int64_t N, int k, int
 // vectors in LDS, 3 waves/SIMD, compile-time k and unit diagonal).  The round-1 timing ablations (cache-hot Gram rows,
 // no orthogonalisation FMAs, ...; results in profiles/r01_ablations_and_shapes.txt) were removed with their 15
 // instantiations in round 3.
+// out[0 .. 8): per-phase tick sums over all workgroups since the library was loaded; out[8 ..): 4 words per workgroup of
+// the last launch (start, end, XCC_ID << 32 | HW_ID, ticks inside the steps).  LYS_ENOSUP unless built with LYS_BLK_STAMPS.
+int bomp_debug_timeline(unsigned long long* out) {
+#ifdef LYS_BLK_STAMPS
+    LYS_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk_ph), sizeof(unsigned long long) * 8));
+    LYS_CHECK_HIP(hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_blk_tl), sizeof(unsigned long long) * 4 * 16384));
+    return LYS_OK;
+#else
+    (void)out;
+    set_error("bomp_debug_timeline: library built without -DLYS_BLK_STAMPS");
+    return LYS_ENOSUP;
+#endif
+}
+
 int bomp_debug_variant(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
                        int variant, int lds_bytes, hipStream_t stream) {
     const dim3 grid((unsigned)((N + 3) / 4)), block(256);
@@ -901,6 +1004,9 @@ static int launch_block(const float* alpha0, const float* G, int64_t N, int k, i
         set_error("bomp: too many signals per launch (%lld)", (long long)N);
         return LYS_ENOSUP;
     }
+#ifdef LYS_BLK_STAMPS
+    if (getenv("LYS_ABL")) unit_diag |= atoi(getenv("LYS_ABL")) << 8;
+#endif
     hipLaunchKernelGGL((bomp_block_kernel<R, KMAX, W, T>), dim3((unsigned)N), dim3(T), 0, stream, alpha0, G, N, k, idx,
                        coef, nnz, unit_diag);
     LYS_LAUNCH_CHECK();

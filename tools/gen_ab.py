@@ -6,7 +6,10 @@ from lyssandra_amd import _lib, engine
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
-for n, K, k, N in [(64, 256, 5, 1 << 20), (64, 256, 10, 1 << 20), (64, 512, 5, 1 << 20), (64, 512, 10, 1 << 20), (64, 1024, 5, 1 << 20), (64, 1024, 10, 1 << 20)]:
+SH = [(64, 256, 5, 1 << 20), (64, 256, 10, 1 << 20), (64, 512, 5, 1 << 20), (64, 512, 10, 1 << 20), (64, 1024, 5, 1 << 20), (64, 1024, 10, 1 << 20)]
+if len(sys.argv) > 1:
+    SH = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]
+for n, K, k, N in SH:
     g = torch.Generator(device=dev).manual_seed(1)
     Dt = torch.randn((n, K), device=dev, generator=g); Dt = Dt / Dt.norm(dim=0, keepdim=True)
     Xs = torch.randn((N, n), device=dev, generator=g)

@@ -24,7 +24,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         print("== rocprofv3 --kernel-trace --stats :: %s ==" % os.path.relpath(f, root))
         print("%-86s %7s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, calls, tot, avg, pct in cur.execute(
-                "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 16"):
+                "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit %d" % int(os.environ.get("LYS_SUMMARY_TOP", "16"))):
             print("%-86s %7d %14d %12.0f %7.2f" % (short(name), calls, tot, avg, pct))
             for key, field in (("bomp_wave2_kernel", "bomp_wave_kernel"), ("bomp_wave_kernel", "bomp_wave_kernel"),
                                ("alpha0_n64_bf16x3_kernel", "alpha0_n64_kernel"),
@@ -51,7 +51,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
                 if key in name:
                     pmc.setdefault(field, {}).update({c: v for c, v in r.items() if c not in ("n", "dur")})
                     break
-        for name in sorted(rows, key=lambda x: -rows[x]["n"])[:8]:
+        for name in sorted(rows, key=lambda x: -rows[x]["n"] * rows[x]["dur"])[:int(os.environ.get("LYS_SUMMARY_TOP", "16")) // 2]:
             r = rows[name]
             vals = ", ".join("%s=%.5g" % (c, v) for c, v in sorted(r.items()) if c not in ("n", "dur"))
             print("%-60s dispatches=%d avg_ns=%.0f  %s" % (short(name)[-60:], r["n"], r["dur"], vals))
