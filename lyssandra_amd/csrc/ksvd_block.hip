@@ -483,7 +483,20 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     // all per-signal addresses are 32-bit byte offsets on uniform bases (host checks N*ldr*4 and N*k*4 < 4 GB)
     const unsigned rsz = (unsigned)ldr * 4u, ksz = (unsigned)k * 4u;
     const int pcmp = have_p ? p : -2;  // dropped slots carry atom -1 = "block -1": must not look like block p
-    const int gteam = bx * TEAMS + team, nteams = nwg * TEAMS;
+    int gteam = bx * TEAMS + team, nteams = nwg * TEAMS;
+    // X(c): the first workgroups also run the group phase (the coupled signals' tuple moments, 128 leaders each), which made
+    // them the launch's critical path (14-18 us in-kernel against 9-12 for the others, tools/bk_stamps.py).  They now leave
+    // the entry walk to the rest -- unless the group phase is most of the launch (small dictionaries: everyone walks).
+    bool walks = true;
+    if (mode == 0 && have_c) {
+        const int kb0 = c << B;
+        const int ngw = (cg_ptr[kb0 + (1 << B)] - cg_ptr[kb0] + 2 * TEAMS - 1) / (2 * TEAMS);
+        if (ngw * 4 <= nwg) {
+            walks = bx >= ngw;
+            gteam = (bx - ngw) * TEAMS + team;
+            nteams = (nwg - ngw) * TEAMS;
+        }
+    }
     // state of the list walk (set by `begin_list`)
     int which = 0, tbeg = 0, tend = 0, chunk = 0, tpos = 0, rp_next = 0;
 
@@ -909,8 +922,10 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     };
 
     if (mode == 0) {
-        walk(ROLE_ACC, c, 1, true);
-        if (lazy) drain();
+        if (walks) {  // uniform per workgroup
+            walk(ROLE_ACC, c, 1, true);
+            if (lazy) drain();
+        }
         BK_WSTAMP(3);
         // ---- group phase: tuple moments of the coupled signals of block c (their leaders, sorted by in-block mask).
         // Workgroup w takes the entries [w * GCH, (w + 1) * GCH) of the block's range, 2 per team (loaded together).
