@@ -40,7 +40,6 @@ N_FEATURES, N_ATOMS, K_NNZ = 64, 1024, 10
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0         # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
-PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: aggregate L2 bandwidth
 SEED_SIGNALS, SEED_DICTIONARY = 20260928, 1234
 
 
@@ -346,9 +345,11 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
                               "bytes_model": "SURVEY 8(d): 8*n bytes per (atom, signal) non-zero = %.3g GB per sweep per GPU"
                                              % (8 * n * nnz_tot / 1e9),
                               "traffic": _sweep_traffic(),
-                              "traffic_model_gbs": 12 * n * nnz_tot / (ms["sweep"] * 1e-3) / 1e9,
-                              "traffic_model": "12*n bytes per non-zero: the row is read for the statistics, read and "
-                                               "written for the update"},
+                              "traffic_ratio_8d": (_sweep_traffic() / (8.0 * n * nnz_tot)) if _sweep_traffic() else None,
+                              "schedule": "lazy: a finished block's update is applied by the signal's next visit (one row "
+                                          "read + one row write per non-zero = the 8(d) bytes); LYS_BKSVD_LAZY=0 = the "
+                                          "eager round-2 schedule (12*n bytes per non-zero)",
+                              "includes": "index build (csr + block index), 257 step launches, final pass, D copy"},
            "final_error": err}
     # configs[1] as BASELINE.md states it: 50 alternations (encode, residual, sweep, error -- what ksvd_dict_learn runs per
     # iteration, ksvd.py:169-229) driven directly on the device-resident batch, one synchronisation at the end
@@ -472,9 +473,20 @@ def config3_shard(synth, N=1 << 17, reps=5):
             "roofline": {"bound": "valu", "kernel": "bomp_block_kernel<8,20,2,512> (one 512-thread workgroup per signal)",
                          "achieved": omp_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": omp_tf / PEAK_FP32_TFLOPS,
                          "flop_per_patch": f_omp, "avg_launch_ms": omp_ms,
+                         "traffic": _recorded("bomp_block_kernel_bytes_per_launch"),
+                         "note": "one signal per CU, eight waves in lock-step: bound by the latency chain of a step "
+                                 "(DESIGN 3.3), not by VALU throughput or by the Gram rows' bandwidth",
                          "gemm_stage": {"kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": gemm_tf,
                                         "frac": gemm_tf / PEAK_FP32_TFLOPS, "flop_per_patch": f_gemm,
                                         "avg_launch_ms": gemm_ms}}}
+
+
+def _recorded(key):
+    """A per-launch figure recorded by tools/profile_aux.sh (rocprofv3 PMC passes of this same command), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "kernel_durations.json"))).get(key)
+    except Exception:
+        return None
 
 
 def config4_minibatch(synth, B=32768, lam=0.2, reps=3):
@@ -524,11 +536,15 @@ def config4_minibatch(synth, B=32768, lam=0.2, reps=3):
             "ms": {"lars_coder": t_code, "statistics_and_update": t_upd},
             "value": B / (t_code * 1e-3), "unit": "signals/s (coder)",
             "mean_nnz": nnz_mean, "mean_breakpoints": br_mean,
-            "roofline": {"bound": "l2", "kernel": "lasso_lars_kernel (one workgroup per signal; active Gram rows re-read per "
-                                                  "breakpoint)",
-                         "achieved": l2_bytes / (t_code * 1e-3) / 1e9, "peak": PEAK_L2_GBS, "unit": "GB/s",
-                         "frac": l2_bytes / (t_code * 1e-3) / 1e9 / PEAK_L2_GBS,
-                         "bytes_model": "sum over breakpoints of |A| Gram rows of 4 K bytes = %.3g GB per mini-batch"
+            # bound: the Gram matrix (268 MB at K = 8192) exceeds the 256 MB Infinity Cache and 98.5 % of the coder's line
+            # requests miss L2 (profiles/traffic.json): the re-read rows are fabric / HBM traffic, priced against HBM
+            "roofline": {"bound": "hbm", "kernel": "lasso_lars_kernel (one workgroup per signal; active Gram rows re-read per "
+                                                   "breakpoint)",
+                         "achieved": l2_bytes / (t_code * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": l2_bytes / (t_code * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "traffic": _recorded("lasso_lars_kernel_bytes_per_launch"),
+                         "bytes_model": "sum over breakpoints of |A| Gram rows of 4 K bytes = %.3g GB per mini-batch; the "
+                                        "time is the whole coder (alpha0 GEMM + LARS path + coordinate-descent polish)"
                                         % (l2_bytes / 1e9)}}
 
 
