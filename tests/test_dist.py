@@ -289,6 +289,21 @@ def _worker(rank, world, port, out):
         assert [len(r) for r in lranges] == ([3, 3, 3] if rank == 0 else [4, 4, 3])
         exp = [c for b0, nb in ((0, 7), (7, 7), (14, 6)) for c in range(b0 + (rank * nb) // 2, b0 + ((rank + 1) * nb) // 2)]
         assert Xloc[0].tolist() == [float(c) for c in exp] and lranges[-1].stop == Xloc.shape[1]
+        # ---- a batch with FEWER signals than ranks (the remainder batch of 9 signals in batches of 8): rank 0's local
+        # range is empty, it contributes zero statistics and still joins the all-reduce (a rank that skipped the
+        # collective, or raised on N = 0, would hang the others)
+        Xm1 = rs.randn(n, 9)
+        Xloc1, lr1 = ld.shard_minibatches(Xm1, 8)
+        assert [len(r) for r in lr1] == ([4, 0] if rank == 0 else [4, 1])
+        Xlast = Xm1[:, 8:9]                                      # the one-signal global batch
+        Xl1 = Xloc1[:, lr1[1].start:lr1[1].stop]
+        assert Xl1.shape[1] == (0 if rank == 0 else 1)
+        Do1, Ao1, Bo1 = D0.copy(), np.zeros((K, K)), np.zeros((n, K))
+        Zl1 = orc.bomp_encode(Xl1, Do1, k) if Xl1.shape[1] else np.zeros((K, 0))
+        ld.odl_batch_sharded(NumpyOdlOps(Do1, Ao1, Bo1, Xl1, Zl1), 0.0)
+        Dg1, Ag1, Bg1 = orc.odl_batch_update(D0.copy(), np.zeros((K, K)), np.zeros((n, K)), Xlast,
+                                             orc.bomp_encode(Xlast, D0, k), 0.0)
+        assert np.max(np.abs(Ao1 - Ag1)) < 1e-12 and np.max(np.abs(Bo1 - Bg1)) < 1e-12 and np.max(np.abs(Do1 - Dg1)) < 1e-10
         # ---- scalar reduction used for the error
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         ld.allreduce_sum_(t)

@@ -864,6 +864,30 @@ def test_approx_ksvd_other_feature_sizes(eng, n, K, k, N):
     assert np.array_equal(D[:, K // 2], D0[:, K // 2])             # unused atom keeps its column
 
 
+def test_online_dl_empty_local_batch(eng):
+    """`dist.shard_minibatches` hands a rank an EMPTY range when the remainder batch has fewer signals than ranks
+    (online_dict_learn.py:84-98 run per shard): zero statistics, and the update step still runs (and still joins the
+    all-reduce: tests/test_dist.py covers the collective with gloo)."""
+    import torch
+    rs = np.random.RandomState(3)
+    n, K, k = 16, 24, 3
+    D0 = rs.randn(n, K)
+    D0 /= np.linalg.norm(D0, axis=0)
+    dd = eng.DeviceDictionary(n, K)
+    dd.set(torch.from_numpy(D0).float().cuda())
+    A0 = np.diag(rs.rand(K) + 0.5)
+    B0 = D0 @ A0
+    st = eng.OdlState(dd, A=A0, B=B0)
+    Xs = torch.empty((0, n), dtype=torch.float32, device="cuda")
+    idx = torch.empty((0, k), dtype=torch.int32, device="cuda")
+    coef = torch.empty((0, k), dtype=torch.float32, device="cuda")
+    nnz = torch.empty((0,), dtype=torch.int32, device="cuda")
+    st.batch_update(Xs, idx, coef, nnz, 0.5)
+    assert float(st.dA.abs().max()) == 0.0 and float(st.dB.abs().max()) == 0.0
+    assert np.allclose(st.A_host(), 0.5 * A0, atol=1e-6) and np.allclose(st.B_host(), 0.5 * B0, atol=1e-6)
+    assert np.abs(dd.to_host() - D0).max() < 1e-5              # B - D A = 0: the atoms only get re-normalised
+
+
 def test_online_dl_non_neg_and_error_pass(eng):
     """non_neg clipping (online_dict_learn.py:96-97) and the epoch-end error pass, against the oracle."""
     from lyssandra_amd.dict_learning.online_dict_learn import online_dict_learn
