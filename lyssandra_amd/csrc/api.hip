@@ -92,6 +92,7 @@ int bksvd_step(int, int, int, float*, int64_t, int, int, int, const int32_t*, co
                const int32_t*, float*, const float*, float*, double*, hipStream_t);
 int bksvd_finish(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const float*, const float*, int, hipStream_t);
 int bksvd_lazy(int, int);
+int bksvd_fused(int, int);
 int bksvd_sweep(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const int32_t*, int, int32_t*, void*,
                 int32_t*, int32_t*, void*, size_t, double*, float*, float*, hipStream_t);
 int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const float*, const int32_t*, const int32_t*,
@@ -624,6 +625,7 @@ int lys_bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, cons
 }
 
 int lys_bksvd_is_lazy(int k, int K) { return bksvd_lazy(k, K); }
+int lys_bksvd_is_fused(int k, int K) { return bksvd_fused(k, K); }
 
 int lys_bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
                     const int32_t* nnz, int B, int32_t* row_ptr, void* entry_records, int32_t* cg_ptr, int32_t* cg_entry,

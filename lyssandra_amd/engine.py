@@ -475,11 +475,15 @@ class HipBlockKsvdOps(object):
             buffers["berec"] = torch.empty((max(1, self.N * self.k), 4), dtype=torch.int32, device=dd.device)  # 16-B records
             buffers["bcg_ptr"] = torch.empty((self.nb * (1 << self.B) + 1,), dtype=torch.int32, device=dd.device)
             buffers["bcg_entry"] = torch.empty((self.N * self.k // 2 + 1,), dtype=torch.int32, device=dd.device)
-            buffers["stats"] = torch.zeros((self.nb, self.stride), dtype=torch.float64, device=dd.device)
+            # the library's size: the slabs of all blocks + the arrival counters of the fused launches behind them
+            nd = int(lib.lys_bksvd_stats_bytes(dd.n, dd.K, self.B)) // 8
+            assert nd >= self.nb * self.stride
+            buffers["stats_all"] = torch.zeros((nd,), dtype=torch.float64, device=dd.device)
+            buffers["stats"] = buffers["stats_all"][:self.nb * self.stride].view(self.nb, self.stride)
             buffers["bDnext"] = torch.zeros_like(dd.D)
         self.row_ptr, self.erec = buffers["brow_ptr"], buffers["berec"]
         self.cg_ptr, self.cg_entry = buffers["bcg_ptr"], buffers["bcg_entry"]
-        self.stats, self.Dnext = buffers["stats"], buffers["bDnext"]
+        self.stats, self.stats_all, self.Dnext = buffers["stats"], buffers["stats_all"], buffers["bDnext"]
         self.nnz = nnz
         self.ws = _workspace(max(int(lib.lys_bksvd_index_workspace_bytes(dd.K, self.k, self.N, self.B)), 4), dd.device,
                              "csr")
@@ -504,7 +508,7 @@ class HipBlockKsvdOps(object):
         _lib.check(self.lib.lys_bksvd_sweep(_ptr(self.R), _ld(self.R), dd.n, dd.K, self.k, self.N, _ptr(self.idx),
                                             _ptr(self.coef), _ptr(self.nnz), self.B, _ptr(self.row_ptr),
                                             _ptr(self.erec), _ptr(self.cg_ptr), _ptr(self.cg_entry), _ptr(self.ws),
-                                            self.ws.numel(), _ptr(self.stats), _ptr(dd.D), _ptr(self.Dnext),
+                                            self.ws.numel(), _ptr(self.stats_all), _ptr(dd.D), _ptr(self.Dnext),
                                             _stream()), "lys_bksvd_sweep")
         dd.invalidate()
         return self.unused()
@@ -515,7 +519,7 @@ class HipBlockKsvdOps(object):
                                             self.B, _ptr(self.row_ptr), _ptr(self.erec), _ptr(self.cg_ptr),
                                             _ptr(self.cg_entry), _ptr(self.ws), self.ws.numel(), _stream()),
                    "lys_bksvd_index")
-        self.stats.zero_()
+        self.stats_all.zero_()
 
     def step(self, mode, c):
         """mode 0 = X(c): block c-1's atom updates (from its reduced slab) || block c's statistics over the signals that
@@ -524,7 +528,7 @@ class HipBlockKsvdOps(object):
         _lib.check(self.lib.lys_bksvd_step(mode, c, self.B, _ptr(self.R), _ld(self.R), dd.n, dd.K, self.k,
                                            _ptr(self.row_ptr), _ptr(self.erec), _ptr(self.cg_ptr), _ptr(self.cg_entry),
                                            _ptr(self.idx), _ptr(self.coef),
-                                           _ptr(dd.D), _ptr(self.Dnext), _ptr(self.stats), _stream()), "lys_bksvd_step")
+                                           _ptr(dd.D), _ptr(self.Dnext), _ptr(self.stats_all), _stream()), "lys_bksvd_step")
 
     def slab(self, c):
         return self.stats[c]
