@@ -410,17 +410,13 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
 // cross-lane sums are fused DPP, FULL (n a multiple of 64) drops the feature guards.
 // ---------------------------------------------------------------------------------------------
 template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
-__global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode_in, int c_in, int nb, int K, float* __restrict__ R,
-                                                                int64_t ldr, int n, int k,
-                                                                const int32_t* __restrict__ row_ptr,
-                                                                const int4* __restrict__ erec,
-                                                                const int32_t* __restrict__ cg_ptr,
-                                                                const int32_t* __restrict__ cg_entry,
-                                                                const int32_t* __restrict__ idx,
-                                                                float* __restrict__ coef, const float* __restrict__ D,
-                                                                float* __restrict__ Dnext, int ldd,
-                                                                double* __restrict__ bbuf, BkLayout lay, int lazy_rt,
-                                                                int* __restrict__ done) {
+__device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, double* sm, int nb, int K, float* __restrict__ R,
+                                            int64_t ldr, int n, int k, const int32_t* __restrict__ row_ptr,
+                                            const int4* __restrict__ erec, const int32_t* __restrict__ cg_ptr,
+                                            const int32_t* __restrict__ cg_entry, const int32_t* __restrict__ idx,
+                                            float* __restrict__ coef, const float* __restrict__ D,
+                                            float* __restrict__ Dnext, int ldd, double* __restrict__ bbuf, BkLayout lay,
+                                            int lazy_rt) {
     // lazy != 0 (k <= 16, see bksvd_lazy): the update of a finished block is NOT applied by a pass of its own (the
     // ROLE_APPLY walk of Y) but by whoever touches the signal next -- the entry of the signal's next atom, whose index
     // record names the pending atom (predecessor), or bksvd_final_kernel for the signal's last block.  Every visit then
@@ -431,58 +427,60 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode_in, int
     constexpr int U = (FB == 1) ? 8 : 4;  // signals in flight per team
     constexpr int NTH = 16 * TEAMS;
     const bool lazy = (SL == 1) && (lazy_rt != 0);  // k <= 16 only: the other instantiations carry none of the lazy code
-    extern __shared__ double sm[];  // narrow step only
-    // The narrow step is workgroup 0: with ~100 KB of dynamic LDS only one workgroup fits a CU, a launch of 257 on 256 CUs
-    // leaves one waiting, and the serial narrow step -- the launch's critical path -- must not be the one that waits.
-    // mode 2 = the FUSED launch Z(c) = [Y(c)] -> [narrow step of block c || X(c+1)] (single GPU, lazy schedule): one launch
-    // and one kernel boundary per block instead of two.  Only workgroup 0 (the narrow step) waits inside the kernel -- for a
-    // device-scope counter that every other workgroup bumps when its Y(c) statistics are in; those workgroups never wait
-    // for anything, so the launch makes progress whatever the residency (no co-residency requirement, no deadlock).
-    int mode = (mode_in == 2) ? 1 : mode_in, c = c_in;
-    int nwg = (int)gridDim.x, bx = (int)blockIdx.x;
-    if (mode_in == 2) {
-        --nwg;
-        --bx;
-        if (bx < 0) {
-            if (threadIdx.x == 0) {
-                while (__hip_atomic_load(done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) __builtin_amdgcn_s_sleep(4);
-            }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of the slab may come from a stale line of this L2
-            bk_narrow_body<LOGB, FB, NTH>(c, K, n, D, Dnext, ldd, bbuf, lay, sm);
-            return;
-        }
-    } else if (mode == 0 && c >= 1) {
-        --nwg;
-        --bx;
-        if (bx < 0) {
-            bk_narrow_body<LOGB, FB, NTH>(c - 1, K, n, D, Dnext, ldd, bbuf, lay, sm);
-            return;
-        }
-    }
-    if (mode_in != 2 && mode == 0 && c >= nb) return;  // X(nb): only the narrow step of the last block
 
     __shared__ __attribute__((aligned(16))) float s_d[2][B][FB * 64];  // old / new atoms of block c-1 (mode Y)
     __shared__ double s_acc[B][FB * 64 + 2];                            // workgroup accumulators of block c
     __shared__ int s_rp[2][B + 1];                                      // row_ptr of block c-1 ([0]) and block c ([1])
     __shared__ int s_q[NTH][4];                                         // workgroup queue of slow-path entries
     __shared__ int s_qn;
+    const int p = c - 1;
+    const bool have_p = (mode == 1) && p >= 0;  // block c-1 is applied in this launch
+    const bool have_c = c < nb;
     const int tid = threadIdx.x, team = tid >> 4, q = tid & 15;
     const int stamp0 = (bx == 0) ? 32 : (bx == nwg / 2) ? 48 : -1;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BK_WSTAMP(i) do { if (stamp0 >= 0) ts[i] = wall_clock64(); } while (0)
-    // per-phase state (a fused launch runs two phases: Y(c), then X(c+1)); the lambdas below capture it by reference
-    int p = c - 1;
-    bool have_p = false, have_c = false;
+    BK_WSTAMP(0);
+    if (tid <= B) {
+        s_rp[0][tid] = (p >= 0) ? row_ptr[(p * B + tid < K) ? p * B + tid : K] : 0;
+        s_rp[1][tid] = have_c ? row_ptr[(c * B + tid < K) ? c * B + tid : K] : 0;
+    }
+    if (tid == 0) s_qn = 0;
+    for (int i = tid; i < B * (FB * 64 + 2); i += NTH) (&s_acc[0][0])[i] = 0.0;
+    if (have_p) {
+        for (int i = tid; i < B * FB * 64; i += NTH) {
+            const int t = i / (FB * 64), f = i % (FB * 64), a = p * B + t;
+            const bool in = (a < K) && (f < ldd);
+            s_d[0][t][f] = in ? D[(int64_t)a * ldd + f] : 0.f;
+            s_d[1][t][f] = in ? Dnext[(int64_t)a * ldd + f] : 0.f;
+        }
+    }
+    __syncthreads();
+    BK_WSTAMP(1);
+
     float4 acc[FB];
     float sq = 0.f;
     int cn = 0, cur = -1;
-    double* bb = bbuf;
+#pragma unroll
+    for (int b = 0; b < FB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    double* bb = bbuf + (int64_t)(have_c ? c : 0) * lay.stride;
     // all per-signal addresses are 32-bit byte offsets on uniform bases (host checks N*ldr*4 and N*k*4 < 4 GB)
     const unsigned rsz = (unsigned)ldr * 4u, ksz = (unsigned)k * 4u;
-    int pcmp = -2;  // dropped slots carry atom -1 = "block -1": must not look like block p
+    const int pcmp = have_p ? p : -2;  // dropped slots carry atom -1 = "block -1": must not look like block p
     int gteam = bx * TEAMS + team, nteams = nwg * TEAMS;
+    // X(c): the first workgroups also run the group phase (the coupled signals' tuple moments, 128 leaders each), which made
+    // them the launch's critical path (14-18 us in-kernel against 9-12 for the others, tools/bk_stamps.py).  They now leave
+    // the entry walk to the rest -- unless the group phase is most of the launch (small dictionaries: everyone walks).
     bool walks = true;
+    if (mode == 0 && have_c) {
+        const int kb0 = c << B;
+        const int ngw = (cg_ptr[kb0 + (1 << B)] - cg_ptr[kb0] + 2 * TEAMS - 1) / (2 * TEAMS);
+        if (ngw * 4 <= nwg) {
+            walks = bx >= ngw;
+            gteam = (bx - ngw) * TEAMS + team;
+            nteams = (nwg - ngw) * TEAMS;
+        }
+    }
     // state of the list walk (set by `begin_list`)
     int which = 0, tbeg = 0, tend = 0, chunk = 0, tpos = 0, rp_next = 0;
 
@@ -907,61 +905,6 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode_in, int
         }
     };
 
-    for (int ph = 0; ph < ((mode_in == 2) ? 2 : 1); ++ph) {
-    if (ph == 1) {
-        // Y(c) of this workgroup is in: its statistics were device-scope atomics (performed at the coherence point, not
-        // parked in this XCD's L2), so "every wave has its acknowledgements" + barrier + ONE relaxed device-scope add
-        // publishes them (a release fence at agent scope would write back the whole L2: 100 us when every wave does it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(done + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mode = 0;
-        c = c + 1;
-        if (c >= nb) break;  // uniform per launch
-    }
-    // ---- phase set-up
-    p = c - 1;
-    have_p = (mode == 1) && p >= 0;  // block c-1 is applied in this phase
-    have_c = c < nb;
-    BK_WSTAMP(0);
-    if (tid <= B) {
-        s_rp[0][tid] = (p >= 0) ? row_ptr[(p * B + tid < K) ? p * B + tid : K] : 0;
-        s_rp[1][tid] = have_c ? row_ptr[(c * B + tid < K) ? c * B + tid : K] : 0;
-    }
-    if (tid == 0) s_qn = 0;
-    for (int i = tid; i < B * (FB * 64 + 2); i += NTH) (&s_acc[0][0])[i] = 0.0;
-    if (have_p) {
-        for (int i = tid; i < B * FB * 64; i += NTH) {
-            const int t = i / (FB * 64), f = i % (FB * 64), a = p * B + t;
-            const bool in = (a < K) && (f < ldd);
-            s_d[0][t][f] = in ? D[(int64_t)a * ldd + f] : 0.f;
-            s_d[1][t][f] = in ? Dnext[(int64_t)a * ldd + f] : 0.f;
-        }
-    }
-    __syncthreads();
-    BK_WSTAMP(1);
-    sq = 0.f;
-    cn = 0;
-    cur = -1;
-#pragma unroll
-    for (int b = 0; b < FB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-    bb = bbuf + (int64_t)(have_c ? c : 0) * lay.stride;
-    pcmp = have_p ? p : -2;
-    gteam = bx * TEAMS + team;
-    nteams = nwg * TEAMS;
-    // X(c): the first workgroups also run the group phase (the coupled signals' tuple moments, 128 leaders each), which made
-    // them the launch's critical path (14-18 us in-kernel against 9-12 for the others, tools/bk_stamps.py).  They now leave
-    // the entry walk to the rest -- unless the group phase is most of the launch (small dictionaries: everyone walks).
-    walks = true;
-    if (mode == 0 && have_c) {
-        const int kb0 = c << B;
-        const int ngw = (cg_ptr[kb0 + (1 << B)] - cg_ptr[kb0] + 2 * TEAMS - 1) / (2 * TEAMS);
-        if (ngw * 4 <= nwg) {
-            walks = bx >= ngw;
-            gteam = (bx - ngw) * TEAMS + team;
-            nteams = (nwg - ngw) * TEAMS;
-        }
-    }
     if (mode == 0) {
         if (walks) {  // uniform per workgroup
             walk(ROLE_ACC, c, 1, true);
@@ -1101,10 +1044,72 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode_in, int
         }
     }
     BK_WSTAMP(5);
-    }  // phases
     if (stamp0 >= 0 && tid == 0)
         for (int i = 0; i < 8; ++i) g_bk_stamp[stamp0 + i] = ts[i];
 #undef BK_WSTAMP
+}
+
+// The launch: mode 0 = X(c), 1 = Y(c) (see the header), 2 = the FUSED launch Z(c) = [Y(c)] -> [narrow step of block c ||
+// X(c+1)] of the single-GPU lazy schedule: one launch and one kernel boundary per block instead of two.  Only workgroup 0
+// (the narrow step) waits inside the kernel -- for a device-scope counter that every other workgroup bumps when its Y(c)
+// statistics are in; those workgroups never wait for anything, so the launch makes progress whatever the residency (no
+// co-residency requirement, no deadlock).  The two phases are two inlined copies of bksvd_phase: a first version that ran
+// them as iterations of one loop over mutable phase state spilled 123 VGPRs (240 B of scratch per lane, 26 MB of scratch
+// traffic per launch) and made every schedule slower.
+template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
+__global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c, int nb, int K, float* __restrict__ R,
+                                                                int64_t ldr, int n, int k,
+                                                                const int32_t* __restrict__ row_ptr,
+                                                                const int4* __restrict__ erec,
+                                                                const int32_t* __restrict__ cg_ptr,
+                                                                const int32_t* __restrict__ cg_entry,
+                                                                const int32_t* __restrict__ idx,
+                                                                float* __restrict__ coef, const float* __restrict__ D,
+                                                                float* __restrict__ Dnext, int ldd,
+                                                                double* __restrict__ bbuf, BkLayout lay, int lazy_rt,
+                                                                int* __restrict__ done) {
+    constexpr int NTH = 16 * TEAMS;
+    extern __shared__ double sm[];  // narrow step / group phase
+    // The narrow step is workgroup 0: with ~100 KB of dynamic LDS only one workgroup fits a CU, a launch of 257 on 256 CUs
+    // leaves one waiting, and the serial narrow step -- the launch's critical path -- must not be the one that waits.
+    int nwg = (int)gridDim.x, bx = (int)blockIdx.x;
+#define BK_PHASE_ARGS nwg, bx, sm, nb, K, R, ldr, n, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, ldd, bbuf, lay, lazy_rt
+    if (mode == 2) {
+        --nwg;
+        --bx;
+        if (bx < 0) {
+            // 16 counters per block (workgroup bx bumps counter bx % 16): no 255-deep queue of device-scope adds on one address
+                        if (threadIdx.x < 16) {
+                const int want = (nwg - (int)threadIdx.x + 15) / 16;
+                while (__hip_atomic_load(done + c * 16 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of the slab may come from a stale line of this L2
+            bk_narrow_body<LOGB, FB, NTH>(c, K, n, D, Dnext, ldd, bbuf, lay, sm);
+            return;
+        }
+        bksvd_phase<FB, LOGB, SL, TEAMS, FULL>(1, c, BK_PHASE_ARGS);  // Y(c)
+        // Y(c) of this workgroup is in: its statistics were device-scope atomics (performed at the coherence point, not
+        // parked in this XCD's L2), so "every wave has its acknowledgements" + barrier + ONE relaxed device-scope add
+        // publishes them (a release fence at agent scope would write back the whole L2: 100 us when every wave does it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(done + c * 16 + (bx & 15), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c + 1 < nb) bksvd_phase<FB, LOGB, SL, TEAMS, FULL>(0, c + 1, BK_PHASE_ARGS);  // X(c+1) without its narrow step
+        return;
+    }
+    if (mode == 0 && c >= 1) {
+        --nwg;
+        --bx;
+        if (bx < 0) {
+            bk_narrow_body<LOGB, FB, NTH>(c - 1, K, n, D, Dnext, ldd, bbuf, lay, sm);
+            return;
+        }
+    }
+    if (mode == 0 && c >= nb) return;  // X(nb): only the narrow step of the last block
+    bksvd_phase<FB, LOGB, SL, TEAMS, FULL>(mode, c, BK_PHASE_ARGS);
+#undef BK_PHASE_ARGS
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1226,10 +1231,13 @@ int bksvd_lazy(int k, int K) {
     return (!(e && e[0] == '0') && k <= 16 && K <= 8192) ? 1 : 0;
 }
 
-// Fused launches (one per block) for the single-GPU sweep of the lazy schedule; LYS_BKSVD_FUSED=0 keeps X / Y apart.
+// Fused launches (one per block) for the single-GPU sweep of the lazy schedule: OPT-IN (LYS_BKSVD_FUSED=1).  Measured in
+// round 3 (tools/profile_ksvd.sh, same box): Z(c) 26.2 us against X 17.4 + Y 8.6 -- the kernel boundary it saves (~3.5 us) is
+// spent inside the kernel instead: the narrow workgroup sees the last arrival 1.8 us late (an uncached device-scope load is a
+// fabric round trip) and both phases run ~1 us slower than as launches of their own.  4.13 against 4.19 ms per sweep.
 int bksvd_fused(int k, int K) {
     const char* e = getenv("LYS_BKSVD_FUSED");
-    return (!(e && e[0] == '0') && bksvd_lazy(k, K)) ? 1 : 0;
+    return ((e && e[0] == '1') && bksvd_lazy(k, K)) ? 1 : 0;
 }
 
 template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
@@ -1338,11 +1346,11 @@ int bk_debug_timestamps(unsigned long long* out64) {
     return LYS_OK;
 }
 
-// the slabs of all blocks, then one int per block (+ spare): the arrival counters of the fused launches
+// the slabs of all blocks, then 16 ints per block (+ spare): the arrival counters of the fused launches
 size_t bksvd_stats_doubles(int n, int K, int B) {
     const BkLayout lay = bk_layout(n, B);
     const size_t nb = (size_t)((K + B - 1) / B);
-    return nb * (size_t)lay.stride + (nb + 4) / 2 + 1;
+    return nb * (size_t)lay.stride + (nb + 2) * 8;  // 16 ints per block
 }
 
 int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int32_t* row_ptr,

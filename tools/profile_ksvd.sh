@@ -15,12 +15,12 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_w
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc -- $CMD > /dev/null 2> $OUT/pmc_sq.err
 cd $ROOT
 {
-  echo "# command: $CMD  (3 alternations; the sweep = 257 launches of bksvd_step_kernel per alternation + the index build)"
+  echo "# command: $CMD  (3 alternations; the sweep = ${STEPS:-257} launches of bksvd_step_kernel per alternation + the index build + the final pass; STEPS=129 with LYS_BKSVD_FUSED=1)"
   tail -3 $OUT/trace_cmd.out
   python $ROOT/tools/summarize_profile.py $OUT
   echo
-  echo "== per-launch split of the last sweep (X(c) = narrow step of block c-1 || statistics of block c; Y(c) = apply block c-1) =="
-  python $ROOT/tools/step_durations.py $OUT/trace 257
+  echo "== per-launch durations of the last sweep (fused: Z(c) = Y(c) -> [narrow step of block c || X(c+1)]; unfused: X(c), Y(c)) =="
+  python $ROOT/tools/step_durations.py $OUT/trace ${STEPS:-257}
 } > $ROOT/gpurun_out/prof_ksvd_${TAG}_summary.txt 2>&1
 find $OUT -name "*.db" -delete
 tail -40 $ROOT/gpurun_out/prof_ksvd_${TAG}_summary.txt
