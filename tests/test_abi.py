@@ -182,3 +182,25 @@ def test_c_caller_compiles_and_links(lib):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     assert os.path.exists(exe)
+
+
+def test_headline_kernels_have_no_scratch(lib):
+    """The product kernels of the hot path must not touch scratch memory: round 3 lost performance twice to scratch nobody
+    had asked for (a 4-element vector indexed at run time in the greedy kernel: C1 shape 1.5x slower; a loop over mutable
+    phase state in the K-SVD step kernel: 26 MB of scratch traffic per launch).  Read from the code objects of the build
+    (tools/kernel_resources.py: no recompilation, no GPU)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+    ks = kernel_resources.kernels()
+    assert len(ks) > 100
+    headline = ["bomp_wave2_kernelILi16ELi10E", "bomp_wave2_kernelILi16ELi5E", "bomp_wave2_kernelILi8ELi10E",
+                "bomp_wave2_kernelILi4ELi5E", "bomp_wave2_kernelILi4ELi10E", "alpha0_n64_bf16x3_kernel", "alpha0_n64_kernel",
+                "bksvd_step_kernelILi1ELi3ELi1ELi64ELb1E", "bksvd_final_kernelILi1ELi3ELi1ELb1E", "bksvd_index_kernel",
+                "bomp_block_kernelILi8ELi20ELi2ELi512E", "bomp_block_kernelILi16ELi10E", "lasso_lars_kernelILi16E",
+                "residual_team_kernel", "odl_increment_kernel", "ksvd_gram64_kernel", "ksvd_eig64_kernel"]
+    for h in headline:
+        hit = [k for k in ks if h in k["name"]]
+        assert hit, "kernel %s not found in the build" % h
+        for k in hit:
+            assert k["scratch"] == 0 and k["spill"] == 0, (k["name"], k["vgpr"], k["spill"], k["scratch"])
