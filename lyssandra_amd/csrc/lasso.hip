@@ -193,7 +193,10 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_cd_kernel(const fl
                 }
                 ++pos;
             }
-        const bool fresh_and_quiet = (round > 0) && (steps == steps_before);
+        // a warm start builds its correlations from the handed-over list exactly like the refresh below does: if its first
+        // round needs no step the state IS fresh and quiet (before round 3 the polish after LARS re-read the active Gram
+        // rows a second time to find that out: 2 x 1 MB per signal at K = 8192)
+        const bool fresh_and_quiet = (round > 0 || warm) && (steps == steps_before);
         if (fresh_and_quiet || steps >= max_steps || round >= MAX_REFRESH || total > kcap || total == 0) break;
         // ---- refresh: c = alpha0 - sum_e coef_e * G[idx_e, :] from the list just written
         __threadfence_block();
