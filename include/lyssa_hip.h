@@ -303,6 +303,14 @@ int lys_odl_increments(const float* X, int64_t ldx, int n, int K, int k,
                        float* dA, float* dB, void* stream);
 /* y = beta*y + x over `count` floats (the beta*A + dA of :84-85). */
 int lys_axpby(float* y, float beta, const float* x, int64_t count, void* stream);
+/* Multi-GPU exchange of the symmetric statistics A = Z Z' (online_dict_learn.py:84; the reference has one process and no
+ * exchange): only the block-upper triangle travels -- row block i (rows [i*block, (i+1)*block)) keeps its columns
+ * [i*block, Kp), the blocks follow each other in `flat` (lys_sym_packed_count floats; Kp = 8192, block = 1024: 144 MB
+ * instead of 256 MB).  lys_sym_pack gathers; lys_sym_unpack scatters the reduced buffer back into A (leading dimension
+ * Kp) and mirrors it below the block diagonal.  Kp and block: multiples of 64. */
+int64_t lys_sym_packed_count(int Kp, int block);
+int lys_sym_pack(const float* A, int Kp, int block, float* flat, void* stream);
+int lys_sym_unpack(const float* flat, int Kp, int block, float* A, void* stream);
 /*
  * Dictionary update of one mini-batch (:91-98): DA = D A once (MFMA GEMM), d_k += (B_k - DA_k) /
  * (A_kk + eps) for all k, optional clipping to >= 0, column normalisation x/(||x||+eps).

@@ -66,6 +66,9 @@ SIGNATURES = {
     "lys_ksvd_exact_sweep": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _Z, _P, _P, _L, _P]),
     "lys_odl_increments": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lys_axpby": (_I, [_P, _F, _P, _L, _P]),
+    "lys_sym_packed_count": (_L, [_I, _I]),
+    "lys_sym_pack": (_I, [_P, _I, _I, _P, _P]),
+    "lys_sym_unpack": (_I, [_P, _I, _I, _P, _P]),
     "lys_odl_update": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "lys_pgd_update": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P]),
     "lys_grid_patches": (_I, [_P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _L, _P]),

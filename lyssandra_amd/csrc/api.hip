@@ -91,6 +91,9 @@ BkLayout bk_layout(int n, int B);
 int bksvd_step(int, int, int, float*, int64_t, int, int, int, const int32_t*, const void*, const int32_t*, const int32_t*,
                const int32_t*, float*, const float*, float*, double*, hipStream_t);
 int bksvd_finish(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const float*, const float*, int, hipStream_t);
+int64_t sym_packed_count(int, int);
+int sym_pack(const float*, int, int, float*, hipStream_t);
+int sym_unpack(const float*, int, int, float*, hipStream_t);
 int bksvd_lazy(int, int);
 int bksvd_fused(int, int);
 int bksvd_sweep(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const int32_t*, int, int32_t*, void*,
@@ -674,6 +677,18 @@ int lys_odl_increments(const float* X, int64_t ldx, int n, int K, int k, const i
                        void* stream) {
     LYS_REQUIRE(X && idx && coef && nnz && row_ptr && entry && dA && dB, "odl_increments: null pointer");
     return odl_increments(X, ldx, n, K, k, idx, coef, nnz, row_ptr, entry, dA, dB, STREAM(stream));
+}
+
+int64_t lys_sym_packed_count(int Kp, int block) { return (Kp > 0 && block > 0) ? sym_packed_count(Kp, block) : 0; }
+
+int lys_sym_pack(const float* A, int Kp, int block, float* flat, void* stream) {
+    LYS_REQUIRE(A && flat, "sym_pack: null pointer");
+    return sym_pack(A, Kp, block, flat, STREAM(stream));
+}
+
+int lys_sym_unpack(const float* flat, int Kp, int block, float* A, void* stream) {
+    LYS_REQUIRE(A && flat, "sym_unpack: null pointer");
+    return sym_unpack(flat, Kp, block, A, STREAM(stream));
 }
 
 int lys_axpby(float* y, float beta, const float* x, int64_t count, void* stream) {

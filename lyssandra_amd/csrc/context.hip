@@ -160,7 +160,7 @@ struct lys_dev {
     int64_t sweep_N = -1;
     int sweep_k = -1;
     // online DL
-    float *A = nullptr, *B = nullptr, *dA = nullptr, *dB = nullptr, *scratch = nullptr;
+    float *A = nullptr, *B = nullptr, *dA = nullptr, *dB = nullptr, *pk = nullptr, *scratch = nullptr;
     int32_t *c_row_ptr = nullptr, *c_entry = nullptr;
     void* csr_ws = nullptr;
     size_t csr_ws_bytes = 0;
@@ -237,7 +237,8 @@ static void dev_free_learning(lys_dev* d) {
     dfree(d->A);
     dfree(d->B);
     dfree(d->dA);
-    dfree(d->dB);
+    dfree(d->pk);
+    d->dB = nullptr;  // lives in the tail of pk
     dfree(d->scratch);
     dfree(d->c_row_ptr);
     dfree(d->c_entry);
@@ -887,13 +888,19 @@ int lys_ctx_get_unused(const lys_ctx* c, int32_t* atoms_host, int cap) {
 }
 
 // ---------------------------------------------------------------------------------------------- online DL
+static int ctx_sym_block(int Kp) { return Kp >= 1024 ? 1024 : Kp; }  // Kp is a multiple of 64
+
 static int dev_reserve_odl(lys_ctx* c, lys_dev* d) {
     if (d->A) return LYS_OK;
     const size_t kk = (size_t)c->Kp * c->Kp, kn = (size_t)c->Kp * c->ldd;
     CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->A), kk * sizeof(float)));
-    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->dA), (kk + kn) * sizeof(float)));  // dA | dB contiguous: one all-reduce
+    // exchange buffer pk = [block-upper triangle of dA | dB]: dB LIVES in its tail (lys_odl_increments writes it there),
+    // dA is gathered into its head by lys_sym_pack: one all-reduce of 144 MB + dB instead of 256 MB + dB at K = 8192
+    const size_t npk = (size_t)lys_sym_packed_count(c->Kp, ctx_sym_block(c->Kp));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->dA), kk * sizeof(float)));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->pk), (npk + kn) * sizeof(float)));
     CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->B), kn * sizeof(float)));
-    d->dB = d->dA + kk;
+    d->dB = d->pk + npk;
     CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->scratch), 2 * kn * sizeof(float)));
     CTX_HIP(hipMemsetAsync(d->A, 0, kk * sizeof(float), d->stream));
     CTX_HIP(hipMemsetAsync(d->B, 0, kn * sizeof(float), d->stream));
@@ -931,7 +938,8 @@ int lys_ctx_odl_accumulate(lys_ctx* c, const float* X_sig_major_host, int64_t Nb
         CTX_HIP(hipSetDevice(d->device));
         CTX_RC(dev_reserve_odl(c, d));
         if (d->Ns == 0) {
-            CTX_HIP(hipMemsetAsync(d->dA, 0, (kk + kn) * sizeof(float), d->stream));  // empty shard: zeros into the sum
+            CTX_HIP(hipMemsetAsync(d->dA, 0, kk * sizeof(float), d->stream));  // empty shard: zeros into the sum
+            CTX_HIP(hipMemsetAsync(d->dB, 0, kn * sizeof(float), d->stream));
             continue;
         }
         if (d->c_cap < d->Ns * k) {
@@ -949,8 +957,21 @@ int lys_ctx_odl_accumulate(lys_ctx* c, const float* X_sig_major_host, int64_t Nb
         CTX_RC(lys_odl_increments(d->Xs, c->n, c->n, c->K, k, d->r_idx, d->r_coef, d->r_nnz, d->c_row_ptr, d->c_entry, d->dA,
                                   d->dB, d->stream));
     }
-    if (c->use_rccl)
-        CTX_RC(ctx_allreduce(c, [&](int i) { return static_cast<void*>(c->dev[i].dA); }, kk + kn, NCCL_FLOAT32));
+    if (c->use_rccl) {
+        const int blk = ctx_sym_block(c->Kp);
+        const size_t npk = (size_t)lys_sym_packed_count(c->Kp, blk);
+        for (int i = 0; i < c->nd; ++i) {
+            lys_dev* d = &c->dev[i];
+            CTX_HIP(hipSetDevice(d->device));
+            CTX_RC(lys_sym_pack(d->dA, c->Kp, blk, d->pk, d->stream));
+        }
+        CTX_RC(ctx_allreduce(c, [&](int i) { return static_cast<void*>(c->dev[i].pk); }, npk + kn, NCCL_FLOAT32));
+        for (int i = 0; i < c->nd; ++i) {
+            lys_dev* d = &c->dev[i];
+            CTX_HIP(hipSetDevice(d->device));
+            CTX_RC(lys_sym_unpack(d->pk, c->Kp, blk, d->dA, d->stream));
+        }
+    }
     for (int i = 0; i < c->nd; ++i) {
         lys_dev* d = &c->dev[i];
         CTX_HIP(hipSetDevice(d->device));

@@ -77,6 +77,68 @@ int axpby(float* y, float beta, const float* x, int64_t count, hipStream_t strea
     return LYS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exchange format of the symmetric statistics matrix A = Z Z' (online_dict_learn.py:84): only the block-upper triangle
+// travels.  Row block i = rows [i*blk, min((i+1)*blk, Kp)) keeps its columns [i*blk, Kp); the blocks follow each other in
+// one flat buffer (K = 8192, blk = 1024: 144 MB instead of 256 MB).  `sym_pack` gathers, `sym_unpack` scatters the reduced
+// buffer back and mirrors it below the block diagonal with an LDS-tiled transpose.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int64_t sym_block_offset(int i, int Kp, int blk) {  // floats before row block i
+    // sum_{j<i} blk * (Kp - j*blk)   (every block before the last is full)
+    return (int64_t)i * blk * Kp - (int64_t)blk * blk * ((int64_t)i * (i - 1) / 2);
+}
+
+int64_t sym_packed_count(int Kp, int blk) {
+    const int nbk = (Kp + blk - 1) / blk;
+    const int last = nbk - 1;
+    return sym_block_offset(last, Kp, blk) + (int64_t)(Kp - last * blk) * (Kp - last * blk);
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void sym_rows_kernel(float* __restrict__ A, int Kp, int blk, float* __restrict__ flat) {
+    const int r = blockIdx.x, i = r / blk, c0 = i * blk, w = Kp - c0;
+    float* dst = flat + sym_block_offset(i, Kp, blk) + (int64_t)(r - c0) * w;
+    float* row = A + (int64_t)r * Kp + c0;
+    for (int c = threadIdx.x * 4; c < w; c += 256 * 4) {  // Kp and blk are multiples of 64: whole float4s
+        if (PACK) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(row + c);
+        else *reinterpret_cast<float4*>(row + c) = *reinterpret_cast<const float4*>(dst + c);
+    }
+}
+
+// A[c][r] = A[r][c] for the 32 x 32 tiles right of the block diagonal (tile row tr in block i, tile column >= (i+1)*blk/32)
+__global__ __launch_bounds__(256) void sym_mirror_kernel(float* __restrict__ A, int Kp, int blk) {
+    __shared__ float t[32][33];
+    const int tr = blockIdx.y, tc = blockIdx.x;
+    if (tc * 32 < (tr * 32 / blk + 1) * blk) return;  // inside or left of the diagonal block: already complete
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) t[y + j][x] = A[(int64_t)(tr * 32 + y + j) * Kp + tc * 32 + x];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) A[(int64_t)(tc * 32 + y + j) * Kp + tr * 32 + x] = t[x][y + j];
+}
+
+int sym_pack(const float* A, int Kp, int blk, float* flat, hipStream_t stream) {
+    if (Kp <= 0 || Kp % 64 || blk <= 0 || blk % 64) {
+        set_error("sym_pack: Kp = %d and block = %d must be positive multiples of 64", Kp, blk);
+        return LYS_EINVAL;
+    }
+    hipLaunchKernelGGL(sym_rows_kernel<true>, dim3(Kp), dim3(256), 0, stream, const_cast<float*>(A), Kp, blk, flat);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+int sym_unpack(const float* flat, int Kp, int blk, float* A, hipStream_t stream) {
+    if (Kp <= 0 || Kp % 64 || blk <= 0 || blk % 64) {
+        set_error("sym_unpack: Kp = %d and block = %d must be positive multiples of 64", Kp, blk);
+        return LYS_EINVAL;
+    }
+    hipLaunchKernelGGL(sym_rows_kernel<false>, dim3(Kp), dim3(256), 0, stream, A, Kp, blk, const_cast<float*>(flat));
+    if (Kp > blk) hipLaunchKernelGGL(sym_mirror_kernel, dim3(Kp / 32, Kp / 32), dim3(256), 0, stream, A, Kp, blk);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 // one wave per atom: d += (B - DA) / (A_aa + eps); clip; d /= (||d|| + eps)     (:93-98)
 __global__ __launch_bounds__(64) void odl_update_kernel(float* __restrict__ D, int ldd, int n, int Kp,
                                                         const float* __restrict__ A, const float* __restrict__ B,

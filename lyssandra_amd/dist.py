@@ -16,6 +16,8 @@ dictionary is replicated.
 The protocol functions below are written against a small `ops` interface so that the SAME control flow runs on the
 HIP engine (engine.HipKsvdOps / engine.OdlState) and, in the CPU tests (gloo, world_size 2), on a numpy stand-in.
 """
+import os
+
 import numpy as np
 
 from .utils import shard_range  # noqa: F401  (re-export)
@@ -163,6 +165,9 @@ def ksvd_cycle_blocks(ops, group=None):
 
 
 # ------------------------------------------------------------------------------------------------ online DL
+_SYM_FLAT = {}  # persistent exchange buffer of allreduce_symmetric_ (device path)
+
+
 def allreduce_symmetric_(A, extra=None, group=None, block=1024):
     """Sum over ranks of a SYMMETRIC square matrix `A` (and optionally of `extra`, any tensor) with one collective that
     carries only the block-upper triangle of A: the row blocks [i*block, (i+1)*block) x [i*block, K) are packed into one
@@ -170,10 +175,35 @@ def allreduce_symmetric_(A, extra=None, group=None, block=1024):
     144 MB + B instead of 256 MB + B on the wire (online_dict_learn.py:84-85).  No-op without a process group."""
     import torch
     ws, _ = world(group)
-    if ws <= 1:
+    if ws <= 1 and os.environ.get("LYS_DIST_FORCE") != "1":     # (forced: the pack / collective / unpack run in a world of one)
         return A
     K = A.shape[0]
     assert A.shape[0] == A.shape[1]
+    if A.is_cuda and A.dtype == torch.float32 and A.is_contiguous() and K % 64 == 0 and block % 64 == 0 and \
+            (extra is None or (extra.is_cuda and extra.dtype == torch.float32 and extra.is_contiguous())):
+        # device path: ONE persistent flat buffer [packed upper blocks | extra], written by lys_sym_pack and one copy,
+        # all-reduced, read back by lys_sym_unpack (scatter + LDS-tiled mirror) and one copy -- no torch.cat, no per-block
+        # slicing, no strided transposes
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        npk = int(lib.lys_sym_packed_count(K, block))
+        nex = 0 if extra is None else extra.numel()
+        key = (A.device, K, block, nex)
+        flat = _SYM_FLAT.get(key)
+        if flat is None:
+            _SYM_FLAT.clear()                      # one shape at a time (K = 8192: 148 MB)
+            flat = _SYM_FLAT[key] = torch.empty((npk + nex,), dtype=torch.float32, device=A.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(lib.lys_sym_pack(P(A), K, block, P(flat), st), "lys_sym_pack")
+        if nex:
+            flat[npk:].copy_(extra.reshape(-1))
+        allreduce_sum_(flat, group)
+        _lib.check(lib.lys_sym_unpack(P(flat), K, block, P(A), st), "lys_sym_unpack")
+        if nex:
+            extra.copy_(flat[npk:].view_as(extra))
+        return A
     parts = [A[i:min(i + block, K), i:].reshape(-1) for i in range(0, K, block)]
     if extra is not None:
         parts.append(extra.reshape(-1))

@@ -864,6 +864,34 @@ def test_approx_ksvd_other_feature_sizes(eng, n, K, k, N):
     assert np.array_equal(D[:, K // 2], D0[:, K // 2])             # unused atom keeps its column
 
 
+@pytest.mark.parametrize("Kp,block", [(2048, 1024), (640, 256), (1024, 1024), (192, 64), (8192, 1024)])
+def test_symmetric_exchange_pack_unpack_round_trip(eng, Kp, block):
+    """The exchange format of Z Z' (online_dict_learn.py:84 per shard; lys_sym_pack / lys_sym_unpack): only the block-upper
+    triangle travels, the receiver mirrors it.  pack -> unpack into a poisoned matrix reproduces the symmetric matrix exactly,
+    and the packed length is the documented one (K = 8192: 144 MB)."""
+    import ctypes
+    import torch
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(Kp + block)
+    M = torch.randn((Kp, Kp), device="cuda", generator=g)
+    A = (M + M.t()).contiguous()
+    npk = int(lib.lys_sym_packed_count(Kp, block))
+    exp = sum((min(i + block, Kp) - i) * (Kp - i) for i in range(0, Kp, block))
+    assert npk == exp
+    if Kp == 8192:
+        assert abs(npk * 4 / 2**20 - 144) < 1
+    flat = torch.full((npk,), float("nan"), device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(lib.lys_sym_pack(P(A), Kp, block, P(flat), st))
+    ref = torch.cat([A[i:min(i + block, Kp), i:].reshape(-1) for i in range(0, Kp, block)])
+    assert torch.equal(flat, ref)
+    A2 = torch.full((Kp, Kp), float("nan"), device="cuda")
+    _lib.check(lib.lys_sym_unpack(P(flat), Kp, block, P(A2), st))
+    assert torch.equal(A2, A)
+
+
 def test_online_dl_empty_local_batch(eng):
     """`dist.shard_minibatches` hands a rank an EMPTY range when the remainder batch has fewer signals than ranks
     (online_dict_learn.py:84-98 run per shard): zero statistics, and the update step still runs (and still joins the
