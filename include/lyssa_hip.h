@@ -189,9 +189,12 @@ int lys_ksvd_atom_apply(int atom, float* R, int64_t ldr, int n, int k,
  * (<= 24 steps, started at d_old) + Rayleigh-Ritz, then x_omega = Rk'u; sign u . d_old >= 0.
  * n > 256 (the LC-KSVD stack [X; sqrt(alpha) Q; sqrt(beta) H], lyssa/dict_learning/lc_ksvd.py:140-172: many features,
  * few signals per atom): the same eigen-solve on the |omega| x |omega| Gram matrix Rk'Rk of the COLUMNS, u = Rk v /
- * ||Rk v||; needs max_support <= 256 there (LYS_ENOSUP otherwise -- no fallback).
+ * ||Rk v|| for the atoms used by <= 256 signals; atoms with more users (n > 256 AND |omega| > 256: neither Gram matrix
+ * is small) run a matrix-free power iteration on Rk Rk' from d_old -- one pass over the atom's restricted residual per
+ * iteration, stopped when successive iterates agree to 1e-6 rad (polled by the host every 4 iterations, at most 400).
  * work: lys_ksvd_exact_workspace_bytes(n).  max_support >= max_a |omega_a| (N is always valid for n <= 256; for n > 256
- * pass the true maximum).  Unused atoms keep their column.  Single GPU.
+ * pass the true maximum: above 256 the call reads row_ptr back to choose the path per atom).  Unused atoms keep their
+ * column.  Single GPU.
  */
 size_t lys_ksvd_exact_workspace_bytes(int n);
 int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k,

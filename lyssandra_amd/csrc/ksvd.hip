@@ -8,6 +8,8 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <vector>
+#include <utility>
 #include <algorithm>
 
 namespace lys {
@@ -1868,20 +1870,103 @@ __global__ __launch_bounds__(256) void ksvd_tall_apply_kernel(int atom, float* _
         for (int f = tid; f < n; f += 256) Dnext[(int64_t)atom * ldd + f] = (s2v > 0.0) ? uraw[f] * inv : dold[f];
 }
 
+// ---- n > 256 AND an atom used by more than TALL_MAX signals: neither Gram matrix (n x n, |omega| x |omega|) is small.
+// Matrix-free power iteration on C = Rk Rk' from u = d_old: per iteration ONE pass over the atom's restricted residual --
+// a workgroup takes MF_SPW signals, forms v_i = rk_i . u (its slice of Rk' u) and adds sum_i v_i rk_i into the next
+// iterate (rows still L2-warm) -- plus a one-workgroup kernel for the norm, the sign (u . d_old) and sin^2 of the angle
+// between successive iterates, which the host polls every few iterations.  Slow next to the Gram paths (an iteration per
+// pass, fp32 atomics into the iterate) but it closes the shape the exact update used to refuse.
+constexpr int MF_SPW = 16;
+
+__global__ __launch_bounds__(256) void ksvd_mf_init_kernel(int atom, int n, const float* __restrict__ D, int ldd,
+                                                           float* __restrict__ u, double* __restrict__ s2) {
+    __shared__ double pr[256], red[16];
+    double acc = 0.0;
+    for (int f = threadIdx.x; f < n; f += 256) {
+        const float d = D[(int64_t)atom * ldd + f];
+        u[f] = d;
+        acc += (double)d * (double)d;
+    }
+    const double tot = block_sum_d(acc, pr, red);
+    if (threadIdx.x == 0) {
+        s2[0] = tot;  // ||u||^2
+        s2[1] = tot;  // u . d_old
+        s2[2] = 1.0;  // sin^2 of the angle to the previous iterate: "not converged"
+    }
+}
+
+__global__ __launch_bounds__(256) void ksvd_mf_iter_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                                           const int32_t* __restrict__ row_ptr,
+                                                           const int32_t* __restrict__ entry,
+                                                           const float* __restrict__ coef, const float* __restrict__ D,
+                                                           int ldd, const float* __restrict__ uold,
+                                                           const double* __restrict__ s2old, float* __restrict__ unew) {
+    __shared__ double pr[256], red[16];
+    __shared__ int64_t sg[MF_SPW];
+    __shared__ float xs[MF_SPW], vs[MF_SPW];
+    const int beg = row_ptr[atom], m = row_ptr[atom + 1] - beg;
+    const int i0 = blockIdx.x * MF_SPW;
+    if (i0 >= m) return;
+    const int cnt = (m - i0 < MF_SPW) ? m - i0 : MF_SPW;
+    const int tid = threadIdx.x;
+    if (tid < cnt) {
+        const int ss = entry[beg + i0 + tid];
+        sg[tid] = (int64_t)(ss / k) * ldr;
+        xs[tid] = coef[ss];
+    }
+    __syncthreads();
+    const float* dold = D + (int64_t)atom * ldd;
+    const double nrm2 = s2old[0];
+    const double inv = (nrm2 > 0.0) ? 1.0 / sqrt(nrm2) : 0.0;
+    for (int s = 0; s < cnt; ++s) {  // v_s = rk_s . u / ||u||   (rk = R_i + d_old x_i, ksvd.py:30-31)
+        const float* Ri = R + sg[s];
+        const float xo = xs[s];
+        double dot = 0.0;
+        for (int f = tid; f < n; f += 256) dot += (double)fmaf(dold[f], xo, Ri[f]) * (double)uold[f];
+        const double tot = block_sum_d(dot, pr, red);
+        if (tid == 0) vs[s] = (float)(tot * inv);
+    }
+    __syncthreads();
+    for (int f = tid; f < n; f += 256) {  // u_new += sum_s v_s rk_s
+        const float d = dold[f];
+        float acc = 0.f;
+        for (int s = 0; s < cnt; ++s) acc = fmaf(vs[s], fmaf(d, xs[s], R[sg[s] + f]), acc);
+        atomicAdd(unew + f, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void ksvd_mf_norm_kernel(int atom, int n, const float* __restrict__ D, int ldd,
+                                                           const float* __restrict__ unew, const float* __restrict__ uold,
+                                                           const double* __restrict__ s2old, double* __restrict__ s2new) {
+    __shared__ double pr[256], red[16];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int f = threadIdx.x; f < n; f += 256) {
+        const double un = (double)unew[f];
+        a += un * un;
+        b += un * (double)D[(int64_t)atom * ldd + f];
+        c += un * (double)uold[f];
+    }
+    a = block_sum_d(a, pr, red);
+    b = block_sum_d(b, pr, red);
+    c = block_sum_d(c, pr, red);
+    if (threadIdx.x == 0) {
+        const double den = a * s2old[0];
+        s2new[0] = a;
+        s2new[1] = b;
+        s2new[2] = (den > 0.0) ? fmax(0.0, 1.0 - (c * c) / den) : 0.0;
+    }
+}
+
 size_t ksvd_exact_work_doubles(int n) {
     if (n <= 64) return (size_t)G64_MAX_PARTS * 4096 / 2;  // fp32 partial Gram matrices of ksvd_gram64_kernel
     if (n <= 256) return (size_t)n * n;
-    return 8 + (size_t)TALL_MAX * TALL_MAX + TALL_MAX / 2 + ((size_t)n + 1) / 2 + 8;
+    // s2 (8) | M | v | u_raw (n floats) | second iterate of the matrix-free path (n floats) | its second s2 (8)
+    return 8 + (size_t)TALL_MAX * TALL_MAX + TALL_MAX / 2 + ((size_t)n + 1) / 2 + 8 + ((size_t)n + 1) / 2 + 8;
 }
 
 static int ksvd_exact_sweep_tall(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
                                  float* coef, double* work, float* D, float* Dnext, int64_t max_support,
                                  hipStream_t stream) {
-    if (max_support > TALL_MAX) {
-        set_error("exact ksvd with n = %d > 256 features needs every atom to be used by <= %d signals (largest: %lld)", n,
-                  TALL_MAX, (long long)max_support);
-        return LYS_ENOSUP;
-    }
     if (max_support <= 0) return LYS_OK;
     const int ldd = padded_features(n);
     static bool attr_set[64] = {};
@@ -1897,17 +1982,56 @@ static int ksvd_exact_sweep_tall(float* R, int64_t ldr, int n, int K, int k, con
     double* M = work + 8;
     float* v = reinterpret_cast<float*>(M + (size_t)TALL_MAX * TALL_MAX);
     float* uraw = v + TALL_MAX;
-    const int mb = (int)((max_support + 63) / 64);
+    float* ub = uraw + 2 * (((size_t)n + 1) / 2) + 16;  // second iterate (after 8 spare doubles behind u_raw)
+    double* s2b = reinterpret_cast<double*>(ub + 2 * (((size_t)n + 1) / 2));
+    // atoms used by more than TALL_MAX signals take the matrix-free path: the host needs every atom's support size
+    std::vector<int32_t> rp;
+    if (max_support > TALL_MAX) {
+        rp.resize((size_t)K + 1);
+        LYS_CHECK_HIP(hipMemcpyAsync(rp.data(), row_ptr, ((size_t)K + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        LYS_CHECK_HIP(hipStreamSynchronize(stream));
+    }
+    const int64_t small_support = (max_support < TALL_MAX) ? max_support : TALL_MAX;
+    const int mb = (int)((small_support + 63) / 64);
     const unsigned fchunks = (unsigned)((n + TALL_FCH - 1) / TALL_FCH);
     for (int a = 0; a < K; ++a) {
-        LYS_CHECK_HIP(hipMemsetAsync(work, 0, (8 + (size_t)max_support * max_support) * sizeof(double), stream));
+        const int64_t ma = rp.empty() ? small_support : (int64_t)(rp[a + 1] - rp[a]);
+        if (ma <= 0 && !rp.empty()) continue;  // unused atom: keeps its column (ksvd_commit), nothing to apply
+        if (ma > TALL_MAX) {
+            // ---- matrix-free power iteration (see ksvd_mf_iter_kernel)
+            float *uo = uraw, *un = ub;
+            double *so = s2, *sn = s2b;
+            hipLaunchKernelGGL(ksvd_mf_init_kernel, dim3(1), dim3(256), 0, stream, a, n, D, ldd, uo, so);
+            const unsigned grid = (unsigned)((ma + MF_SPW - 1) / MF_SPW);
+            constexpr int MAX_IT = 400, POLL = 4;
+            for (int it = 0; it < MAX_IT; ++it) {
+                LYS_CHECK_HIP(hipMemsetAsync(un, 0, (size_t)n * sizeof(float), stream));
+                hipLaunchKernelGGL(ksvd_mf_iter_kernel, dim3(grid), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef,
+                                   D, ldd, uo, so, un);
+                hipLaunchKernelGGL(ksvd_mf_norm_kernel, dim3(1), dim3(256), 0, stream, a, n, D, ldd, un, uo, so, sn);
+                std::swap(uo, un);
+                std::swap(so, sn);
+                if ((it + 1) % POLL == 0) {
+                    double h[3];
+                    LYS_CHECK_HIP(hipMemcpyAsync(h, so, sizeof(h), hipMemcpyDeviceToHost, stream));
+                    LYS_CHECK_HIP(hipStreamSynchronize(stream));
+                    // successive iterates within 1e-6 rad (sin^2 < 1e-12), or a zero restricted residual
+                    if (!(h[2] > 1e-12) || !(h[0] > 0.0)) break;
+                }
+            }
+            hipLaunchKernelGGL(ksvd_tall_apply_kernel, dim3((unsigned)ma), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry,
+                               coef, D, ldd, uo, so, Dnext);
+            LYS_LAUNCH_CHECK();
+            continue;
+        }
+        LYS_CHECK_HIP(hipMemsetAsync(work, 0, (8 + (size_t)small_support * small_support) * sizeof(double), stream));
         hipLaunchKernelGGL(ksvd_gram_t_kernel, dim3(fchunks, mb == 1 ? 1 : 10), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
                            entry, coef, D, ldd, M);
         hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, a, n, row_ptr, M, D, ldd, Dnext, 0, entry,
                            coef, v);
         hipLaunchKernelGGL(ksvd_tall_u_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, R, ldr, n, k,
                            row_ptr, entry, coef, D, ldd, v, uraw, s2);
-        hipLaunchKernelGGL(ksvd_tall_apply_kernel, dim3((unsigned)max_support), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
+        hipLaunchKernelGGL(ksvd_tall_apply_kernel, dim3((unsigned)small_support), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
                            entry, coef, D, ldd, uraw, s2, Dnext);
         LYS_LAUNCH_CHECK();
     }

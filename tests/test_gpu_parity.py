@@ -410,19 +410,37 @@ def test_exact_ksvd_other_shapes(eng, n, K, k, N):
     assert np.max(np.abs(Zh - Zo)) < 5e-5 * np.abs(Zo).max()
 
 
-def test_exact_ksvd_tall_limit(eng):
-    """n > 256 with an atom used by more than 256 signals is outside both exact paths: loud error, no fallback."""
+@pytest.mark.parametrize("n,K,k,N", [(300, 4, 2, 600), (700, 12, 3, 2400), (1030, 6, 2, 1500), (300, 40, 3, 3000)])
+def test_exact_ksvd_wide_signals_large_supports(eng, n, K, k, N):
+    """n > 256 AND atoms used by more than 256 signals (ksvd.py:19-43): neither Gram matrix is small -- the matrix-free
+    power iteration on Rk Rk' (round 3; `LYS_ENOSUP` before).  Atoms with <= 256 users in the same dictionary still take
+    the column-Gram path ((300, 40, 3, 3000): both paths inside one sweep).  Against the float64 oracle's exact SVD."""
+    from oracle import lyssa_oracle as orc
     from lyssandra_amd.dict_learning.ksvd import ksvd
-    from lyssandra_amd import _lib
-    rs = np.random.RandomState(5)
-    n, K, N = 300, 4, 600
-    D = rs.randn(n, K)
-    D /= np.linalg.norm(D, axis=0)
-    Z = np.zeros((K, N))
-    Z[0, :] = rs.randn(N)
-    Z[1, ::2] = rs.randn(N // 2)
-    with pytest.raises(_lib.LyssaHipError):
-        ksvd(rs.randn(n, N), D, Z, verbose=False)
+    rs = np.random.RandomState(n + K)
+    Dt = rs.randn(n, K)
+    Dt /= np.linalg.norm(Dt, axis=0)
+    X = np.zeros((n, N))
+    for i in range(N):
+        sel = rs.choice(K - 1, k, replace=False)          # atom K-1 never used by the codes below
+        X[:, i] = Dt[:, sel] @ (rs.randn(k) + np.sign(rs.randn(k)))
+    X += 0.05 * rs.randn(n, N)
+    X = X.astype(np.float32).astype(np.float64)
+    D0 = (Dt + 0.3 * rs.randn(n, K))
+    D0 = (D0 / np.linalg.norm(D0, axis=0)).astype(np.float32).astype(np.float64)
+    Z = orc.bomp_encode(X, D0, k)
+    Z[K - 1, :] = 0
+    users = (Z != 0).sum(axis=1)
+    assert users.max() > 256                               # the regime under test
+    Do, Zo, uo = orc.ksvd_exact(X, D0.copy(), Z.copy())
+    Dh, Zh = D0.copy(), Z.copy()
+    _, _, uh = ksvd(X, Dh, Zh, verbose=False)
+    assert list(uh) == list(uo) and (K - 1) in uh
+    assert np.array_equal(Dh[:, K - 1], D0[:, K - 1])
+    print("n=%d K=%d: users per atom %d..%d, atom err %.3g, code err %.3g"
+          % (n, K, users[:K - 1].min(), users.max(), _atom_err(Dh, Do), np.max(np.abs(Zh - Zo)) / np.abs(Zo).max()))
+    assert _atom_err(Dh, Do) < 5e-5, _atom_err(Dh, Do)
+    assert np.max(np.abs(Zh - Zo)) < 5e-5 * np.abs(Zo).max()
 
 
 def _lasso_problem(seed, n, K, N, active=6, noise=0.05):
