@@ -1139,7 +1139,7 @@ int exact_debug_stamps(unsigned long long* out16) {
 // signals, stages 64 restricted-residual rows at a time in LDS (next round's rows prefetched into registers) and
 // accumulates the 64 x 64 product with v_mfma_f32_32x32x2_f32 (one 32 x 32 quadrant per wave); the fp32 partial goes to
 // part[b][64][64] with plain stores and the eigen-solver sums the P partials in fp64 while it loads C.
-constexpr int G64_MAX_PARTS = 64;
+constexpr int G64_MAX_PARTS = 256;
 constexpr int G64_ROWS = 768;  // most signals one workgroup takes (descriptor staging area)
 
 __global__ __launch_bounds__(256) void ksvd_gram64_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n, int k,
@@ -1512,9 +1512,50 @@ __device__ bool ritz_tridiag(int m, const double (*H)[EIG_M], double beta, doubl
     return sqrt(r0 * r0 + tail * tail) <= tol * fabs(theta);
 }
 
+// C = sum of the P fp32 partial Gram matrices, in fp64, spread over 16 workgroups (one matrix element per thread): the
+// eigen-solver's single workgroup used to pull all P x 16 KB through one CU (8.7 us of its 24 at P = 32).
+__global__ __launch_bounds__(256) void ksvd_gram64_reduce_kernel(int atom, const int32_t* __restrict__ row_ptr,
+                                                                 const float* __restrict__ part, int parts,
+                                                                 double* __restrict__ C) {
+    if (row_ptr[atom] >= row_ptr[atom + 1]) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;  // 0 .. 4095
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int p = 0;
+    for (; p + 3 < parts; p += 4) {
+        a0 += (double)part[(int64_t)p * 4096 + e];
+        a1 += (double)part[(int64_t)(p + 1) * 4096 + e];
+        a2 += (double)part[(int64_t)(p + 2) * 4096 + e];
+        a3 += (double)part[(int64_t)(p + 3) * 4096 + e];
+    }
+    for (; p < parts; ++p) a0 += (double)part[(int64_t)p * 4096 + e];
+    C[e] = (a0 + a1) + (a2 + a3);
+}
+
+// Wave-wide sum of a double, every lane gets the result: four DPP row steps on the two halves, then the four row sums
+// through readlane.
+__device__ __forceinline__ double wave_sum_d(double x) {
+#define LYS_DSTEP(CTRL)                                                                            \
+    do {                                                                                           \
+        const int lo_ = dpp_i<CTRL>(__double2loint(x)), hi_ = dpp_i<CTRL>(__double2hiint(x));      \
+        x += __hiloint2double(hi_, lo_);                                                           \
+    } while (0)
+    LYS_DSTEP(0xB1);
+    LYS_DSTEP(0x4E);
+    LYS_DSTEP(0x124);
+    LYS_DSTEP(0x128);
+#undef LYS_DSTEP
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // n <= 64 with the partial Gram sums of ksvd_gram64_kernel: the same Lanczos / Rayleigh-Ritz recurrence on ONE wave
-// (lane = vector component).  The four-wave kernel above spends its time in ~15 workgroup barriers per step; here all
-// reductions are LDS broadcast reads inside a wave (no barrier at all): ~1.5 us per step instead of ~6.  The 256
+// (lane = vector component).  The four-wave kernel above spends its time in ~15 workgroup barriers per step; here the
+// matrix-vector product is a loop of LDS broadcast reads and the dot products / norms are DPP reductions inside the wave (no
+// barrier at all).  The 256
 // threads only share the load of C (sum of the fp32 partials in fp64), then waves 1..3 retire.
 constexpr int E64_QS = 65;  // row stride of the Krylov basis (doubles): lanes reading different rows hit different banks
 
@@ -1528,7 +1569,18 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
     if (row_ptr[atom] >= row_ptr[atom + 1]) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long ts0 = wall_clock64();
-    {
+    if (parts < 0) {
+        // C already summed in fp64 by ksvd_gram64_reduce_kernel (64 x 64 doubles behind the partials): 32 KB
+        const double2* C2 = reinterpret_cast<const double2*>(part);
+        double2 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = C2[tid + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            Cl[2 * (tid + 256 * q)] = v[q].x;
+            Cl[2 * (tid + 256 * q) + 1] = v[q].y;
+        }
+    } else {
         const float4* P = reinterpret_cast<const float4*>(part);
         double t[16];
 #pragma unroll
@@ -1559,20 +1611,7 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
     if (tid >= 64) return;
     const unsigned long long ts1 = wall_clock64();
     const double d0 = (lane < n) ? (double)D[(int64_t)atom * ldd + lane] : 0.0;
-    auto sumsq64 = [&](double x) {  // sum over the wave of x^2, computed by every lane from LDS
-        __builtin_amdgcn_wave_barrier();
-        wv[lane] = x;
-        __builtin_amdgcn_wave_barrier();
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // four chains: the loops are bound by the fp64 FMA latency
-#pragma unroll 4
-        for (int c = 0; c < 64; c += 4) {
-            t0 = fma(wv[c], wv[c], t0);
-            t1 = fma(wv[c + 1], wv[c + 1], t1);
-            t2 = fma(wv[c + 2], wv[c + 2], t2);
-            t3 = fma(wv[c + 3], wv[c + 3], t3);
-        }
-        return (t0 + t1) + (t2 + t3);
-    };
+    auto sumsq64 = [&](double x) { return wave_sum_d(x * x); };  // (round 2: a 64-step loop of LDS broadcast reads, ~0.45 us)
     {
         const double nrm2 = sumsq64(d0);
         Q[lane] = (nrm2 > 0.0) ? d0 / sqrt(nrm2) : (lane == 0 ? 1.0 : 0.0);
@@ -1596,6 +1635,20 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
         }
         // classical Gram-Schmidt, twice: lane i <= j takes the dot product q_i . w
         for (int round = 0; round < 2; ++round) {
+            if (j < 6) {
+                // few basis vectors (K-SVD's restricted residuals converge in ~4 steps): one DPP reduction per dot product
+                double hj[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) hj[i] = (i <= j) ? wave_sum_d(Q[i * E64_QS + lane] * w) : 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    if (i <= j) {
+                        if (lane == 0) H[i][j] = (round == 0) ? hj[i] : H[i][j] + hj[i];
+                        w = fma(-hj[i], Q[i * E64_QS + lane], w);
+                    }
+                }
+                continue;
+            }
             __builtin_amdgcn_wave_barrier();
             wv[lane] = w;
             __builtin_amdgcn_wave_barrier();
@@ -1639,12 +1692,7 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
     double u = 0.0;
     for (int j = 0; j < m; ++j) u = fma(cvec[j], Q[j * E64_QS + lane], u);
     const double un2 = sumsq64(u);
-    __builtin_amdgcn_wave_barrier();
-    wv[lane] = u * d0;
-    __builtin_amdgcn_wave_barrier();
-    double sg = 0.0;
-#pragma unroll 8
-    for (int c = 0; c < 64; ++c) sg += wv[c];
+    const double sg = wave_sum_d(u * d0);
     if (un2 > 0.0) u *= (sg < 0.0 ? -1.0 : 1.0) / sqrt(un2);
     else u = d0;
     if (lane < n) Dnext[(int64_t)atom * ldd + lane] = (float)u;
@@ -1958,7 +2006,7 @@ __global__ __launch_bounds__(256) void ksvd_mf_norm_kernel(int atom, int n, cons
 }
 
 size_t ksvd_exact_work_doubles(int n) {
-    if (n <= 64) return (size_t)G64_MAX_PARTS * 4096 / 2;  // fp32 partial Gram matrices of ksvd_gram64_kernel
+    if (n <= 64) return (size_t)G64_MAX_PARTS * 4096 / 2 + 4096;  // fp32 partial Gram matrices of ksvd_gram64_kernel + their fp64 sum
     if (n <= 256) return (size_t)n * n;
     // s2 (8) | M | v | u_raw (n floats) | second iterate of the matrix-free path (n floats) | its second s2 (8)
     return 8 + (size_t)TALL_MAX * TALL_MAX + TALL_MAX / 2 + ((size_t)n + 1) / 2 + 8 + ((size_t)n + 1) / 2 + 8;
@@ -2058,7 +2106,12 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     const int nb = (n + 63) / 64;
     const unsigned gx = (unsigned)std::max<int64_t>(1, (max_support + GRAM_SPB - 1) / GRAM_SPB);
     // n <= 64: MFMA Gram kernel with per-workgroup partial sums (no memset, no atomics); slices of <= 320 signals
-    int parts = (int)std::min<int64_t>(G64_MAX_PARTS, std::max<int64_t>(1, (max_support + 319) / 320));
+    static int slice = 0;  // signals per Gram workgroup (LYS_EXACT_SLICE; measured at configs[1]: 64 -> 49.9 ms per sweep, 128 -> 44.6, 192 -> 44.4, 320 -> 47.7)
+    if (!slice) {
+        const char* e = getenv("LYS_EXACT_SLICE");
+        slice = (e && atoi(e) >= 64) ? atoi(e) : 192;
+    }
+    int parts = (int)std::min<int64_t>(G64_MAX_PARTS, std::max<int64_t>(1, (max_support + slice - 1) / slice));
     if ((max_support + parts - 1) / parts + 63 > G64_ROWS) parts = 0;  // an atom used by > 45k signals: atomics path
     if (n > 64) parts = 0;
     for (int a = 0; a < K; ++a) {
@@ -2070,9 +2123,13 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
             hipLaunchKernelGGL(ksvd_gram_kernel, dim3(gx, nb * (nb + 1) / 2), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr,
                                entry, coef, D, ldd, work);
         }
-        if (parts > 0)
+        if (parts > 0) {
+            double* Csum = work + (size_t)G64_MAX_PARTS * 4096 / 2;
+            hipLaunchKernelGGL(ksvd_gram64_reduce_kernel, dim3(16), dim3(256), 0, stream, a, row_ptr,
+                               reinterpret_cast<const float*>(work), parts, Csum);
             hipLaunchKernelGGL(ksvd_eig64_kernel, dim3(1), dim3(256), 0, stream, a, n, row_ptr,
-                               reinterpret_cast<const float*>(work), parts, D, ldd, Dnext);
+                               reinterpret_cast<const float*>(Csum), -1, D, ldd, Dnext);
+        }
         else
             hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, a, n, row_ptr, work, D, ldd, Dnext,
                                c_in_lds);
