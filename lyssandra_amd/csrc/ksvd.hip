@@ -1466,30 +1466,72 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
 // converged just fails the test.  Every lane computes the same scalars; O(m) per Newton step.  Returns true when the
 // Ritz pair's residual sqrt(r_0^2 + (beta s_m)^2) <= tol * theta, with the normalised s in cvec.
 __device__ bool ritz_tridiag(int m, const double (*H)[EIG_M], double beta, double* cvec, double tol, int lane) {
-    double sc = 0.0;
-    for (int i = 0; i < m; ++i) {
-        double row = fabs(H[i][i]);
-        if (i > 0) row += fabs(H[i - 1][i]);
-        if (i < m - 1) row += fabs(H[i][i + 1]);
-        sc = fmax(sc, row);
-    }
-    if (!(sc > 0.0)) return false;
-    const double isc = 1.0 / sc;
-    double x = 1.0;  // scaled Gershgorin bound
-    for (int it = 0; it < 48; ++it) {
-        double p0 = 1.0, d0 = 0.0, p1 = H[0][0] * isc - x, d1 = -1.0;
-        for (int i = 1; i < m; ++i) {
-            const double a = H[i][i] * isc - x, b = H[i - 1][i] * isc, b2 = b * b;
-            const double p2 = a * p1 - b2 * p0, d2 = a * d1 - p1 - b2 * d0;
-            p0 = p1;
-            d0 = d1;
-            p1 = p2;
-            d1 = d2;
+    double sc = 0.0, x = 1.0;  // x: largest eigenvalue of the scaled matrix, Newton from the (scaled) Gershgorin bound
+    constexpr int RM = 6;      // K-SVD's restricted residuals stop at m = 3 .. 5
+    if (m <= RM) {
+        // small m: the tridiagonal goes to REGISTERS first (one batch of LDS broadcast reads) -- the Newton iteration of the
+        // general branch re-reads H from LDS inside its inner loop (two dependent round trips per row and iteration: ~2 us
+        // per call at m = 4).  (All EIG_M = 24 rows in registers with guarded steps was slower than the LDS loop.)
+        double da[RM], db[RM];  // diagonal, sub-diagonal (db[i] = H[i-1][i])
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            da[i] = (i < m) ? H[i][i] : 0.0;
+            db[i] = (i >= 1 && i < m) ? H[i - 1][i] : 0.0;
         }
-        if (d1 == 0.0) break;
-        const double dx = p1 / d1;
-        x -= dx;
-        if (fabs(dx) <= 4e-16) break;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            double row = fabs(da[i]) + fabs(db[i]);          // rows >= m are all zero
+            if (i + 1 < RM) row += fabs(db[i + 1]);
+            sc = fmax(sc, row);
+        }
+        if (!(sc > 0.0)) return false;
+        const double isc = 1.0 / sc;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            da[i] *= isc;
+            db[i] = (db[i] * isc) * (db[i] * isc);  // b^2 of the scaled matrix
+        }
+        for (int it = 0; it < 48; ++it) {
+            double p0 = 1.0, d0 = 0.0, p1 = da[0] - x, d1 = -1.0;
+#pragma unroll
+            for (int i = 1; i < RM; ++i) {
+                const double a = da[i] - x, b2 = db[i];
+                const double p2 = a * p1 - b2 * p0, d2 = a * d1 - p1 - b2 * d0;
+                const bool on = i < m;  // uniform: selects, no branches
+                p0 = on ? p1 : p0;
+                d0 = on ? d1 : d0;
+                p1 = on ? p2 : p1;
+                d1 = on ? d2 : d1;
+            }
+            if (d1 == 0.0) break;
+            const double dx = p1 / d1;
+            x -= dx;
+            if (fabs(dx) <= 4e-16) break;
+        }
+    } else {
+        for (int i = 0; i < m; ++i) {
+            double row = fabs(H[i][i]);
+            if (i > 0) row += fabs(H[i - 1][i]);
+            if (i < m - 1) row += fabs(H[i][i + 1]);
+            sc = fmax(sc, row);
+        }
+        if (!(sc > 0.0)) return false;
+        const double isc = 1.0 / sc;
+        for (int it = 0; it < 48; ++it) {
+            double p0 = 1.0, d0 = 0.0, p1 = H[0][0] * isc - x, d1 = -1.0;
+            for (int i = 1; i < m; ++i) {
+                const double a = H[i][i] * isc - x, b = H[i - 1][i] * isc, b2 = b * b;
+                const double p2 = a * p1 - b2 * p0, d2 = a * d1 - p1 - b2 * d0;
+                p0 = p1;
+                d0 = d1;
+                p1 = p2;
+                d1 = d2;
+            }
+            if (d1 == 0.0) break;
+            const double dx = p1 / d1;
+            x -= dx;
+            if (fabs(dx) <= 4e-16) break;
+        }
     }
     const double theta = x * sc;
     // backward recurrence, s_{m-1} = 1
