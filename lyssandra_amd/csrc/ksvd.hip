@@ -1561,16 +1561,17 @@ __global__ __launch_bounds__(256) void ksvd_gram64_reduce_kernel(int atom, const
                                                                  double* __restrict__ C) {
     if (row_ptr[atom] >= row_ptr[atom + 1]) return;
     const int e = blockIdx.x * 256 + threadIdx.x;  // 0 .. 4095
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int p = 0;
-    for (; p + 3 < parts; p += 4) {
-        a0 += (double)part[(int64_t)p * 4096 + e];
-        a1 += (double)part[(int64_t)(p + 1) * 4096 + e];
-        a2 += (double)part[(int64_t)(p + 2) * 4096 + e];
-        a3 += (double)part[(int64_t)(p + 3) * 4096 + e];
+    // 16 loads in flight per thread (clamped partial index, masked add): the loop is a chain of dependent HBM/L2 round
+    // trips otherwise (4 in flight: 8 us per launch at 54 partials)
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < parts; p0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = part[(int64_t)min(p0 + u, parts - 1) * 4096 + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u & 3] += (p0 + u < parts) ? (double)v[u] : 0.0;
     }
-    for (; p < parts; ++p) a0 += (double)part[(int64_t)p * 4096 + e];
-    C[e] = (a0 + a1) + (a2 + a3);
+    C[e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 // Wave-wide sum of a double, every lane gets the result: four DPP row steps on the two halves, then the four row sums
@@ -2148,10 +2149,10 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     const int nb = (n + 63) / 64;
     const unsigned gx = (unsigned)std::max<int64_t>(1, (max_support + GRAM_SPB - 1) / GRAM_SPB);
     // n <= 64: MFMA Gram kernel with per-workgroup partial sums (no memset, no atomics); slices of <= 320 signals
-    static int slice = 0;  // signals per Gram workgroup (LYS_EXACT_SLICE; measured at configs[1]: 64 -> 49.9 ms per sweep, 128 -> 44.6, 192 -> 44.4, 320 -> 47.7)
+    static int slice = 0;  // signals per Gram workgroup (LYS_EXACT_SLICE; measured at configs[1] with the 16-deep reduce kernel: 96 / 128 / 160 / 192 / 256 -> 37.9 / 36.6 / 37.6 / 37.8 / 39.4 ms per sweep)
     if (!slice) {
         const char* e = getenv("LYS_EXACT_SLICE");
-        slice = (e && atoi(e) >= 64) ? atoi(e) : 192;
+        slice = (e && atoi(e) >= 64) ? atoi(e) : 128;
     }
     int parts = (int)std::min<int64_t>(G64_MAX_PARTS, std::max<int64_t>(1, (max_support + slice - 1) / slice));
     if ((max_support + parts - 1) / parts + 63 > G64_ROWS) parts = 0;  // an atom used by > 45k signals: atomics path
