@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "common.h"
 #include "../../include/lyssa_hip.h"
 
@@ -841,11 +843,14 @@ int lys_ctx_ksvd_sweep(lys_ctx* c, int* n_unused_host) {
                                  (size_t)stride, NCCL_FLOAT64));
     }
     // counts travel inside the (reduced) slabs: slab cb, atom t: [sum x R (n) | sum x^2 | count] at t * (n + 2)
-    double* hstats = static_cast<double*>(malloc(c->dev[0].stats_bytes));
-    if (!hstats) {
+    std::vector<double> hstats_v;  // released on every return path
+    try {
+        hstats_v.resize(c->dev[0].stats_bytes / sizeof(double) + 1);
+    } catch (...) {
         set_error("ctx_ksvd_sweep: out of host memory");
         return LYS_EINVAL;
     }
+    double* hstats = hstats_v.data();
     for (int i = 0; i < c->nd; ++i) {
         lys_dev* d = &c->dev[i];
         CTX_HIP(hipSetDevice(d->device));
@@ -858,16 +863,12 @@ int lys_ctx_ksvd_sweep(lys_ctx* c, int* n_unused_host) {
         d->gram_valid = false;
     }
     const int rcs = ctx_sync_all(c);
-    if (rcs) {
-        free(hstats);
-        return rcs;
-    }
+    if (rcs) return rcs;
     c->n_unused = 0;
     for (int a = 0; a < c->K; ++a) {
         const double cnt = hstats[(size_t)(a / B) * stride + (size_t)(a % B) * (c->n + 2) + c->n + 1];
         if (cnt < 0.5) c->unused[c->n_unused++] = a;
     }
-    free(hstats);
     float b = 0.f;
     CTX_HIP(hipSetDevice(c->dev[0].device));
     CTX_HIP(hipEventElapsedTime(&b, c->dev[0].ev[1], c->dev[0].ev[2]));
@@ -891,7 +892,14 @@ int lys_ctx_get_unused(const lys_ctx* c, int32_t* atoms_host, int cap) {
 static int ctx_sym_block(int Kp) { return Kp >= 1024 ? 1024 : Kp; }  // Kp is a multiple of 64
 
 static int dev_reserve_odl(lys_ctx* c, lys_dev* d) {
-    if (d->A) return LYS_OK;
+    if (d->A && d->dA && d->pk && d->B && d->scratch) return LYS_OK;
+    // a failed allocation of an earlier call leaves a partial set: start over
+    dfree(d->A);
+    dfree(d->dA);
+    dfree(d->pk);
+    dfree(d->B);
+    dfree(d->scratch);
+    d->dB = nullptr;
     const size_t kk = (size_t)c->Kp * c->Kp, kn = (size_t)c->Kp * c->ldd;
     CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->A), kk * sizeof(float)));
     // exchange buffer pk = [block-upper triangle of dA | dB]: dB LIVES in its tail (lys_odl_increments writes it there),
