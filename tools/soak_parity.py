@@ -10,6 +10,8 @@ from oracle import c_oracle
 
 n, K, k, N = 64, 1024, 10, 1 << 18
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if len(sys.argv) > 3:   # other templates of the greedy kernel: soak_parity.py <seeds> <K> <k>
+    K, k = int(sys.argv[2]), int(sys.argv[3])
 tot = ties = tie_diff = bad = 0
 worst = 0.0
 for seed in range(seeds):
