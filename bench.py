@@ -48,6 +48,31 @@ def flops_per_signal(n, K, k):
     return 2 * n * K, K * k * (k + 1) + k ** 3
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: re-run this same command line under torch.distributed.run, one rank
+    per GPU on this node (rendezvous on 127.0.0.1, a free port).  Rank 0 prints the one JSON line; the launcher's exit
+    code is ours.  Fails before launching anything when the node cannot hold the ranks."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
+    backend = os.environ.get("LYS_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and n_dev < n_ranks:
+        raise SystemExit("--gpus %d needs %d HIP devices, %d visible (LYS_BENCH_BACKEND=gloo lets the ranks share a device "
+                         "to smoke-test the N > 1 path)" % (n_ranks, n_ranks, n_dev))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +87,11 @@ def main():
                     help="processes for the all-cores CPU baseline (-1 = min(host cpus, 64), 0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: start the N ranks ourselves, like the reference's parallel path spawns its
+        # own workers inside one call (lyssa/utils/__init__.py:92-129, sparse_coding.py:713-724)
+        raise SystemExit(self_launch(args.gpus))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -70,10 +100,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if args.gpus != world and distributed:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and not distributed:
-        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
     n_dev = torch.cuda.device_count()
     if n_dev < 1:
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")

@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace lys {
@@ -124,10 +126,15 @@ int64_t tile_signals(int Kp) {
     } else {
         // never more than a sixteenth of the device memory per tile (18 GB on a 288 GB MI355X: no effect there; on a
         // smaller or busier device the 4 GiB default would otherwise pin a large share of it per stream)
-        static int64_t cap = -1;
-        if (cap < 0) {
+        // cached per device id (the multi-device context calls this with each of its devices current in turn)
+        static std::atomic<int64_t> caps[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        int64_t cap = caps[dev].load(std::memory_order_relaxed);
+        if (cap <= 0) {
             size_t fr = 0, tot = 0;
             cap = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) ? (int64_t)(tot / 16) : (4ll << 30);
+            caps[dev].store(cap, std::memory_order_relaxed);
         }
         if (bytes > cap) bytes = cap;
     }
@@ -139,9 +146,10 @@ int64_t tile_signals(int Kp) {
 // alpha0 = X D: signal-tile-stationary kernel for n <= 64, generic NT GEMM otherwise
 // `split_scratch` (alpha0_bf16x3_scratch_bytes, or null): room for the dictionary's three bf16 planes -- with it the
 // n <= 64 product runs on the bf16 matrix cores at fp32 accuracy (gemm.hip, "bf16x3"); LYS_ALPHA0_BF16X3=0 disables it.
-static int g_alpha0_override = -1;  // lys_set_alpha0_bf16x3: -1 = follow the environment
+static std::atomic<int> g_alpha0_override{-1};  // lys_set_alpha0_bf16x3: -1 = follow the environment
 static bool alpha0_bf16x3_enabled() {
-    if (g_alpha0_override >= 0) return g_alpha0_override == 1;
+    const int ov = g_alpha0_override.load(std::memory_order_relaxed);
+    if (ov >= 0) return ov == 1;
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("LYS_ALPHA0_BF16X3");

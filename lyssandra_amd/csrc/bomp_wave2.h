@@ -209,7 +209,7 @@ __device__ __forceinline__ f32x4 lds_chunk(unsigned addr, int i, int c) {
 // operations are not unrolled, which would push the state to scratch).
 template <int R, int KMAX, int NLDS, int NV, int J, bool FAST, bool STAMP = false>
 __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* __restrict__ G, int k, int lane,
-                                      f32x4* __restrict__ lds /* [NLDS][C][64] of this wave */,
+                                      f32x4* lds /* [NLDS][C][64] of this wave; also read through s.laneoff: no restrict */,
                                       float* __restrict__ sc /* scalar area of this wave */, int unit_diag_rt) {
     using L = Lay<R>;
     using S = State<R, KMAX, NLDS, NV>;
@@ -384,7 +384,7 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
 // One signal on one wave: `s.a` holds its alpha0 row; greedy steps, back-substitution, outputs.
 template <int R, int KMAX, int NLDS, int NV, bool FAST, bool STAMP>
 __device__ __forceinline__ void run_signal(State<R, KMAX, NLDS, NV>& s, const float* __restrict__ G, int64_t sig, int k,
-                                           int lane, f32x4* __restrict__ lds_wave, float* __restrict__ sc,
+                                           int lane, f32x4* lds_wave, float* __restrict__ sc,
                                            int32_t* __restrict__ idx_out, float* __restrict__ coef_out,
                                            int32_t* __restrict__ nnz_out, int unit_diag) {
     using L = Lay<R>;

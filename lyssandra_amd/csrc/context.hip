@@ -810,10 +810,17 @@ int lys_ctx_ksvd_sweep(lys_ctx* c, int* n_unused_host) {
         CTX_HIP(hipSetDevice(d->device));
         CTX_RC(dev_reserve_sweep(c, d, B));
         if (i == 0) CTX_HIP(hipEventRecord(d->ev[1], d->stream));
-        CTX_RC(lys_residual(d->Xs, c->n, d->D, c->n, c->K, k, d->Ns, d->r_idx, d->r_coef, d->r_nnz, d->R, c->ldd, nullptr,
-                            d->stream));
-        CTX_RC(lys_bksvd_index(d->r_idx, d->r_coef, d->r_nnz, c->K, k, d->Ns, B, d->row_ptr, d->erec, d->cg_ptr, d->cg_entry,
-                               d->sweep_ws, d->sweep_ws_bytes, d->stream));
+        if (d->Ns > 0) {
+            CTX_RC(lys_residual(d->Xs, c->n, d->D, c->n, c->K, k, d->Ns, d->r_idx, d->r_coef, d->r_nnz, d->R, c->ldd, nullptr,
+                                d->stream));
+            CTX_RC(lys_bksvd_index(d->r_idx, d->r_coef, d->r_nnz, c->K, k, d->Ns, B, d->row_ptr, d->erec, d->cg_ptr,
+                                   d->cg_entry, d->sweep_ws, d->sweep_ws_bytes, d->stream));
+        } else {
+            // empty shard (fewer resident signals than devices): an empty index -- the step launches walk nothing, the zeroed
+            // slabs still join every all-reduce and the replicated narrow steps keep this device's dictionary in step
+            CTX_HIP(hipMemsetAsync(d->row_ptr, 0, (size_t)(c->K + 1) * sizeof(int32_t), d->stream));
+            CTX_HIP(hipMemsetAsync(d->cg_ptr, 0, ((size_t)nb * ((size_t)1 << B) + 1) * sizeof(int32_t), d->stream));
+        }
         CTX_HIP(hipMemsetAsync(d->stats, 0, d->stats_bytes, d->stream));
     }
     // one device, no collective between the half steps: the fused launches (one per block, lys_bksvd_step mode 2)
@@ -953,12 +960,17 @@ int lys_ctx_odl_accumulate(lys_ctx* c, const float* X_sig_major_host, int64_t Nb
         if (d->c_cap < d->Ns * k) {
             dfree(d->c_row_ptr);
             dfree(d->c_entry);
-            dfree(d->csr_ws);
             CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->c_row_ptr), (size_t)(c->K + 1) * sizeof(int32_t)));
             CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->c_entry), (size_t)d->Ns * k * sizeof(int32_t)));
-            d->csr_ws_bytes = lys_csr_workspace_bytes(c->K, k, d->Ns);
-            CTX_HIP(hipMalloc(&d->csr_ws, d->csr_ws_bytes ? d->csr_ws_bytes : 16));
             d->c_cap = d->Ns * k;
+        }
+        // the sort's workspace depends on the signal count (chunks of 64), not on Ns * k: sized on its own
+        const size_t csr_need = lys_csr_workspace_bytes(c->K, k, d->Ns);
+        if (!d->csr_ws || csr_need > d->csr_ws_bytes) {
+            dfree(d->csr_ws);
+            d->csr_ws_bytes = 0;
+            CTX_HIP(hipMalloc(&d->csr_ws, csr_need ? csr_need : 16));
+            d->csr_ws_bytes = csr_need;
         }
         CTX_RC(lys_csr_by_atom(d->r_idx, d->r_coef, d->r_nnz, c->K, k, d->Ns, d->c_row_ptr, d->c_entry, d->csr_ws,
                                d->csr_ws_bytes, d->stream));

@@ -1407,8 +1407,9 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
     }
     struct Key {
         void *R, *row_ptr, *erec, *cg_ptr, *cg_entry, *idx, *coef, *D, *Dnext, *bbuf;
-        int64_t ldr;
+        int64_t ldr, N;      // N fixes bksvd_finish's grid and argument
         int n, K, k, B;
+        int lazy, fused;     // the schedule is baked into the captured kernel arguments and launch order
     };
     struct Cache {
         bool warmed = false, valid = false;
@@ -1426,7 +1427,12 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
             LYS_CHECK_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
             LYS_CHECK_HIP(hipEventCreateWithFlags(&c.ev_out, hipEventDisableTiming));
         }
-        const Key key{R, row_ptr, erec, cg_ptr, cg_entry, (void*)idx, coef, D, Dnext, bbuf, ldr, n, K, k, B};
+        Key key;
+        memset(&key, 0, sizeof(Key));      // padding bytes take part in the memcmp below
+        key.R = R; key.row_ptr = row_ptr; key.erec = erec; key.cg_ptr = cg_ptr; key.cg_entry = cg_entry;
+        key.idx = (void*)idx; key.coef = coef; key.D = D; key.Dnext = Dnext; key.bbuf = bbuf;
+        key.ldr = ldr; key.N = N; key.n = n; key.K = K; key.k = k; key.B = B;
+        key.lazy = bksvd_lazy(k, K) ? 1 : 0; key.fused = bksvd_fused(k, K) ? 1 : 0;
         if (!(c.valid && memcmp(&c.key, &key, sizeof(Key)) == 0)) {
             if (c.exec) (void)hipGraphExecDestroy(c.exec);
             c.exec = nullptr;
@@ -1443,8 +1449,7 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
             const hipError_t e3 = hipGraphInstantiate(&c.exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             LYS_CHECK_HIP(e3);
-            memset(&c.key, 0, sizeof(Key));
-            c.key = key;
+            memcpy(&c.key, &key, sizeof(Key));
             c.valid = true;
         }
         LYS_CHECK_HIP(hipEventRecord(c.ev_in, stream));

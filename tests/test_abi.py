@@ -204,3 +204,21 @@ def test_headline_kernels_have_no_scratch(lib):
         assert hit, "kernel %s not found in the build" % h
         for k in hit:
             assert k["scratch"] == 0 and k["spill"] == 0, (k["name"], k["vgpr"], k["spill"], k["scratch"])
+
+
+def test_bench_bare_multi_gpu_command_needs_only_a_device():
+    """`python bench.py --gpus 2` (no launcher) must start its own ranks; on a box without a GPU the ONLY complaint is
+    the missing device -- not argument handling (lyssa/utils/__init__.py:92-129: one call spawns its workers)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_self_launch_two_ranks_gloo")
+    env = dict(os.environ)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs a HIP device" in r.stderr, r.stderr[-2000:]
+    assert "torch.distributed.run" not in r.stderr

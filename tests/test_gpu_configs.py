@@ -525,3 +525,27 @@ def test_lc_ksvd_classifier_end_to_end(eng):
         scores.append((lc.best_score, tuple(sorted(lc.best_param_set.items()))))
     assert scores[0] == scores[1]
     assert scores[0][0] > 0.7, scores
+
+
+# ------------------------------------------------------------------------------------------------ bench launch
+def test_bench_self_launch_two_ranks_gloo():
+    """The bare `python bench.py --gpus 2` starts its two ranks itself (gloo lets them share this box's one GPU) and rank 0
+    prints one line with n_gpus = 2 and both exchange legs (lyssa/utils/__init__.py:92-129: one call spawns its workers)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LYS_BENCH_BACKEND="gloo")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--patches-per-gpu", str(1 << 17)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
+    assert "exchange" in line["ksvd_iteration"]["ms"], line["ksvd_iteration"]
+    assert "exchange" in line["odl_batch"]["ms"], line["odl_batch"]
