@@ -202,6 +202,18 @@ int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k,
                          double* work, size_t work_bytes, float* D_packed, float* D_next,
                          int64_t max_support, void* stream);
 /*
+ * Non-negative K-SVD cycle, lyssa/dict_learning/ksvd.py:46-95 (`nn_ksvd`; ksvd_dict_learn(non_neg=True, approx=False),
+ * :187-188, which passes the ITERATION INDEX as n_cycles): per atom the rank-1 solve of the exact update, then
+ * d = max(u, 0), x = max(Rk'u, 0); the atom is skipped when d'd or x'x <= eps (:79-82); n_cycles alternating projections
+ * d = max(Rk x / x'x, 0), x = max(Rk'd / d'd, 0) (:84-88); d /= ||d||, x *= ||d|| (:90-93); R[:, omega] = Rk - d x'.
+ * The sign of u is u . d_old >= 0 (the reference's randomized_svd(flip_sign=False) leaves it to chance -- with it the
+ * clip).  n <= 256.  work: lys_ksvd_exact_workspace_bytes(n); xbuf: max_support floats (the x iterates of one atom).
+ */
+int lys_nn_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k,
+                      const int32_t* row_ptr, const int32_t* entry, float* coef,
+                      double* work, size_t work_bytes, float* xbuf, float* D_packed, float* D_next,
+                      int64_t max_support, int n_cycles, void* stream);
+/*
  * The same update per atom for signal SHARDS (n <= 256; one process per GPU): lys_ksvd_exact_gram writes this shard's
  * Rk Rk' into the fp64 n x n buffer C (zeroed inside); the caller all-reduces C over the ranks (the exchange step the
  * exact update needs: the Gram matrix IS the sufficient statistic); lys_ksvd_exact_update runs the eigen-solve on the

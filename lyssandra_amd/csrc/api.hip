@@ -66,7 +66,7 @@ int ksvd_atom_apply(int, float*, int64_t, int, int, const int32_t*, const int32_
                     const float*, float*, hipStream_t);
 int ksvd_commit(int, int, const int32_t*, const float*, float*, hipStream_t);
 int ksvd_exact_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
-                     int64_t, hipStream_t);
+                     int64_t, hipStream_t, int nn_cycles, float* xbuf);
 size_t ksvd_exact_work_doubles(int);
 int ksvd_exact_gram(int, const float*, int64_t, int, int, const int32_t*, const int32_t*, const float*, const float*, double*,
                     int64_t, hipStream_t);
@@ -657,7 +657,19 @@ int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32
     LYS_REQUIRE(R && row_ptr && entry && coef && work && D_packed && D_next && (ldr % 4) == 0 && max_support >= 0,
                 "ksvd_exact_sweep: bad arguments");
     LYS_REQUIRE(work_bytes >= ksvd_exact_work_doubles(n) * sizeof(double), "ksvd_exact_sweep: work buffer too small");
-    return ksvd_exact_sweep(R, ldr, n, K, k, row_ptr, entry, coef, work, D_packed, D_next, max_support, STREAM(stream));
+    return ksvd_exact_sweep(R, ldr, n, K, k, row_ptr, entry, coef, work, D_packed, D_next, max_support, STREAM(stream), -1,
+                            nullptr);
+}
+
+int lys_nn_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
+                      float* coef, double* work, size_t work_bytes, float* xbuf, float* D_packed, float* D_next,
+                      int64_t max_support, int n_cycles, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && coef && work && xbuf && D_packed && D_next && (ldr % 4) == 0 && max_support >= 0 &&
+                    n_cycles >= 0,
+                "nn_ksvd_sweep: bad arguments");
+    LYS_REQUIRE(work_bytes >= ksvd_exact_work_doubles(n) * sizeof(double), "nn_ksvd_sweep: work buffer too small");
+    return ksvd_exact_sweep(R, ldr, n, K, k, row_ptr, entry, coef, work, D_packed, D_next, max_support, STREAM(stream),
+                            n_cycles, xbuf);
 }
 
 int lys_ksvd_exact_gram(int atom, const float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,

@@ -2062,9 +2062,14 @@ __global__ __launch_bounds__(256) void ksvd_mf_norm_kernel(int atom, int n, cons
     }
 }
 
-size_t ksvd_exact_work_doubles(int n) {
+// doubles of nn_ksvd's per-atom state behind the exact update's work area: [4 scalars | s (256) | working d (256 floats)]
+constexpr size_t NN_STATE_DOUBLES = 4 + 256 + 128;
+static size_t exact_base_doubles(int n) {
     if (n <= 64) return (size_t)G64_MAX_PARTS * 4096 / 2 + 4096;  // fp32 partial Gram matrices of ksvd_gram64_kernel + their fp64 sum
-    if (n <= 256) return (size_t)n * n;
+    return (size_t)n * n;
+}
+size_t ksvd_exact_work_doubles(int n) {
+    if (n <= 256) return exact_base_doubles(n) + NN_STATE_DOUBLES;
     // s2 (8) | M | v | u_raw (n floats) | second iterate of the matrix-free path (n floats) | its second s2 (8)
     return 8 + (size_t)TALL_MAX * TALL_MAX + TALL_MAX / 2 + ((size_t)n + 1) / 2 + 8 + ((size_t)n + 1) / 2 + 8;
 }
@@ -2143,10 +2148,252 @@ static int ksvd_exact_sweep_tall(float* R, int64_t ldr, int n, int K, int k, con
     return ksvd_commit(n, K, row_ptr, Dnext, D, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Non-negative K-SVD atom update (lyssa/dict_learning/ksvd.py:46-95, `nn_ksvd`).  Per atom, after the same rank-1 solve as
+// the exact update (u in Dnext[atom], sign u . d_old >= 0; the reference's randomized_svd leaves the sign to chance):
+//     d = max(u, 0), x = max(Rk'u, 0)                                  (:73-77; skip the atom if d'd or x'x <= eps, :79-82)
+//     n_cycles times:  d = max(Rk x / x'x, 0),  x = max(Rk'd / d'd, 0)  (:84-88)
+//     d /= ||d||, x *= ||d||;  D[:,k] = d, X[k,omega] = x, R[:,omega] = Rk - d x'   (:90-95)
+// Rk = R[:,omega] + d_old x_old is never materialised: every pass rebuilds its rows from R, D[atom] and the stored
+// coefficients, which stay untouched until the commit.  State of the current atom in `st` (doubles):
+//   [0] x'x accumulator  [1] d'd  [2] skip flag  [3] x'x of the finished pass  [4 .. 4+n) sum_i x_i rk_i
+// x iterates live in xbuf[e - row_ptr[atom]] (float, max_support entries).
+// ---------------------------------------------------------------------------------------------
+constexpr int NN_ST = 4;
+
+// x_i = max(scale * rk_i . v, 0) with v = vsrc (first: u = Dnext[atom], scale 1; later: the working d, scale 1 / d'd)
+template <int FB>
+__global__ __launch_bounds__(256) void nn_x_kernel(int atom, int first, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                                   const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+                                                   const float* __restrict__ coef, const float* __restrict__ D, int ldd,
+                                                   const float* __restrict__ vsrc /* n floats: u or the working d */,
+                                                   float* __restrict__ xbuf, double* __restrict__ st) {
+    __shared__ double s_sq[16];
+    const int beg = row_ptr[atom], end = row_ptr[atom + 1];
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int gteam = blockIdx.x * 16 + team, nteams = gridDim.x * 16;
+    if (beg + blockIdx.x * 16 >= end) return;
+    if (!first && st[2] != 0.0) return;
+    const float scale = first ? 1.f : (float)(1.0 / st[1]);
+    float4 dold[FB], v[FB];
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        const int f = 64 * b + 4 * q;
+        dold[b] = v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < n) {
+            dold[b] = *reinterpret_cast<const float4*>(D + (int64_t)atom * ldd + f);
+            v[b] = *reinterpret_cast<const float4*>(vsrc + f);
+        }
+    }
+    double sq = 0.0;
+    for (int e = beg + gteam; e < end; e += nteams) {
+        const int ss = entry[e];
+        const int64_t sig = ss / k;
+        const float xo = coef[ss];
+        float dot = 0.f;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < n) r = *reinterpret_cast<const float4*>(R + sig * ldr + f);
+            dot = fmaf(fmaf(dold[b].x, xo, r.x), v[b].x, dot);
+            dot = fmaf(fmaf(dold[b].y, xo, r.y), v[b].y, dot);
+            dot = fmaf(fmaf(dold[b].z, xo, r.z), v[b].z, dot);
+            dot = fmaf(fmaf(dold[b].w, xo, r.w), v[b].w, dot);
+        }
+        const float x = fmaxf(row16_sum(dot) * scale, 0.f);
+        if (q == 0) xbuf[e - beg] = x;
+        sq += (double)x * (double)x;
+    }
+    if (q == 0) s_sq[team] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int t = 0; t < 16; ++t) tot += s_sq[t];
+        atomicAdd(st, tot);
+    }
+}
+
+// st[4 + f] += sum_i x_i rk_i[f]
+template <int FB>
+__global__ __launch_bounds__(256) void nn_dacc_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                                      const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+                                                      const float* __restrict__ coef, const float* __restrict__ D, int ldd,
+                                                      const float* __restrict__ xbuf, double* __restrict__ st) {
+    __shared__ float s_acc[16][FB * 64];
+    const int beg = row_ptr[atom], end = row_ptr[atom + 1];
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int gteam = blockIdx.x * 16 + team, nteams = gridDim.x * 16;
+    if (beg + blockIdx.x * 16 >= end) return;
+    if (st[2] != 0.0) return;
+    float4 dold[FB], acc[FB];
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        const int f = 64 * b + 4 * q;
+        dold[b] = acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < n) dold[b] = *reinterpret_cast<const float4*>(D + (int64_t)atom * ldd + f);
+    }
+    for (int e = beg + gteam; e < end; e += nteams) {
+        const int ss = entry[e];
+        const int64_t sig = ss / k;
+        const float xo = coef[ss];
+        const float x = xbuf[e - beg];
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (f < n) {
+                const float4 r = *reinterpret_cast<const float4*>(R + sig * ldr + f);
+                acc[b].x = fmaf(fmaf(dold[b].x, xo, r.x), x, acc[b].x);
+                acc[b].y = fmaf(fmaf(dold[b].y, xo, r.y), x, acc[b].y);
+                acc[b].z = fmaf(fmaf(dold[b].z, xo, r.z), x, acc[b].z);
+                acc[b].w = fmaf(fmaf(dold[b].w, xo, r.w), x, acc[b].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        s_acc[team][64 * b + 4 * q + 0] = acc[b].x;
+        s_acc[team][64 * b + 4 * q + 1] = acc[b].y;
+        s_acc[team][64 * b + 4 * q + 2] = acc[b].z;
+        s_acc[team][64 * b + 4 * q + 3] = acc[b].w;
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < n; f += 256) {
+        double tot = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) tot += (double)s_acc[t][f];
+        atomicAdd(st + NN_ST + f, tot);
+    }
+}
+
+// the serial scalar logic between the passes, one workgroup.  phase 0: after the first x pass (d = max(u, 0), the skip
+// test of :79-82); phase 1: after an accumulate pass (d = max(s / x'x, 0)).  Both leave d (unnormalised) in `dwork`,
+// d'd in st[1], and reset the accumulators.
+__global__ __launch_bounds__(256) void nn_prep_kernel(int atom, int phase, int n, const int32_t* __restrict__ row_ptr,
+                                                      const float* __restrict__ D, int ldd, float* __restrict__ Dnext,
+                                                      float* __restrict__ dwork, double* __restrict__ st) {
+    __shared__ double s_red[256];
+    if (row_ptr[atom] >= row_ptr[atom + 1]) return;
+    if (phase == 1 && st[2] != 0.0) return;
+    const double xtx = st[0];
+    double part = 0.0;
+    for (int f = threadIdx.x; f < ldd; f += 256) {
+        float d = 0.f;
+        if (f < n) {
+            d = (phase == 0) ? Dnext[(int64_t)atom * ldd + f] : (float)(st[NN_ST + f] / xtx);
+            d = (d < 0.f) ? 0.f : d;   // NaN (x'x = 0 inside the loop: the reference divides by zero too) stays NaN
+        }
+        dwork[f] = d;
+        part += (double)d * (double)d;
+    }
+    s_red[threadIdx.x] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double dtd = s_red[0];
+    const double eps = 2.220446049250313e-16;  // np.finfo('float').eps
+    const bool skip = (phase == 0) && (dtd <= eps || xtx <= eps);
+    __syncthreads();
+    if (skip)  // the atom, its coefficients and the residual stay as they were (`continue`, :82)
+        for (int f = threadIdx.x; f < ldd; f += 256) Dnext[(int64_t)atom * ldd + f] = D[(int64_t)atom * ldd + f];
+    for (int f = threadIdx.x; f < n; f += 256) st[NN_ST + f] = 0.0;
+    if (threadIdx.x == 0) {
+        // the x'x of the latest x pass stays in st[0] until the NEXT accumulate pass has been turned into d (phase 1 reads
+        // and clears it; the x pass that follows accumulates afresh)
+        st[0] = (phase == 0 && !skip) ? xtx : 0.0;
+        st[1] = dtd;
+        st[3] = xtx;
+        if (phase == 0) st[2] = skip ? 1.0 : 0.0;
+    }
+}
+
+// d /= ||d||, x *= ||d||, coefficients and residual rows written (:90-95); the new atom goes to Dnext[atom].
+template <int FB>
+__global__ __launch_bounds__(256) void nn_commit_kernel(int atom, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                        const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+                                                        float* __restrict__ coef, const float* __restrict__ D, int ldd,
+                                                        const float* __restrict__ dwork, float* __restrict__ Dnext,
+                                                        const float* __restrict__ xbuf, double* __restrict__ st) {
+    const int beg = row_ptr[atom], end = row_ptr[atom + 1];
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int gteam = blockIdx.x * 16 + team, nteams = gridDim.x * 16;
+    if (beg >= end || st[2] != 0.0) return;
+    if (blockIdx.x != 0 && beg + blockIdx.x * 16 >= end) return;
+    const double nrm = sqrt(st[1]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) st[0] = 0.0;  // the last x pass's x'x is never consumed: clean for the next atom
+    const float fn = (float)nrm, rn = (float)(1.0 / nrm);
+    float4 dold[FB], d[FB];
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+        const int f = 64 * b + 4 * q;
+        dold[b] = d[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < n) {
+            dold[b] = *reinterpret_cast<const float4*>(D + (int64_t)atom * ldd + f);
+            d[b] = *reinterpret_cast<const float4*>(dwork + f);
+            d[b].x *= rn; d[b].y *= rn; d[b].z *= rn; d[b].w *= rn;
+            if (blockIdx.x == 0 && team == 0) *reinterpret_cast<float4*>(Dnext + (int64_t)atom * ldd + f) = d[b];
+        }
+    }
+    for (int e = beg + gteam; e < end; e += nteams) {
+        const int ss = entry[e];
+        const int64_t sig = ss / k;
+        const float xo = coef[ss];
+        const float xn = xbuf[e - beg] * fn;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            if (f < n) {
+                const float4 r = *reinterpret_cast<const float4*>(R + sig * ldr + f);
+                float4 o;
+                o.x = fmaf(-d[b].x, xn, fmaf(dold[b].x, xo, r.x));
+                o.y = fmaf(-d[b].y, xn, fmaf(dold[b].y, xo, r.y));
+                o.z = fmaf(-d[b].z, xn, fmaf(dold[b].z, xo, r.z));
+                o.w = fmaf(-d[b].w, xn, fmaf(dold[b].w, xo, r.w));
+                *reinterpret_cast<float4*>(R + sig * ldr + f) = o;
+            }
+        }
+        if (q == 0) coef[ss] = xn;
+    }
+}
+
+template <int FB>
+static int nn_atom_passes(int a, int nn_cycles, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr,
+                          const int32_t* entry, float* coef, const float* D, int ldd, float* Dnext, float* xbuf, double* st,
+                          hipStream_t stream) {
+    float* dwork = reinterpret_cast<float*>(st + NN_ST + 256);  // ldd <= 256 floats
+    hipLaunchKernelGGL(nn_x_kernel<FB>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, 1, R, ldr, n, k, row_ptr, entry, coef, D, ldd,
+                       Dnext + (int64_t)a * ldd, xbuf, st);
+    hipLaunchKernelGGL(nn_prep_kernel, dim3(1), dim3(256), 0, stream, a, 0, n, row_ptr, D, ldd, Dnext, dwork, st);
+    for (int j = 0; j < nn_cycles; ++j) {
+        hipLaunchKernelGGL(nn_dacc_kernel<FB>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D,
+                           ldd, xbuf, st);
+        hipLaunchKernelGGL(nn_prep_kernel, dim3(1), dim3(256), 0, stream, a, 1, n, row_ptr, D, ldd, Dnext, dwork, st);
+        hipLaunchKernelGGL(nn_x_kernel<FB>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, 0, R, ldr, n, k, row_ptr, entry, coef, D,
+                           ldd, dwork, xbuf, st);
+    }
+    hipLaunchKernelGGL(nn_commit_kernel<FB>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D,
+                       ldd, dwork, Dnext, xbuf, st);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 // One exact cycle on one GPU.  max_support: upper bound of |omega_a| over the atoms (sizes the Gram grid).
+// nn_cycles >= 0: the non-negative variant (nn_ksvd, ksvd.py:46-95) with that many alternating projections per atom;
+// xbuf: max_support floats (nn only).
 int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
-                     float* coef, double* work, float* D, float* Dnext, int64_t max_support, hipStream_t stream) {
-    if (n > 256) return ksvd_exact_sweep_tall(R, ldr, n, K, k, row_ptr, entry, coef, work, D, Dnext, max_support, stream);
+                     float* coef, double* work, float* D, float* Dnext, int64_t max_support, hipStream_t stream,
+                     int nn_cycles, float* xbuf) {
+    if (n > 256) {
+        if (nn_cycles >= 0) {
+            set_error("nn_ksvd: n = %d > 256 is outside the non-negative update", n);
+            return LYS_ENOSUP;
+        }
+        return ksvd_exact_sweep_tall(R, ldr, n, K, k, row_ptr, entry, coef, work, D, Dnext, max_support, stream);
+    }
+    double* nn_st = work + exact_base_doubles(n);
+    if (nn_cycles >= 0) LYS_CHECK_HIP(hipMemsetAsync(nn_st, 0, NN_STATE_DOUBLES * sizeof(double), stream));
     const int ldd = padded_features(n);
     const int fb = fb_of(n);
     static bool attr_set[64] = {};
@@ -2190,6 +2437,16 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
         else
             hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, a, n, row_ptr, work, D, ldd, Dnext,
                                c_in_lds);
+        if (nn_cycles >= 0) {
+            int rc;
+            switch (fb) {
+                case 1: rc = nn_atom_passes<1>(a, nn_cycles, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext, xbuf, nn_st, stream); break;
+                case 2: rc = nn_atom_passes<2>(a, nn_cycles, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext, xbuf, nn_st, stream); break;
+                default: rc = nn_atom_passes<4>(a, nn_cycles, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext, xbuf, nn_st, stream); break;
+            }
+            if (rc) return rc;
+            continue;
+        }
         switch (fb) {
             case 1: hipLaunchKernelGGL(ksvd_exact_apply_kernel<1>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;
             case 2: hipLaunchKernelGGL(ksvd_exact_apply_kernel<2>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D, ldd, Dnext); break;

@@ -57,6 +57,21 @@ def ksvd(Y, D, X, n_cycles=1, verbose=True):
     return D, X, unused_atoms
 
 
+def nn_ksvd(Y, D, X, n_cycles=1, verbose=True):
+    """lyssa/dict_learning/ksvd.py:46-95 -- the non-negative K-SVD update: rank-1 solve per atom, projection of (d, x) onto
+    the non-negative orthant, ``n_cycles`` alternating projections, renormalisation.  One pass over the atoms; an atom whose
+    projected d or x vanishes keeps its column, codes and residual (:79-82).  Same in-place contract as ``approx_ksvd``.
+    Sign of the rank-1 pair: u . d_old >= 0 (the reference's randomized_svd leaves it to chance)."""
+    Ys = engine.signals_to_device(Y)
+    dd = engine.DeviceDictionary.from_host(D)
+    idx, coef, nnz = engine.sparsify_host(X)
+    R, _ = engine.residual(Ys, dd, idx, coef, nnz, want_R=True, want_err=False)
+    unused_atoms = engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, nn_cycles=n_cycles)
+    D[:] = dd.to_host()
+    _scatter_codes(X, idx, coef, nnz)
+    return D, X, unused_atoms
+
+
 def _scatter_codes(X, idx, coef, nnz):
     """Write the (updated) coefficients back into the dense host matrix, support unchanged."""
     hi, hc, hn = idx.cpu().numpy(), coef.cpu().numpy(), nnz.cpu().numpy()
@@ -87,10 +102,6 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
         # the reference's default (ksvd_coder(max_iter=None)): under Python 2 `0 < None` is False, the loop never runs and
         # the initial dictionary is returned with all-zero codes -- reproduced explicitly instead of a py3 TypeError
         max_iter = 0
-    if non_neg and not approx:
-        raise NotImplementedError("nn_ksvd (non_neg=True with approx=False) is outside the accelerated path")
-    if eta is not None and group is not None:
-        raise NotImplementedError("eta (force_mi) is not available in group (sharded) mode")
     X = np.asarray(X)
     n_samples = X.shape[1]
     unused_data = []
@@ -131,7 +142,10 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
         R, _ = engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False,
                                out=R if (R is not None and R.shape[0] == idx.shape[0]) else None)
         unused_atoms = []
-        for _ in range(n_cycles):
+        if non_neg and not approx:
+            # ksvd.py:187-188: nn_ksvd with n_cycles = the ITERATION INDEX (alternating projections), one pass over the atoms
+            unused_atoms += engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=buffers, group=group, nn_cycles=it)
+        for _ in range(0 if (non_neg and not approx) else n_cycles):
             if approx:
                 unused_atoms += engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group, buffers=buffers)
             else:  # ksvd.py:189-190: exact rank-1 update
@@ -146,9 +160,12 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
             unused_data.remove(pick)
         # ---- force mutual incoherence, not in the last iteration (ksvd.py:209-213)
         if eta is not None and it < max_iter - 1:
-            from .utils import force_mi
             Dh = dd.to_host()
-            Dh, unused_data = force_mi(Dh, X, (idx, coef, nnz), unused_data, eta)
+            if group is None:
+                from .utils import force_mi
+                Dh, unused_data = force_mi(Dh, X, (idx, coef, nnz), unused_data, eta)
+            else:   # replicated decision: code-row norms all-reduced, candidate columns fetched by global index
+                Dh, unused_data = _dist.force_mi_sharded(Dh, X, (idx, coef, nnz), shard_span, unused_data, eta, group)
             dd.set(Dh)
         # ---- error with the updated codes (ksvd.py:220)
         error = engine.approx_error(Xs, dd, idx, coef, nnz)

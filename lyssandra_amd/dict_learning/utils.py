@@ -79,7 +79,7 @@ def _code_row_norms(Z, n_atoms):
     return np.sqrt(np.einsum('ij,ij->i', Z, Z))
 
 
-def force_mi(D, X, Z, unused_data, eta, max_tries=100):
+def force_mi(D, X, Z, unused_data, eta, max_tries=100, fetch_column=None, usage=None):
     """lyssa/dict_learning/utils.py:86-139 -- replace atoms whose mutual coherence exceeds ``eta`` by datapoints.
 
     Host control flow with the GLOBAL numpy RNG like the reference: the coherence matrix |D'D| is computed ONCE (:89)
@@ -91,15 +91,19 @@ def force_mi(D, X, Z, unused_data, eta, max_tries=100):
     candidate lowers the coherence (``min_idx is None`` at :134) the atom is left alone, and when the candidate list
     runs dry (:119-120, the reference returns a bare ``D`` that its caller cannot unpack) ``(D, unused_data)`` is
     returned.
+    Signal shards (lyssandra_amd.dist.force_mi_sharded): ``fetch_column(i)`` returns GLOBAL column i on every rank and
+    ``usage`` the code-row norms over all shards; D and the RNG state are replicated, so every rank takes the same decisions.
     """
     D = np.asarray(D)
     K = D.shape[1]
     coherence = np.abs(D.T @ D)            # computed once, never refreshed (:89)
     coherence[np.diag_indices(K)] = 0.0
-    usage = _code_row_norms(Z, K)
+    if usage is None:
+        usage = _code_row_norms(Z, K)
 
     def column(i):
-        return _normalize(np.asarray(X[:, i], dtype=np.float64))
+        raw = X[:, i] if fetch_column is None else fetch_column(int(i))
+        return _normalize(np.asarray(raw, dtype=np.float64))
 
     for first in range(K):
         partner = int(coherence[first].argmax())

@@ -272,3 +272,18 @@ def fetch_global_column(X_local, span, g, group=None):
         v += torch.from_numpy(np.asarray(X_local[:, g - s], dtype=np.float64))
     allreduce_sum_(v, group)
     return v.numpy()
+
+
+def force_mi_sharded(D, X_local, Z_local, span, unused_data, eta, group=None, max_tries=100):
+    """`force_mi` (lyssa/dict_learning/utils.py:86-139, the `eta` step of ksvd_dict_learn, ksvd.py:209-213) when the signals
+    and codes are sharded: a replicated host decision.  It needs |D'D| (D is replicated), the code-row norms ||Z[k, :]|| --
+    ONE all-reduce of the K local sums of squares -- and the candidate datapoints by GLOBAL index (`fetch_global_column`,
+    the owner contributes).  Every rank holds the same numpy RNG state and therefore draws the same candidates.
+    `Z_local`: dense (K, N_local) host codes or the device triplet."""
+    import torch
+    from .dict_learning.utils import _code_row_norms, force_mi
+    K = np.asarray(D).shape[1]
+    sq = torch.from_numpy(np.asarray(_code_row_norms(Z_local, K), dtype=np.float64) ** 2)
+    allreduce_sum_(sq, group)
+    return force_mi(D, None, None, unused_data, eta, max_tries=max_tries,
+                    fetch_column=lambda g: fetch_global_column(X_local, span, g, group), usage=np.sqrt(sq.numpy()))

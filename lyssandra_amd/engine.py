@@ -621,8 +621,10 @@ class HipExactKsvdOps(object):
         self.dd.invalidate()
 
 
-def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None):
+def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None, nn_cycles=None):
     """One cycle of the EXACT rank-1 K-SVD update (lyssa/dict_learning/ksvd.py:19-43), in place on R, coef, dd.D.
+    ``nn_cycles`` (int >= 0): the non-negative variant instead (`nn_ksvd`, ksvd.py:46-95) with that many alternating
+    projections per atom (`lys_nn_ksvd_sweep`; single GPU, n <= 256).
 
     Per atom: Gram matrix of the restricted residual, its leading eigenvector (Lanczos + Rayleigh-Ritz in one
     workgroup), coefficient / residual update (the reference: sklearn ``randomized_svd(n_iter=10)``, random sign).
@@ -635,6 +637,8 @@ def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None):
     if buffers is None:
         buffers = {}
     if group is not None:
+        if nn_cycles is not None:
+            raise _lib.LyssaHipError("nn_ksvd runs on one GPU (its per-atom projections are not exchanged between shards)")
         from . import dist as _d
         return _d.ksvd_exact_cycle_sharded(HipExactKsvdOps(R, dd, idx, coef, nnz, buffers), dd.K, group)
     row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
@@ -647,9 +651,17 @@ def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None):
         Dnext = buffers["exact_Dnext"] = torch.zeros_like(dd.D)
     counts = row_ptr[1:] - row_ptr[:-1]
     max_support = int(counts.max().item()) if counts.numel() else 0
-    _lib.check(lib.lys_ksvd_exact_sweep(_ptr(R), _ld(R), dd.n, dd.K, k, _ptr(row_ptr), _ptr(entry), _ptr(coef),
-                                        _ptr(work), work.numel() * 8, _ptr(dd.D), _ptr(Dnext), max_support,
-                                        _stream()), "lys_ksvd_exact_sweep")
+    if nn_cycles is not None:
+        xbuf = buffers.get("nn_xbuf")
+        if xbuf is None or xbuf.numel() < max(1, max_support):
+            xbuf = buffers["nn_xbuf"] = torch.zeros((max(1, max_support),), dtype=torch.float32, device=dd.device)
+        _lib.check(lib.lys_nn_ksvd_sweep(_ptr(R), _ld(R), dd.n, dd.K, k, _ptr(row_ptr), _ptr(entry), _ptr(coef),
+                                         _ptr(work), work.numel() * 8, _ptr(xbuf), _ptr(dd.D), _ptr(Dnext), max_support,
+                                         int(nn_cycles), _stream()), "lys_nn_ksvd_sweep")
+    else:
+        _lib.check(lib.lys_ksvd_exact_sweep(_ptr(R), _ld(R), dd.n, dd.K, k, _ptr(row_ptr), _ptr(entry), _ptr(coef),
+                                            _ptr(work), work.numel() * 8, _ptr(dd.D), _ptr(Dnext), max_support,
+                                            _stream()), "lys_ksvd_exact_sweep")
     dd.invalidate()
     return torch.nonzero(counts == 0).flatten().cpu().numpy().tolist()
 

@@ -443,6 +443,52 @@ def ksvd_exact(Y, D, X, n_cycles=1):
     return D, X, unused
 
 
+def nn_ksvd(Y, D, X, n_cycles=1, signs=None):
+    """lyssa/dict_learning/ksvd.py:46-95 (`nn_ksvd`).  Mutates D and X in place; returns (D, X, unused_atoms).
+
+    One pass over the atoms (no outer cycle loop, :53); per atom the rank-1 SVD of Rk :66, d = max(u, 0), x = max(S v, 0)
+    :73-77, `continue` when d'd or x'x <= eps :79-82 (atom, codes and residual untouched), n_cycles alternating projections
+    d = max(Rk x / x'x, 0), x = max(d'Rk / d'd, 0) :84-88, then d /= ||d||, x *= ||d|| :90-92 and the residual update :95.
+    The reference's randomized_svd(n_iter=50, flip_sign=False) returns (u, v) with an ARBITRARY common sign, and the clip
+    makes the result depend on it.  The restatement uses the exact SVD with u . d_old >= 0; `signs` (one +-1 per USED atom, in
+    visiting order -- what the reference's solver happened to return, recorded by oracle/make_golden.py) reproduces the
+    reference's own run instead.
+    """
+    n_atoms = D.shape[1]
+    unused = []
+    R = Y - fast_dot(D, X)
+    used = 0
+    for k in range(n_atoms):
+        omega = X[k, :] != 0
+        if not np.any(omega):
+            unused.append(k)
+            continue
+        Rk = R[:, omega] + np.outer(D[:, k], X[k, omega])
+        U, S, Vt = np.linalg.svd(Rk, full_matrices=False)
+        d, x = U[:, 0].copy(), S[0] * Vt[0, :]
+        sgn = 1.0 if np.dot(d, D[:, k]) >= 0 else -1.0
+        if signs is not None:
+            sgn *= float(signs[used])
+        used += 1
+        d, x = sgn * d, sgn * x
+        d[d < 0] = 0
+        x[x < 0] = 0
+        if np.dot(d, d) <= EPS64 or np.dot(x, x) <= EPS64:
+            continue
+        for _ in range(n_cycles):
+            d = np.dot(Rk, x) / np.dot(x, x)
+            d[d < 0] = 0
+            x = np.dot(d.T, Rk) / np.dot(d, d)
+            x[x < 0] = 0
+        nrm = norm(d)
+        d = d / nrm
+        x = x * nrm
+        D[:, k] = d
+        X[k, omega] = x
+        R[:, omega] = Rk - np.outer(D[:, k], X[k, omega])
+    return D, X, unused
+
+
 def ksvd_dict_learn(X, n_atoms, init_dict='data', encode=None, max_iter=20, n_cycles=1, verbose=True,
                     trace=None):
     """lyssa/dict_learning/ksvd.py:129-231, approx=True, eta=None path.

@@ -21,6 +21,8 @@ Fixtures:
   F12 (round 2; `python oracle/make_golden.py F12` regenerates it alone) dataset-level preproc ('global_centering',
       'global_standarization', 'whitening' = zca_transform), error-constrained 'omp' (tol, no n_nonzero_coefs) and
       'thresh' with 2048 atoms
+  F14 (round 4; `python oracle/make_golden.py F14`) nn_ksvd (ksvd.py:46-95) on non-negative data / dictionary / codes,
+      n_cycles = 0, 1, 3; the sign of u . d_old the reference's randomized_svd returned per atom is recorded
 """
 import contextlib
 import io
@@ -226,6 +228,54 @@ def make_f13():
     yp = np.array([(c * 7 + i) % n_classes for i, c in enumerate(labels)])
     out.update(acc_pred=yp, acc=ref_acc(yp, labels), avg_acc=ref_avg_acc(yp, labels))
     np.savez_compressed(os.path.join(OUT, "F13.npz"), **out)
+
+
+def make_f14():
+    """F14: nn_ksvd (ksvd.py:46-95) on non-negative data, dictionary and codes, n_cycles = 0, 1, 3 (ksvd_dict_learn passes the
+    iteration index, :187-188).  randomized_svd(flip_sign=False) returns an arbitrary common sign of (u, v) and the clip makes
+    the result depend on it: the generator wraps the solver (in the imported module, not in the reference tree) to RECORD, per
+    used atom, the sign of u . d_old the reference's run saw; the fixture stores inputs, outputs and those signs."""
+    load_reference()
+    import lyssa.dict_learning.ksvd as ref_ksvd_mod
+    rs = np.random.RandomState(1414)
+    n, K, N, k = 36, 48, 900, 4
+    D0 = np.abs(rs.randn(n, K)) + 0.05
+    D0 = f32(D0 / np.linalg.norm(D0, axis=0, keepdims=True))
+    Z0 = np.zeros((K, N))
+    for i in range(N):
+        Z0[rs.choice(K - 2, k, replace=False), i] = np.abs(rs.randn(k)) + 0.1       # atoms K-2, K-1 stay unused
+    Z0 = f32(Z0)
+    X = f32(np.abs(D0.dot(Z0) + 0.05 * rs.randn(n, N)))
+    out = dict(X=X.astype(np.float32), D0=D0.astype(np.float32), Z0=Z0.astype(np.float32), k=k)
+    inner = ref_ksvd_mod.randomized_svd
+    state = {"signs": [], "d_old": None, "ratios": []}
+
+    def recording_svd(Rk, **kw):
+        U, S, V = inner(Rk, **kw)
+        sv = np.linalg.svd(Rk, compute_uv=False)
+        state["ratios"].append(sv[1] / sv[0] if sv.size > 1 else 0.0)
+        state["signs"].append(U[:, 0].copy())
+        return U, S, V
+    ref_ksvd_mod.randomized_svd = recording_svd
+    try:
+        for cyc in (0, 1, 3):
+            state["signs"], state["ratios"] = [], []
+            D, Z = D0.copy(), Z0.copy()
+            np.random.seed(1400 + cyc)
+            D1, Z1, unused = quiet(ref_ksvd_mod.nn_ksvd, X, D, Z, n_cycles=cyc, verbose=False)
+            # sign of u . d_old per used atom: d_old of atom a is D0[:, a] (every atom is visited once)
+            used = [a for a in range(K) if a not in unused]
+            sg = np.array([1.0 if np.dot(u, D0[:, a]) >= 0 else -1.0 for u, a in zip(state["signs"], used)])
+            out["c%d_D" % cyc] = D1.copy()
+            out["c%d_Z" % cyc] = Z1.copy()
+            out["c%d_unused" % cyc] = np.array(unused, dtype=np.int32)
+            out["c%d_signs" % cyc] = sg
+            out["c%d_sigma_ratio_max" % cyc] = float(np.max(state["ratios"]))
+            print("F14 cycles", cyc, "unused", unused, "negative signs", int((sg < 0).sum()), "max s2/s1",
+                  out["c%d_sigma_ratio_max" % cyc], "zeros created", int(((Z1 == 0) & (Z0 != 0)).sum()))
+    finally:
+        ref_ksvd_mod.randomized_svd = inner
+    np.savez_compressed(os.path.join(OUT, "F14.npz"), **out)
 
 
 def main():
@@ -511,6 +561,8 @@ def main():
     print("F11 replaced atoms:", np.flatnonzero(np.abs(D1 - D).max(0) > 0), "unused left", len(un1))
     np.savez_compressed(os.path.join(OUT, "F11.npz"), **out)
 
+    make_f14()
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)
 
@@ -520,6 +572,8 @@ if __name__ == "__main__":
         make_f12()
     elif sys.argv[1:] == ["F13"]:
         make_f13()
+    elif sys.argv[1:] == ["F14"]:
+        make_f14()
     else:
         main()
         make_f12()

@@ -278,6 +278,21 @@ def _worker(rank, world, port, out):
         assert np.max(np.abs(Di - Dfull)) < 1e-14 and unused_data == unused_full and 7 not in unused_data
         col = ld.fetch_global_column(Xl, span, 150)
         assert np.array_equal(col, X[:, 150])
+        # ---- eta / force_mi on shards (ksvd.py:209-213): a replicated decision from all-reduced code-row norms and globally
+        # fetched candidate columns == the reference's force_mi on the full matrices (same global RNG state)
+        Dc = D0.copy()
+        for a_, b_ in ((2, 11), (5, 20)):                       # two strongly coherent pairs
+            v = Dc[:, a_] + 0.05 * rs.randn(n)
+            Dc[:, b_] = v / np.sqrt((v * v).sum())
+        pool = [i for i in range(40, 120)]
+        np.random.seed(99)
+        Dm, un_m = ld.force_mi_sharded(Dc.copy(), Xl, Z[:, span[0]:span[1]], span, list(pool), 0.9)
+        rng_after = np.random.randint(0, 2 ** 31 - 1)
+        np.random.seed(99)
+        Dmf, un_f = orc.force_mi(Dc.copy(), X, Z, list(pool), 0.9)
+        assert np.random.randint(0, 2 ** 31 - 1) == rng_after                  # same number of draws
+        assert un_m == un_f and len(un_f) < len(pool)
+        assert np.max(np.abs(Dm - Dmf)) < 1e-14 and np.abs(Dm - Dc).max() > 0
         # ---- mini-batch sharding: local batch b == this rank's slice of global batch b
         Xm = np.arange(2 * 20.0).reshape(2, 20)
         Xloc, lbs = ld.shard_minibatches(Xm, 8)                 # global batches 8, 8, 4 -> local 4, 4, 2

@@ -380,6 +380,65 @@ def test_exact_ksvd_golden(eng):
     assert errs[2] < errs[1] < errs[0]
 
 
+@pytest.mark.parametrize("cycles", [0, 1, 3])
+def test_nn_ksvd_golden(eng, cycles):
+    """ksvd.py:46-95 (`nn_ksvd`) on F14, the reference's own run (its solver returned u . d_old >= 0 for every atom, the
+    device's convention): atoms, codes, the exact zero a clip creates, unused atoms -- and against the float64 oracle."""
+    from oracle import lyssa_oracle as orc
+    from lyssandra_amd.dict_learning.ksvd import nn_ksvd
+    g = load_golden("F14")
+    X, D0, Z0 = g["X"].astype(np.float64), g["D0"].astype(np.float64), g["Z0"].astype(np.float64)
+    Dh, Zh = D0.copy(), Z0.copy()
+    Dr, Zr, unused = nn_ksvd(X, Dh, Zh, n_cycles=cycles, verbose=False)
+    assert Dr is Dh and Zr is Zh
+    assert list(unused) == list(g["c%d_unused" % cycles])
+    Dref, Zref = g["c%d_D" % cycles], g["c%d_Z" % cycles]
+    assert _atom_err(Dh, Dref) < 2e-5, _atom_err(Dh, Dref)
+    assert np.max(np.abs(Zh - Zref)) < 2e-5 * np.abs(Zref).max()
+    assert np.array_equal(Zh != 0, Zref != 0)          # the clipped coefficient is an exact zero on the device too
+    assert Dh.min() >= 0 and Zh.min() >= 0
+    assert np.array_equal(Dh[:, unused], D0[:, unused])
+    Do, Zo, _ = orc.nn_ksvd(X, D0.copy(), Z0.copy(), n_cycles=cycles)
+    assert _atom_err(Dh, Do) < 2e-5 and np.max(np.abs(Zh - Zo)) < 2e-5 * np.abs(Zo).max()
+
+
+@pytest.mark.parametrize("n,K,k,N,cycles", [(100, 30, 3, 500, 2), (200, 24, 4, 400, 1), (20, 16, 2, 60, 4)])
+def test_nn_ksvd_other_shapes_and_skip(eng, n, K, k, N, cycles):
+    """nn_ksvd at 2 / 4 feature blocks per lane and a tiny shape, with one atom whose rank-1 pair projects to zero (its
+    restricted residual is negative: d = max(u, 0) keeps u's sign convention u . d_old >= 0, x = max(Rk'u, 0) = 0 ->
+    `continue`, ksvd.py:79-82: atom, codes and residual rows stay) -- against the float64 oracle; and the learner branch
+    ksvd_dict_learn(non_neg=True, approx=False) (ksvd.py:187-188: n_cycles = iteration index)."""
+    from oracle import lyssa_oracle as orc
+    from lyssandra_amd.dict_learning.ksvd import nn_ksvd, ksvd_dict_learn
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    rs = np.random.RandomState(7 * n + K)
+    D0 = np.abs(rs.randn(n, K)) + 0.05
+    D0 = (D0 / np.linalg.norm(D0, axis=0)).astype(np.float32).astype(np.float64)
+    Z0 = np.zeros((K, N))
+    for i in range(N):
+        Z0[rs.choice(K - 1, k, replace=False), i] = np.abs(rs.randn(k)) + 0.1
+    Z0 = Z0.astype(np.float32).astype(np.float64)
+    X = np.abs(D0 @ Z0 + 0.05 * rs.randn(n, N))
+    # atom 0's signals: make the residual restricted to atom 0 point AGAINST d_old, so that x = max(Rk'u, 0) = 0
+    users = np.flatnonzero(Z0[0] != 0)
+    X[:, users] -= np.outer(D0[:, 0], 3.0 * Z0[0, users])
+    X = X.astype(np.float32).astype(np.float64)
+    Do, Zo, uo = orc.nn_ksvd(X, D0.copy(), Z0.copy(), n_cycles=cycles)
+    skipped = np.array_equal(Do[:, 0], D0[:, 0]) and np.array_equal(Zo[0], Z0[0])
+    Dh, Zh = D0.copy(), Z0.copy()
+    _, _, uh = nn_ksvd(X, Dh, Zh, n_cycles=cycles, verbose=False)
+    assert list(uh) == list(uo) and (K - 1) in uh
+    assert _atom_err(Dh, Do) < 5e-5, _atom_err(Dh, Do)
+    assert np.max(np.abs(Zh - Zo)) < 5e-5 * np.abs(Zo).max()
+    if skipped:
+        assert np.array_equal(Dh[:, 0], D0[:, 0]) and np.array_equal(Zh[0], Z0[0])
+    # learner branch: runs, keeps D non-negative and unit norm
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    Dl, Zl = ksvd_dict_learn(np.abs(X), K, init_dict=D0, sparse_coder=se, max_iter=3, non_neg=True, approx=False,
+                             verbose=False)
+    assert Dl.min() >= 0 and np.allclose(np.linalg.norm(Dl, axis=0), 1.0, atol=1e-5)
+
+
 @pytest.mark.parametrize("n,K,k,N", [(200, 48, 4, 700), (100, 40, 3, 300), (16, 24, 2, 30),
                                      (700, 60, 3, 400), (401, 12, 3, 600), (1030, 40, 4, 200)])
 def test_exact_ksvd_other_shapes(eng, n, K, k, N):
@@ -696,10 +755,14 @@ def _sharded_worker(rank, world, port, out, backend="gloo"):
         np.random.seed(99)                                   # same RNG state on every rank
         Dk, _ = ksvd_dict_learn(Xl, 48, init_dict='data', sparse_coder=se, max_iter=2, approx=True, verbose=False,
                                 return_codes=False, group=dist.group.WORLD, shard_span=span, n_total=X.shape[1])
+        # eta (force_mi, ksvd.py:209-213) on shards: replicated decision from all-reduced code-row norms
+        np.random.seed(97)
+        Dke, _ = ksvd_dict_learn(Xl, 48, init_dict='data', sparse_coder=se, max_iter=3, approx=True, eta=0.5, verbose=False,
+                                 return_codes=False, group=dist.group.WORLD, shard_span=span, n_total=X.shape[1])
         Xb, lbs = ld.shard_minibatches(X, 500)
         Do, Ao, Bo = online_dict_learn(Xb, K, sparse_coder=se, batch_size=lbs, D_init=D0.copy(), beta=0.9, n_epochs=1,
                                        group=dist.group.WORLD)
-        res.update(Dk=Dk, Do=Do, Ao=Ao)
+        res.update(Dk=Dk, Do=Do, Ao=Ao, Dke=Dke)
         # ---- exact rank-1 update on shards: one Gram-matrix all-reduce per atom
         dd2 = eng.DeviceDictionary.from_host(D0)
         i2, c2, z2 = eng.bomp_encode(Xs, dd2, k)
@@ -836,6 +899,14 @@ def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
     Dk, _ = ksvd_dict_learn(X, 48, init_dict='data', sparse_coder=se, max_iter=2, approx=True, verbose=False,
                             return_codes=False)
     assert np.array_equal(r0["Dk"], r1["Dk"]) and _atom_err(r0["Dk"], Dk) < 1e-4
+    np.random.seed(97)
+    Dke, _ = ksvd_dict_learn(X, 48, init_dict='data', sparse_coder=se, max_iter=3, approx=True, eta=0.5, verbose=False,
+                             return_codes=False)
+    np.random.seed(97)
+    Dk0, _ = ksvd_dict_learn(X, 48, init_dict='data', sparse_coder=se, max_iter=3, approx=True, verbose=False,
+                             return_codes=False)
+    assert _atom_err(Dke, Dk0) > 1e-2                    # eta = 0.5 did replace atoms on this data
+    assert np.array_equal(r0["Dke"], r1["Dke"]) and _atom_err(r0["Dke"], Dke) < 1e-4
     Do, Ao, Bo = online_dict_learn(X, D0.shape[1], sparse_coder=se, batch_size=500, D_init=D0.copy(), beta=0.9,
                                    n_epochs=1)
     assert np.array_equal(r0["Do"], r1["Do"]) and _atom_err(r0["Do"], Do) < 1e-4

@@ -142,6 +142,24 @@ def test_exact_ksvd_matches_reference():
         D = Dr.copy()
 
 
+@pytest.mark.parametrize("cycles", [0, 1, 3])
+def test_nn_ksvd_matches_reference(cycles):
+    """ksvd.py:46-95 on F14 (the reference's own seeded run): atoms, codes, unused atoms, the zero a clip creates.  The
+    reference's solver returned u . d_old >= 0 for every atom of this fixture (recorded signs), i.e. the restatement's
+    convention, so the comparison is direct."""
+    g = load_golden("F14")
+    X, D0, Z0 = g["X"].astype(np.float64), g["D0"].astype(np.float64), g["Z0"].astype(np.float64)
+    signs = g["c%d_signs" % cycles]
+    assert np.all(signs > 0)
+    D1, Z1, unused = orc.nn_ksvd(X, D0.copy(), Z0.copy(), n_cycles=cycles, signs=signs)
+    assert list(unused) == list(g["c%d_unused" % cycles])
+    assert np.max(np.abs(D1 - g["c%d_D" % cycles])) <= 1e-9
+    assert np.max(np.abs(Z1 - g["c%d_Z" % cycles])) <= 1e-9 * np.abs(Z1).max()
+    assert np.array_equal(Z1 != 0, g["c%d_Z" % cycles] != 0)
+    assert D1.min() >= 0 and Z1.min() >= 0
+    assert np.allclose(np.linalg.norm(D1, axis=0), 1.0, atol=1e-12)
+
+
 @pytest.mark.parametrize("verbose", [True, False])
 def test_ksvd_driver_matches_reference(verbose):
     """Host control flow: patience quirk (11 encode calls for max_iter=50) and global-RNG consumption."""
