@@ -181,6 +181,7 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     float* base = dnew + (size_t)B * NF;
     float* stot = base + (size_t)B * NF;
     float* QC = stot + (size_t)B * NF;
+    float* tpart = QC + (size_t)MAXG * (NF + B);  // [2][16 teams][NF]: per-team sums of the groups beyond the staging capacity
     const double* bb = bbuf + (int64_t)c * lay.stride;
     const int tid = threadIdx.x, lane = tid & 63, team = tid >> 4, q = tid & 15;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -269,12 +270,16 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     constexpr int NT = 16;  // teams in the atom loop (measured round 3: 4 teams = one wave, no rendezvous: 11.5 us for 8 atoms; 8 teams: 9.5; 16: 8)
     const bool active = tid < 16 * NT;
     int arrivals = 0;  // in-loop rendezvous taken so far (uniform over the active waves)
+    int par = 0;       // tpart buffer of the next atom with overflow groups: a team that is ahead writes the OTHER buffer
     for (int t = 0; active && t < B; ++t) {
         const int a = c * B + t;
         if (a >= K) break;
         if (s_cnt[t] == 0.f) continue;  // unused atom keeps its column (ksvd.py:112-115): dnew[t] == dold[t]; uniform
         // groups with target t: team j evaluates list entries gfirst[t] + j, + NT, ..
         const int lbeg = gfirst[t], lend = gfirst[t + 1];
+        float4 ov[FB];  // this team's groups beyond the staging capacity, summed in list order
+#pragma unroll
+        for (int b = 0; b < FB; ++b) ov[b] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int li = lbeg + team; li < lend; li += NT) {
             const int g = glist[li];
             const int sl = gslot[g];
@@ -329,15 +334,26 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
                 float* dst = QC + (size_t)sl * (NF + B);
 #pragma unroll
                 for (int b = 0; b < FB; ++b) *reinterpret_cast<float4*>(dst + 64 * b + 4 * q) = u[b];
-            } else {  // group beyond the staging capacity (not seen in practice): unordered LDS atomics
+            } else {
+                // group beyond the staging capacity (small dictionaries with many signals: K = 48 has > 64 occupied groups
+                // per block): into this team's private sum -- list order inside a team, team order below.  (Unordered LDS
+                // atomics here made the replicas of a 2-rank run differ in the last bit of a block's LAST atom, the target
+                // with the most groups.)
 #pragma unroll
                 for (int b = 0; b < FB; ++b) {
-                    atomicAdd(&stot[t * NF + 64 * b + 4 * q + 0], u[b].x);
-                    atomicAdd(&stot[t * NF + 64 * b + 4 * q + 1], u[b].y);
-                    atomicAdd(&stot[t * NF + 64 * b + 4 * q + 2], u[b].z);
-                    atomicAdd(&stot[t * NF + 64 * b + 4 * q + 3], u[b].w);
+                    ov[b].x += u[b].x;
+                    ov[b].y += u[b].y;
+                    ov[b].z += u[b].z;
+                    ov[b].w += u[b].w;
                 }
             }
+        }
+        const bool overflow = lend > MAXG && lend > lbeg;  // uniform
+        float* tp = tpart + (size_t)par * 16 * NF;
+        if (overflow) {
+            par ^= 1;
+#pragma unroll
+            for (int b = 0; b < FB; ++b) *reinterpret_cast<float4*>(tp + team * NF + 64 * b + 4 * q) = ov[b];
         }
         if (lend > lbeg) {  // uniform over the active waves: every team's slots are written before any team sums them
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -356,7 +372,16 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
 #pragma unroll
         for (int b = 0; b < FB; ++b) {
             const float4 b4 = *reinterpret_cast<const float4*>(base + t * NF + 64 * b + 4 * q);
-            float4 s4 = *reinterpret_cast<const float4*>(stot + t * NF + 64 * b + 4 * q);
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (overflow) {
+                for (int j = 0; j < NT; ++j) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(tp + j * NF + 64 * b + 4 * q);
+                    s4.x += p4.x;
+                    s4.y += p4.y;
+                    s4.z += p4.z;
+                    s4.w += p4.w;
+                }
+            }
             // the list position IS the staging slot (both count the non-empty groups in ascending order): no indirection
             const int lstop = (lend < MAXG) ? lend : MAXG;
 #pragma unroll 4
@@ -1221,7 +1246,7 @@ static size_t group_lds_bytes(int n, int B) {  // LDS slots of X(c)'s group phas
 static size_t narrow_lds_bytes(int n, int B) {
     const size_t nf = (size_t)((n + 63) / 64) * 64;
     (void)n;
-    return ((size_t)4 * B * nf + (size_t)bk_maxg(B) * (nf + B)) * sizeof(float);
+    return ((size_t)4 * B * nf + (size_t)bk_maxg(B) * (nf + B) + (size_t)2 * 16 * nf) * sizeof(float);
 }
 
 // The lazy schedule needs the predecessor fields of the index records, which only the k <= 16 index builder writes

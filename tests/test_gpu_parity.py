@@ -753,7 +753,7 @@ def _sharded_worker(rank, world, port, out, backend="gloo"):
         from lyssandra_amd.sparse_coding import sparse_encoder
         se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
         np.random.seed(99)                                   # same RNG state on every rank
-        Dk, _ = ksvd_dict_learn(Xl, 48, init_dict='data', sparse_coder=se, max_iter=2, approx=True, verbose=False,
+        Dk, _ = ksvd_dict_learn(Xl, 48, init_dict='data', sparse_coder=se, max_iter=4, approx=True, verbose=False,
                                 return_codes=False, group=dist.group.WORLD, shard_span=span, n_total=X.shape[1])
         # eta (force_mi, ksvd.py:209-213) on shards: replicated decision from all-reduced code-row norms
         np.random.seed(97)
@@ -896,9 +896,11 @@ def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
     from lyssandra_amd.sparse_coding import sparse_encoder
     se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
     np.random.seed(99)
-    Dk, _ = ksvd_dict_learn(X, 48, init_dict='data', sparse_coder=se, max_iter=2, approx=True, verbose=False,
+    Dk, _ = ksvd_dict_learn(X, 48, init_dict='data', sparse_coder=se, max_iter=4, approx=True, verbose=False,
                             return_codes=False)
-    assert np.array_equal(r0["Dk"], r1["Dk"]) and _atom_err(r0["Dk"], Dk) < 1e-4
+    # four alternations: K = 48 has more occupied tuple groups per block than the narrow step stages (its overflow sums were
+    # unordered LDS atomics until round 4: replicas differed in the last bit from the third alternation on)
+    assert np.array_equal(r0["Dk"], r1["Dk"]) and _atom_err(r0["Dk"], Dk) < 1e-3
     np.random.seed(97)
     Dke, _ = ksvd_dict_learn(X, 48, init_dict='data', sparse_coder=se, max_iter=3, approx=True, eta=0.5, verbose=False,
                              return_codes=False)
