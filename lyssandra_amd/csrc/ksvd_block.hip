@@ -277,9 +277,15 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
         if (s_cnt[t] == 0.f) continue;  // unused atom keeps its column (ksvd.py:112-115): dnew[t] == dold[t]; uniform
         // groups with target t: team j evaluates list entries gfirst[t] + j, + NT, ..
         const int lbeg = gfirst[t], lend = gfirst[t + 1];
-        float4 ov[FB];  // this team's groups beyond the staging capacity, summed in list order
+        // groups beyond the staging capacity (list index >= MAXG) are summed per team, in list order, into the team's own
+        // LDS row (a register accumulator here cost 20 bytes of scratch per lane), and the 16 rows in team order below
+        const bool overflow = lend > MAXG && lend > lbeg;  // uniform
+        float* tp = tpart + (size_t)par * 16 * NF;
+        if (overflow) {
+            par ^= 1;
 #pragma unroll
-        for (int b = 0; b < FB; ++b) ov[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = 0; e < 4 * FB; ++e) tp[team * NF + 64 * (e >> 2) + 4 * q + (e & 3)] = 0.f;
+        }
         for (int li = lbeg + team; li < lend; li += NT) {
             const int g = glist[li];
             const int sl = gslot[g];
@@ -341,19 +347,13 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
                 // with the most groups.)
 #pragma unroll
                 for (int b = 0; b < FB; ++b) {
-                    ov[b].x += u[b].x;
-                    ov[b].y += u[b].y;
-                    ov[b].z += u[b].z;
-                    ov[b].w += u[b].w;
+                    float* row = tp + team * NF + 64 * b + 4 * q;  // (scalar accesses: a float4 temporary here went to scratch)
+                    row[0] += u[b].x;
+                    row[1] += u[b].y;
+                    row[2] += u[b].z;
+                    row[3] += u[b].w;
                 }
             }
-        }
-        const bool overflow = lend > MAXG && lend > lbeg;  // uniform
-        float* tp = tpart + (size_t)par * 16 * NF;
-        if (overflow) {
-            par ^= 1;
-#pragma unroll
-            for (int b = 0; b < FB; ++b) *reinterpret_cast<float4*>(tp + team * NF + 64 * b + 4 * q) = ov[b];
         }
         if (lend > lbeg) {  // uniform over the active waves: every team's slots are written before any team sums them
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -374,12 +374,13 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
             const float4 b4 = *reinterpret_cast<const float4*>(base + t * NF + 64 * b + 4 * q);
             float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (overflow) {
+#pragma unroll 4
                 for (int j = 0; j < NT; ++j) {
-                    const float4 p4 = *reinterpret_cast<const float4*>(tp + j * NF + 64 * b + 4 * q);
-                    s4.x += p4.x;
-                    s4.y += p4.y;
-                    s4.z += p4.z;
-                    s4.w += p4.w;
+                    const float* pr = tp + j * NF + 64 * b + 4 * q;
+                    s4.x += pr[0];
+                    s4.y += pr[1];
+                    s4.z += pr[2];
+                    s4.w += pr[3];
                 }
             }
             // the list position IS the staging slot (both count the non-empty groups in ascending order): no indirection

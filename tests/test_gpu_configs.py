@@ -104,20 +104,21 @@ def test_approx_ksvd_sweep_dense_coupling_many_signals(eng, n, K, k, N, monkeypa
         assert ae < 1e-5 and ce < 1e-5 and abs(err_dev - err_o) / err_o < 1e-5
 
 
-def test_ksvd_alternation_config2_shape_five_iterations(eng):
+def _ksvd_chain(eng, N, iters, seed, min_ok):   # min_ok: allowed fraction of tie signals
     """configs[1] as a CHAIN (lyssa/dict_learning/ksvd.py:169-229: encode -> approx_ksvd -> unused-atom replacement -> encode
-    ...), 5 iterations at 2^18 patches, K = 1024, k = 10, every link graded against the float64 C restatement:
+    ...) at K = 1024, k = 10, every link graded against the float64 C restatement:
       * encode of iteration t: oracle Batch-OMP with the GPU's current dictionary -- identical supports and order on every
         no-tie signal (gap >= 1e-5), coefficients to 1e-5 of max|z| (tie-aware: tie signals are counted, not compared);
       * sweep of iteration t: oracle approx_ksvd from the GPU's codes -- atoms / codes / error to 1e-5;
-      * unused atoms: identical lists, replaced by the same (seeded) data samples on both sides.
+      * unused atoms: identical lists, replaced by the same (seeded) data samples on both sides;
+      * the noise-floor stop (NOISE_REL, csrc/bomp.hip) is COUNTED: every signal the engine stops before the oracle does must
+        be an exactly-representable one (an initial / replacement sample, coded by one atom with a rounding-noise residual).
     Multi-iteration drift is what the single-cycle tests cannot see: the dictionary the GPU carries into iteration t + 1 is
-    its own output, so an error that compounds shows up as a failing link at a later iteration; the error sequence of the
-    whole chain is also compared with a chain driven by the oracle's sweeps (loose: one tie flip changes a support)."""
+    its own output, so an error that compounds shows up as a failing link at a later iteration."""
     import torch
     from oracle import c_oracle
-    n, K, k, N, iters = 64, 1024, 10, 1 << 18, 5
-    gen = torch.Generator(device="cuda").manual_seed(2024)
+    n, K, k = 64, 1024, 10
+    gen = torch.Generator(device="cuda").manual_seed(seed)
     Xs = torch.randn((N, n), device="cuda", generator=gen)
     X = Xs.t().contiguous().double().cpu().numpy()
     rs = np.random.RandomState(7)
@@ -133,7 +134,8 @@ def test_ksvd_alternation_config2_shape_five_iterations(eng):
     is_atom[sel] = True
     dd = eng.DeviceDictionary.from_host(D0)
     buffers, out, R = {}, None, None
-    errs_gpu, n_ties, n_unused_tot = [], 0, 0
+    errs_gpu, errs_orc, n_ties, n_unused_tot, n_noise = [], [], 0, 0, 0
+    worst = [0.0, 0.0, 0.0]
     for it in range(iters):
         Dcur = dd.D[:K, :n].t().contiguous().double().cpu().numpy()
         out = eng.bomp_encode(Xs, dd, k, out=out)
@@ -142,9 +144,17 @@ def test_ksvd_alternation_config2_shape_five_iterations(eng):
         oi, oc, on, gap = c_oracle.bomp_encode_sparse(X, Dcur, k)
         ok = (gap >= 1e-5) & ~is_atom
         n_ties += int((gap < 1e-5).sum())
-        assert ok.mean() > 0.98, (it, ok.mean())
+        # iteration 0 carries the deliberate duplicate atom: every signal that selects it has a zero gap (about 1 % of them)
+        # otherwise: everything but the exactly-representable samples and the measured tie rate (0.14 % on Gaussian signals)
+        assert ok.mean() > 1.0 - is_atom.mean() - (min_ok if it > 0 else 0.015), (it, ok.mean())
         assert np.array_equal(hi[ok], oi[ok]) and np.array_equal(hn[ok], on[ok]), "iteration %d: support mismatch" % it
         assert (hn[is_atom] >= 1).all() and (hi[is_atom, 0] == oi[is_atom, 0]).all()      # the exact atom is found first
+        # noise-floor stops: where the engine selected fewer atoms than the float64 oracle.  Only exactly-representable
+        # signals may do that (on a tie signal a different atom may be picked, never fewer atoms)
+        early = hn < on
+        assert not (early & ~is_atom).any(), (it, np.flatnonzero(early & ~is_atom)[:10])
+        n_noise += int(early.sum())
+        assert int(early.sum()) <= int(is_atom.sum())
         scale = np.abs(oc).max(axis=1, keepdims=True)
         assert np.max((np.abs(hc - oc) / scale)[ok]) < 1e-5, "iteration %d: coefficients" % it
         R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False, out=R)
@@ -156,17 +166,41 @@ def test_ksvd_alternation_config2_shape_five_iterations(eng):
         ae = _atom_err(Dg, Do)
         ce = np.max(np.abs(coef.double().cpu().numpy() - co)) / np.abs(co).max()
         assert ae < 1e-5 and ce < 1e-5 and abs(err - err_o) < 1e-5 * err_o, (it, ae, ce, err, err_o)
+        worst = [max(worst[0], ae), max(worst[1], ce), max(worst[2], abs(err - err_o) / err_o)]
         errs_gpu.append(err)
+        errs_orc.append(err_o)
         # unused-atom replacement with seeded data samples (the reference draws them from the global RNG, ksvd.py:219-229)
         n_unused_tot += len(unused)
         for a in unused:
             j = rs.randint(N)
             is_atom[j] = True
             dd.set_atom(a, X[:, j] / np.linalg.norm(X[:, j]))
-        print("iteration %d: %d tie signals, %d unused atoms, atom err %.2g, code err %.2g, error %.8g (oracle sweep %.8g)"
-              % (it, int((gap < 1e-5).sum()), len(unused), ae, ce, err, err_o))
+        if it < 5 or it % 10 == 9:
+            print("iteration %d: %d tie signals, %d unused atoms, %d noise-floor stops (of %d exact signals), atom err %.2g, "
+                  "code err %.2g, error %.8g (oracle sweep %.8g)"
+                  % (it, int((gap < 1e-5).sum()), len(unused), int(early.sum()), int(is_atom.sum()), ae, ce, err, err_o))
+    print("%d iterations at N = %d: worst link atom err %.2g, code err %.2g, error value %.2g; %d tie signal-iterations, "
+          "%d noise-floor stops in total" % (iters, N, worst[0], worst[1], worst[2], n_ties, n_noise))
     assert n_unused_tot >= 1                                   # the duplicate atom made the replacement path run
-    assert all(b < a for a, b in zip(errs_gpu, errs_gpu[1:]))  # the alternation keeps lowering the objective
+    # the error curve of the chain (within 1e-5 of the reference's at every link, graded above) falls; link by
+    # link only over the first iterations (greedy codes give no monotonicity guarantee: late in the 50-iteration chain single
+    # links rise by 1e-4 relative, in the float64 oracle's curve exactly as in the GPU's)
+    assert all(b < a for a, b in zip(errs_gpu[:5], errs_gpu[1:5])) and errs_gpu[-1] < errs_gpu[0]
+    return errs_gpu, errs_orc
+
+
+def test_ksvd_alternation_config2_shape_five_iterations(eng):
+    """5 alternations at 2^18 patches, every link graded (see _ksvd_chain)."""
+    _ksvd_chain(eng, 1 << 18, 5, 2024, 3e-3)
+
+
+def test_ksvd_alternation_config2_shape_fifty_iterations(eng):
+    """configs[1] as BASELINE.json states it -- 50 alternations -- at 2^16 patches (the float64 C oracle regrades every link in
+    about a second): the error curve within 1e-5 of the oracle's at each of the 50 links (ksvd.py:169-229)."""
+    errs_gpu, errs_orc = _ksvd_chain(eng, 1 << 16, 50, 2025, 3e-3)
+    assert len(errs_gpu) == 50
+    assert max(abs(a - b) / b for a, b in zip(errs_gpu, errs_orc)) < 1e-5
+    assert errs_gpu[-1] < 0.9 * errs_gpu[0]                      # measured 0.858 on Gaussian patches
 
 
 # ------------------------------------------------------------------------------------------------ config 4 shape
@@ -222,6 +256,50 @@ def test_online_dl_config4_shape(eng):
               "B err %.2e, atom err %.2e" % (b, hn.mean(), hn.max(), int(br.max()), st.max(), kkt, ea, eb, ed))
         assert ea < 1e-5 and eb < 1e-5 and ed < 1e-5
         dd.set(Do)                                                   # next batch starts from the oracle's dictionary
+
+
+def test_online_dl_long_horizon_accumulation(eng):
+    """lyssa/dict_learning/online_dict_learn.py:62-98 over 128 mini-batches with beta=None (the linspace that converges to 1:
+    A and B then sum EVERY batch, and the update forms B - D A, a cancellation): n = 64, K = 1024, batch 2048, k = 10.  The
+    float64 shadow accumulates A and B from the GPU's OWN codes (support flips cannot enter) and redoes every dictionary
+    update from the GPU's current dictionary; after every 16th batch A, B to 1e-5 of their maxima, every update's atoms to
+    1e-5.  (The device keeps A and B in fp32: this is the test that says whether that holds over an epoch.)"""
+    import torch
+    from oracle import lyssa_oracle as orc
+    n, K, k, bs, nbatch = 64, 1024, 10, 2048, 128
+    gen = torch.Generator(device="cuda").manual_seed(404)
+    Dt = torch.randn((n, K), device="cuda", generator=gen)
+    Dt = Dt / Dt.norm(dim=0, keepdim=True)
+    # signals with structure (sparse combinations of a hidden dictionary + noise) so that B ~ D A: the cancellation is real
+    Dh = torch.randn((K, n), device="cuda", generator=gen)
+    Dh = Dh / Dh.norm(dim=1, keepdim=True)
+    sel = torch.randint(0, K, (bs * nbatch, 4), device="cuda", generator=gen)
+    w = torch.randn((bs * nbatch, 4), device="cuda", generator=gen)
+    Xs = (Dh[sel] * w[:, :, None]).sum(1) + 0.05 * torch.randn((bs * nbatch, n), device="cuda", generator=gen)
+    dd = eng.DeviceDictionary(n, K)
+    dd.set(Dt)
+    state = eng.OdlState(dd)
+    beta = np.linspace(0, 1, num=nbatch)                                    # online_dict_learn.py:66-68
+    A64, B64 = np.zeros((K, K)), np.zeros((n, K))
+    worst_a = worst_b = worst_d = 0.0
+    out = None
+    for i in range(nbatch):
+        xb = Xs[i * bs:(i + 1) * bs]
+        Dcur = dd.to_host()
+        idx, coef, nnz = out = eng.bomp_encode(xb, dd, k, out=out)
+        Zb = eng.densify(idx, coef, nnz, K)                                 # the GPU's own codes, float64 (K, bs)
+        state.batch_update(xb, idx, coef, nnz, float(beta[i]))
+        Do, A64, B64 = orc.odl_batch_update(Dcur.copy(), A64, B64, xb.t().double().cpu().numpy(), Zb, beta[i])
+        de = _atom_err(dd.to_host(), Do)
+        worst_d = max(worst_d, de)
+        assert de < 1e-5, (i, de)
+        if i % 16 == 15:
+            ea = np.max(np.abs(state.A_host() - A64)) / np.abs(A64).max()
+            eb = np.max(np.abs(state.B_host() - B64)) / np.abs(B64).max()
+            worst_a, worst_b = max(worst_a, ea), max(worst_b, eb)
+            print("batch %3d (beta %.3f): A err %.2e, B err %.2e of max, worst atom err so far %.2e" % (i, beta[i], ea, eb, worst_d))
+            assert ea < 1e-5 and eb < 1e-5, (i, ea, eb)
+    print("128 mini-batches: A %.2e, B %.2e, atoms %.2e" % (worst_a, worst_b, worst_d))
 
 
 # ------------------------------------------------------------------------------------------------ config 3 shard

@@ -1298,8 +1298,13 @@ def test_bomp_direct_parity_262144_signals(eng, alpha0_mode):
     n_tie = int((~ok).sum())
     n_tie_diff = int((idx[~ok] != oi[~ok]).any(axis=1).sum())
     print("N=%d tie signals (gap < 1e-5): %d, of which selected differently: %d" % (N, n_tie, n_tie_diff))
-    assert n_tie < 0.01 * N
+    assert n_tie < 3e-3 * N                      # measured 0.14 % on Gaussian signals (profiles/r03_soak_parity.txt)
     assert np.array_equal(idx[ok], oi[ok]) and np.array_equal(nnz[ok], on[ok])       # identical supports AND order
+    # the noise-floor stop (NOISE_REL, csrc/bomp.hip): Gaussian signals have no exactly-representable member, so NO signal
+    # may end with fewer atoms than the float64 oracle selects -- tie signals included (a tie changes which atom, not how many)
+    n_early = int((nnz < on).sum())
+    print("signals stopped before the oracle's atom count: %d" % n_early)
+    assert n_early == 0
     scale = np.abs(oc).max(axis=1, keepdims=True)
     worst = np.max((np.abs(coef - oc) / scale)[ok])
     print("worst coefficient error relative to max|z|: %.3g" % worst)
@@ -1358,7 +1363,9 @@ def test_bomp_template_sweep(eng, n, K, k, alpha0_mode):
     X = Xs.t().contiguous().double().cpu().numpy()
     oi, oc, on, gap = c_oracle.bomp_encode_sparse(X, D, k)
     ok = gap >= TIE_GAP
-    assert ok.mean() > 0.9
+    # measured tie rates: <= 0.5 % for n >= 32; small n with k close to n / 2 (residuals near the fp32 noise floor) more
+    print("n=%d K=%d k=%d: %.2f %% of the signals graded (no tie along the path)" % (n, K, k, 100 * ok.mean()))
+    assert ok.mean() > (0.99 if n >= 32 else 0.9)
     assert np.array_equal(idx[ok], oi[ok]) and np.array_equal(nnz[ok], on[ok])
     scale = np.abs(oc).max(axis=1, keepdims=True)
     assert np.max((np.abs(coef - oc) / scale)[ok]) < COEF_TOL
@@ -1381,7 +1388,8 @@ def test_omp_template_sweep(eng, n, K, k):
     Zo, gap = orc.omp_encode(X, D, k, want_gap=True)
     ok = gap >= TIE_GAP                                             # graded per no-tie signal with the recorded gap
     same = np.array([np.array_equal(Z[:, i] != 0, Zo[:, i] != 0) for i in range(N)])
-    assert ok.mean() > 0.9 and same[ok].all(), np.flatnonzero(ok & ~same)[:10]
+    print("omp n=%d K=%d k=%d: %.2f %% graded" % (n, K, k, 100 * ok.mean()))
+    assert ok.mean() > (0.98 if n >= 32 else 0.9) and same[ok].all(), np.flatnonzero(ok & ~same)[:10]
     err = (np.abs(Z - Zo)[:, ok].max(axis=0) / np.abs(Zo)[:, ok].max(axis=0)).max()
     assert err < COEF_TOL, err
 
