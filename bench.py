@@ -43,6 +43,17 @@ PEAK_HBM_GBS = 8000.0
 SEED_SIGNALS, SEED_DICTIONARY = 20260928, 1234
 
 
+def kernel_source_sha():
+    """sha1 over the sources of the two kernels of the encode step (greedy kernel + alpha0 GEMM): the recorded PMC traffic and
+    rocprofv3 averages in profiles/ carry the fingerprint they were taken on (tools/summarize_profile.py)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("bomp_wave2.h", "bomp_wave.hip", "gemm.hip", "common.h"):
+        with open(os.path.join(ROOT, "lyssandra_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def flops_per_signal(n, K, k):
     """F = 2nK (alpha0) + K k (k+1) (correlation updates) + k^3 (Cholesky/solves)."""
     return 2 * n * K, K * k * (k + 1) + k ** 3
@@ -203,6 +214,12 @@ def main():
                 rocprof = json.load(open(dpath))
             except Exception:
                 rocprof = {}
+        # the recorded figures (PMC traffic, rocprofv3 averages) were taken on named kernels: flag them when the build no
+        # longer launches those (tools/profile.sh rewrites the files; until then the numbers describe another kernel)
+        greedy_kernel, gemm_kernel = "bomp_wave2_kernel<16,10,3,2,1>", ("alpha0_n64_bf16x3_kernel" if bf16x3 else
+                                                                        "alpha0_n64_kernel")
+        traffic_stale = bool(rocprof) and (rocprof.get("kernel_source_sha") != kernel_source_sha()
+                                           or rocprof.get("alpha0_n64_kernel_name") != gemm_kernel)
         result = {
             "metric": "patches/sec Batch-OMP (1024 atoms, k=10, 64-dim)",
             "value": value,
@@ -227,13 +244,14 @@ def main():
                 # the contract's vocabulary is "hbm" | "mfma"; this kernel issues no MFMA (SQ_INSTS_MFMA = 0): it is bound by
                 # VALU issue, and the fp32 vector peak equals the fp32 matrix peak (157.3 TFLOP/s)
                 "bound": "valu",
-                "kernel": "w2::bomp_wave2_kernel<16,10,3,2,1> (greedy argmax + progressive Cholesky, one wave per signal; "
+                "kernel": "w2::" + greedy_kernel + " (greedy argmax + progressive Cholesky, one wave per signal; "
                           "2 vectors in LDS, the last one never stored)",
                 "achieved": omp_tf,
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": omp_tf / PEAK_FP32_TFLOPS,
                 "traffic": traffic,
+                "traffic_stale": traffic_stale,
                 "bytes_8d_per_launch": bytes_8d * sig_per_launch,
                 "traffic_ratio_8d": (traffic / (bytes_8d * sig_per_launch)) if traffic else None,
                 "traffic_ratio_8d_whole_step": ((traffic + gemm_traffic) / (bytes_8d * sig_per_launch))
@@ -281,7 +299,8 @@ def main():
             if rank == 0:
                 result["odl_batch"] = ob
     if world == 1 and not args.no_aux:
-        for name, fn in (("config3_shard", config3_shard), ("config4_minibatch", config4_minibatch)):
+        for name, fn in (("config1_host", config1_host), ("config3_shard", config3_shard),
+                         ("config4_minibatch", config4_minibatch)):
             try:
                 result[name] = fn(synth)
             except Exception as e:  # pragma: no cover
@@ -474,6 +493,68 @@ def _profiled_encode(fn, reps):
                "lys_profile_collect")
     _lib.check(lib.lys_profile_enable(0), "lys_profile_enable")
     return g_ms.value / reps, o_ms.value / reps, wall
+
+
+def config1_host(synth, N=10000, reps=7):
+    """Auxiliary: configs[0] ("Batch-OMP encode 10k random 64-dim patches, 256-atom random dict, k=5") through the DROP-IN
+    boundary as the reference's caller uses it (lyssa/sparse_coding.py:600-635, 708-726): host float64 (n, N) in, dense
+    float64 (K, N) out -- `sparse_encoder.encode` -- and `encode_sparse` (host in, device triplet out); PCIe and the host
+    conversions are INSIDE these times (never part of `value`).  The library-owned context (`lys_ctx_bomp_encode`, host
+    arrays in / host triplet out) splits the same call into host->device, kernels, device->host with its own HIP events."""
+    import numpy as np
+    import torch
+    from lyssandra_amd import _lib
+    from lyssandra_amd.sparse_coding import sparse_encoder
+    n, K, k = 64, 256, 5
+    rs = np.random.RandomState(SEED_DICTIONARY)
+    D = rs.randn(n, K)
+    D /= np.linalg.norm(D, axis=0)
+    X = rs.randn(n, N)
+    se = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': k}, verbose=False)
+    se.encode(X[:, :256], D)
+
+    def med(fn):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+    t_dense = med(lambda: se.encode(X, D))
+    t_sparse = med(lambda: se.encode_sparse(X, D))
+    # the same call through the plain-C context: stage split by the library's HIP events
+    lib = _lib.load()
+    Xh = np.ascontiguousarray(X.T, dtype=np.float32)
+    Dh = np.ascontiguousarray(D.T, dtype=np.float32)
+    idx, coef, nnz = np.empty((N, k), np.int32), np.empty((N, k), np.float32), np.empty((N,), np.int32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    ctx = ctypes.c_void_p()
+    _lib.check(lib.lys_ctx_create(torch.cuda.current_device(), ctypes.byref(ctx)), "lys_ctx_create")
+    try:
+        _lib.check(lib.lys_ctx_set_dictionary(ctx, P(Dh), n, K), "lys_ctx_set_dictionary")
+        stages = []
+        for _ in range(reps + 1):
+            _lib.check(lib.lys_ctx_bomp_encode(ctx, P(Xh), N, k, P(idx), P(coef), P(nnz)), "lys_ctx_bomp_encode")
+            ms4 = (ctypes.c_double * 4)()
+            _lib.check(lib.lys_ctx_timings(ctx, ms4), "lys_ctx_timings")
+            stages.append(list(ms4))
+        stages = sorted(stages[1:], key=lambda m: m[3])[len(stages[1:]) // 2]
+    finally:
+        lib.lys_ctx_destroy(ctx)
+    return {"workload": "configs[0]: Batch-OMP encode of %d random 64-dim patches, 256-atom random dictionary, k=5, through the "
+                        "drop-in class with HOST float64 arrays (median of %d calls)" % (N, reps),
+            "encode_dense_float64": {"ms": t_dense, "patches_per_s": N / (t_dense * 1e-3),
+                                     "result_bytes": 8 * K * N,
+                                     "note": "host float64 (n,N) -> device fp32, encode, dense float64 (K,N) written on the "
+                                             "device and copied into a page-locked host array"},
+            "encode_sparse": {"ms": t_sparse, "patches_per_s": N / (t_sparse * 1e-3),
+                              "note": "host float64 in, device-resident sparse triplet out"},
+            "c_abi_context": {"ms": {"host_to_device": stages[0], "kernels": stages[1], "device_to_host": stages[2],
+                                     "sum": stages[3]},
+                              "patches_per_s": N / (stages[3] * 1e-3),
+                              "note": "lys_ctx_bomp_encode: host fp32 [N][n] in, host triplet out; stages from lys_ctx_timings"},
+            "unit": "patches/s (PCIe-inclusive; never `value`)"}
 
 
 def config3_shard(synth, N=1 << 17, reps=5):

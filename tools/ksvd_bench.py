@@ -34,6 +34,7 @@ for it in range(iters):
     unused, t_sweep = timed(lambda: cycle(R, dd, idx, coef, nnz, buffers=buffers))
     err, t_err = timed(lambda: engine.approx_error(Xs, dd, idx, coef, nnz))
     nnz_tot = int(nnz.sum().item())
-    gbs = 3 * 4 * n * nnz_tot / (t_sweep * 1e-3) / 1e9
-    print("it %d: encode %.2f ms | residual %.2f ms | csr+sweep %.2f ms (%.0f GB/s algorithmic, %.1f%% of 8 TB/s) | "
-          "error %.2f ms | err=%.6g unused=%d" % (it, t_enc, t_res, t_sweep, gbs, gbs / 80.0, t_err, err, len(unused)))
+    gbs = 8 * n * nnz_tot / (t_sweep * 1e-3) / 1e9          # 8n bytes per non-zero, the model bench.py prices with
+    print("it %d: encode %.2f ms | residual %.2f ms | csr+sweep %.2f ms (%.0f GB/s by SURVEY 8(d)'s 8n bytes per non-zero, "
+          "%.1f%% of 8 TB/s) | error %.2f ms | err=%.6g unused=%d"
+          % (it, t_enc, t_res, t_sweep, gbs, gbs / 80.0, t_err, err, len(unused)))

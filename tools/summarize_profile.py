@@ -69,4 +69,8 @@ if json_out:
             durations[field + "_tcc_hit"] = c["TCC_HIT_sum"]
             durations[field + "_tcc_miss"] = c.get("TCC_MISS_sum")
     durations["source"] = "rocprofv3 --kernel-trace --stats of `python bench.py` (tools/profile.sh), averages over all launches"
+    # fingerprint of the kernel sources these figures were taken on: bench.py flags them `traffic_stale` when the tree differs
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha
+    durations["kernel_source_sha"] = kernel_source_sha()
     json.dump(durations, open(json_out, "w"), indent=1)
