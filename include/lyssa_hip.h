@@ -94,6 +94,16 @@ int lys_set_alpha0_bf16x3(int mode);
 /* Only the alpha0 = X D GEMM of the above (timing / MFMA-stage measurement). alpha0 is [N][Kp]. */
 int lys_alpha0(const float* X, int64_t ldx, const float* D_packed, int n, int K, int64_t N,
                float* alpha0, void* stream);
+/*
+ * The same product on the bf16 matrix cores at fp32 accuracy -- the kernels lys_bomp_encode / lys_omp_encode /
+ * lys_thresh_encode run when their workspace carries room for the dictionary's bf16 planes: every fp32 operand split into
+ * three bf16 planes, the six products with i + j <= 4 accumulated in fp32 (n <= 64: signal-tile-stationary kernel; n > 64,
+ * round 4: k-looped 128 x 128 GEMM).  scratch: lys_alpha0_scratch_bytes(n, K) bytes (0 = no such kernel for the shape).
+ * (lyssa/sparse_coding.py:631, `fast_dot(D.T, X)`)
+ */
+size_t lys_alpha0_scratch_bytes(int n, int K);
+int lys_alpha0_bf16x3(const float* X_sig_major, int64_t ldx, const float* D_packed, int n, int K, int64_t N,
+                      float* alpha0, void* scratch, size_t scratch_bytes, void* stream);
 /* Only the greedy/Cholesky stage, from a precomputed alpha0 [N][Kp] (timing / tests). */
 int lys_bomp_from_alpha0(const float* alpha0, const float* G, int K, int k, int64_t N,
                          int32_t* idx, float* coef, int32_t* nnz, void* stream);

@@ -39,6 +39,8 @@ SIGNATURES = {
     "lys_lasso_workspace_bytes": (_Z, [_I, _I, _L]),
     "lys_lasso_encode": (_I, [_P, _L, _P, _P, _I, _I, _F, _I, _I, _F, _L, _P, _P, _P, _P, _P, _Z, _P]),
     "lys_alpha0": (_I, [_P, _L, _P, _I, _I, _L, _P, _P]),
+    "lys_alpha0_scratch_bytes": (_Z, [_I, _I]),
+    "lys_alpha0_bf16x3": (_I, [_P, _L, _P, _I, _I, _L, _P, _P, _Z, _P]),
     "lys_bomp_from_alpha0": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P]),
     "lys_residual": (_I, [_P, _L, _P, _I, _I, _I, _L, _P, _P, _P, _P, _L, _P, _P]),
     "lys_csr_workspace_bytes": (_Z, [_I, _I, _L]),

@@ -42,6 +42,9 @@ int alpha0_n64(const float*, int64_t, const float*, int, float*, int, int64_t, i
 int alpha0_n64_bf16x3(const float*, int64_t, const float*, int, float*, int, int64_t, int, void*, hipStream_t, bool presplit = false);
 int alpha0_bf16x3_split(const float*, int, int, int, void*, hipStream_t);
 size_t alpha0_bf16x3_scratch_bytes(int Kp);
+size_t alpha0_bf16x3_scratch_bytes(int Kp, int n);
+bool alpha0_split_path(int n, int Kp);
+int gemm_nt_bf16x3(const float*, int64_t, const void*, int, float*, int64_t, int64_t, int, hipStream_t);
 bool bomp_has_wave_kernel(int Kp, int k);
 size_t bomp_generic_scratch_bytes(int Kp, int k);
 int bomp_from_alpha0(const float*, const float*, int, int, int64_t, int32_t*, float*, int32_t*, float*, hipStream_t,
@@ -170,6 +173,14 @@ static int alpha0_any(const float* X, int64_t ldx, const float* D, int ldd, floa
             return alpha0_n64_bf16x3(X, ldx, D, ldd, a0, Kp, cnt, n, split_scratch, stream, presplit);
         return alpha0_n64(X, ldx, D, ldd, a0, Kp, cnt, n, stream);
     }
+    if (use_fast && n > 64 && split_scratch && alpha0_bf16x3_enabled() && alpha0_split_path(n, Kp)) {
+        // k-looped bf16x3 GEMM (round 4): the dictionary's planes in split_scratch ([3][Kp][ldp])
+        if (!presplit) {
+            const int rc = alpha0_bf16x3_split(D, ldd, Kp, n, split_scratch, stream);
+            if (rc) return rc;
+        }
+        return gemm_nt_bf16x3(X, ldx, split_scratch, n, a0, Kp, cnt, Kp, stream);
+    }
     return gemm_nt(X, ldx, D, ldd, a0, Kp, cnt, Kp, n, stream, true);
 }
 
@@ -284,7 +295,8 @@ size_t lys_bomp_workspace_bytes(int n, int K, int k, int64_t N) {
     int64_t rows = (N <= t) ? ((N < 1) ? 1 : N) : (pipeline_enabled() ? 2 * t : t);  // one tile (two if ping-pong)
     size_t bytes = (size_t)rows * (size_t)Kp * sizeof(float);
     if (!bomp_has_wave_kernel(Kp, k)) bytes += bomp_generic_scratch_bytes(Kp, k);
-    if (alpha0_fast_path(n, Kp)) bytes += alpha0_bf16x3_scratch_bytes(Kp);  // the dictionary's bf16 planes, at the end
+    if (alpha0_fast_path(n, Kp) || (n > 64 && alpha0_split_path(n, Kp)))
+        bytes += alpha0_bf16x3_scratch_bytes(Kp, n);  // the dictionary's bf16 planes, at the end
     return bytes;
 }
 
@@ -294,6 +306,22 @@ int lys_alpha0(const float* X, int64_t ldx, const float* D_packed, int n, int K,
     const int Kp = padded_atoms(K), ldd = padded_features(n);
     // the dictionary is zero-padded to ldd columns, so reading the first n columns of X is all that is needed
     return alpha0_any(X, ldx, D_packed, ldd, alpha0, Kp, N, n, STREAM(stream));
+}
+
+size_t lys_alpha0_scratch_bytes(int n, int K) {
+    const int Kp = padded_atoms(K);
+    return (alpha0_fast_path(n, Kp) || (n > 64 && alpha0_split_path(n, Kp))) ? alpha0_bf16x3_scratch_bytes(Kp, n) : 0;
+}
+
+int lys_alpha0_bf16x3(const float* X, int64_t ldx, const float* D_packed, int n, int K, int64_t N, float* alpha0,
+                      void* scratch, size_t scratch_bytes, void* stream) {
+    LYS_REQUIRE(X && D_packed && alpha0 && n > 0 && K > 0 && N >= 0 && ldx >= n, "alpha0_bf16x3: bad arguments");
+    const int Kp = padded_atoms(K), ldd = padded_features(n);
+    const size_t need = lys_alpha0_scratch_bytes(n, K);
+    LYS_REQUIRE(need > 0, "alpha0_bf16x3: no bf16-plane kernel for n = %d, K = %d", n, K);
+    LYS_REQUIRE(scratch && scratch_bytes >= need, "alpha0_bf16x3: scratch too small (%zu < %zu bytes)", scratch_bytes, need);
+    LYS_REQUIRE(alpha0_bf16x3_enabled(), "alpha0_bf16x3: disabled (lys_set_alpha0_bf16x3 / LYS_ALPHA0_BF16X3)");
+    return alpha0_any(X, ldx, D_packed, ldd, alpha0, Kp, N, n, STREAM(stream), scratch, false);
 }
 
 int lys_bomp_from_alpha0(const float* alpha0, const float* G, int K, int k, int64_t N, int32_t* idx, float* coef,
@@ -331,8 +359,8 @@ static int encode_tiles(int mode, const float* X, int64_t ldx, const float* D_pa
     // the last alpha0_bf16x3_scratch_bytes of a workspace sized by lys_bomp_workspace_bytes hold the dictionary's bf16
     // planes; a smaller (older-sized) workspace simply keeps the fp32 matrix-core kernel
     void* split = nullptr;
-    if (alpha0_fast_path(n, Kp)) {
-        const size_t sp = alpha0_bf16x3_scratch_bytes(Kp);
+    if (alpha0_fast_path(n, Kp) || (n > 64 && alpha0_split_path(n, Kp))) {
+        const size_t sp = alpha0_bf16x3_scratch_bytes(Kp, n);
         if (workspace_bytes >= gen_bytes + sp + (size_t)Kp * sizeof(float) + 16) {
             workspace_bytes -= sp;
             split = static_cast<char*>(workspace) + ((workspace_bytes) & ~(size_t)15);

@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void alpha0_n64_kernel(cons
 // same assignment: slot s of half h carries feature 16 ks + 8 h + s for both.
 // ------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int B3_LD = 72;  // bf16 elements per LDS row (144 B = 36 dwords = 4 mod 32: conflict-free ds_read_b128)
 
@@ -572,12 +573,209 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_bf16x3_kernel(const float* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the same bf16x3 product for n > 64 (configs[2]: 256-dim patches, 4096 atoms; configs[3]: 128-dim descriptors) as a
+// k-looped NT GEMM.  C[M x Nc] = A[M x Kin] * B[Nc x Kin]^T with B given as its three bf16 planes (split once per
+// dictionary, rows padded to a multiple of 32 features), A split on the fly by the thread that loads it.  128 x 128 block
+// tile, 4 waves x (2 x 2) MFMA tiles of v_mfma_f32_32x32x16_bf16, K consumed in slabs of 32 features; the next slab is
+// fetched into registers behind the 48 MFMAs of the current one (the fp32 kernel above has no prefetch: with the matrix
+// time cut 5x the exposed load latency would be all that is left).  LDS: 2 x 3 planes x 128 rows x 80 B = 60 KB, two
+// workgroups per CU.  Block order: column tiles fastest, so that the 8 XCDs (blocks are dealt round-robin) each keep 1/8
+// of the dictionary planes and the current signal tiles in their own L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int GB_LDP = 40;  // bf16 elements per LDS row: 32 + 8 (80 B = 20 dwords: the b128 reads of 8 lanes cover all banks)
+
+__global__ __launch_bounds__(256) void split_bf16x3_rows_kernel(const float* __restrict__ D, int ldd, int Kp, int n, int ldp,
+                                                                unsigned* __restrict__ Dsp) {
+    const int hp = ldp >> 1;                           // feature pairs per row
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)Kp * hp) return;
+    const int a = (int)(t / hp), f = (int)(t % hp) * 2;
+    const float v0 = (f < n && f < ldd) ? D[(int64_t)a * ldd + f] : 0.f;
+    const float v1 = (f + 1 < n && f + 1 < ldd) ? D[(int64_t)a * ldd + f + 1] : 0.f;
+    unsigned p1, p2, p3;
+    split3(v0, v1, p1, p2, p3);
+    Dsp[t] = p1;
+    Dsp[(size_t)Kp * hp + t] = p2;
+    Dsp[(size_t)2 * Kp * hp + t] = p3;
+}
+
+// WAVES = 8 (512 threads, wave tile 64 x 32, 4 waves per SIMD with two workgroups per CU) is the product: with WAVES = 4
+// (wave tile 64 x 64, 246 VGPRs, 2 waves per SIMD) the one-slab register prefetch does not cover the L2 latency behind 48
+// MFMAs and the matrix cores idle 60 % of the time (measured: 1.75 ms against 2.60 for the fp32 kernel at configs[2]).
+template <bool STREAM_C, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_bf16x3_kernel(const float* __restrict__ A, int64_t lda,
+                                                                      const unsigned* __restrict__ Bsp, int ldp,
+                                                                      float* __restrict__ C, int64_t ldc, int64_t M, int Nc,
+                                                                      int Kin) {
+    constexpr int NT = 64 * WAVES;
+    constexpr int NJ = (WAVES == 4) ? 2 : 1;        // 32-atom tiles per wave
+    constexpr int A_IT = 1024 / NT, B_IT = 1536 / NT;
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * 128 * GB_LDP];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * 128 * GB_LDP];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = (WAVES == 4) ? (wid >> 1) : (wid >> 2), wn = (WAVES == 4) ? (wid & 1) : (wid & 3);
+    const int n_ct = Nc / 128;
+    const int64_t bm = (int64_t)(blockIdx.x / n_ct) * 128;
+    const int bn = (blockIdx.x % n_ct) * 128;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+    const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const int hp = ldp >> 1;
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4v pa[A_IT];   // next A slab: rows lrow + (NT / 8) i, features k0 + lc4 .. + 3
+    u32x4 pb[B_IT];    // next B slab: 3 planes x 128 rows x 64 B = 1536 chunks of 16 B
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int64_t ga = bm + lrow + (NT / 8) * i;
+            ga = (ga < M) ? ga : M - 1;                   // rows past the end repeat the last one (never stored)
+            const float* p = A + ga * lda + k0 + lc4;
+            const int kc = k0 + lc4;
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            if (a_vec && kc + 3 < Kin) {
+                v = *reinterpret_cast<const f32x4v*>(p);
+            } else {
+                if (kc + 0 < Kin) v.x = p[0];
+                if (kc + 1 < Kin) v.y = p[1];
+                if (kc + 2 < Kin) v.z = p[2];
+                if (kc + 3 < Kin) v.w = p[3];
+            }
+            pa[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int e = tid + NT * i;                    // plane = e / 512, row = (e / 4) % 128, 16-byte chunk = e % 4
+            const int pl = e >> 9, row = (e >> 2) & 127, ch = e & 3;
+            pb[i] = *reinterpret_cast<const u32x4*>(Bsp + ((size_t)pl * Nc + bn + row) * hp + (k0 >> 1) + ch * 4);
+        }
+    };
+    auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            unsigned p1[2], p2[2], p3[2];
+            split3(pa[i].x, pa[i].y, p1[0], p2[0], p3[0]);
+            split3(pa[i].z, pa[i].w, p1[1], p2[1], p3[1]);
+            const int at = (lrow + (NT / 8) * i) * GB_LDP + lc4;
+            *reinterpret_cast<uint2*>(&As[0 * 128 * GB_LDP + at]) = make_uint2(p1[0], p1[1]);
+            *reinterpret_cast<uint2*>(&As[1 * 128 * GB_LDP + at]) = make_uint2(p2[0], p2[1]);
+            *reinterpret_cast<uint2*>(&As[2 * 128 * GB_LDP + at]) = make_uint2(p3[0], p3[1]);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int e = tid + NT * i;
+            const int pl = e >> 9, row = (e >> 2) & 127, ch = e & 3;
+            *reinterpret_cast<u32x4*>(&Bs[(pl * 128 + row) * GB_LDP + ch * 8]) = pb[i];
+        }
+    };
+    fetch(0);
+    stage();
+    __syncthreads();
+    for (int k0 = 0; k0 < Kin; k0 += 32) {
+        const bool more = k0 + 32 < Kin;
+        if (more) fetch(k0 + 32);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[2][3], b[NJ][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i][pl] = *reinterpret_cast<const bf16x8*>(&As[(pl * 128 + wm * 64 + i * 32 + l31) * GB_LDP + ks * 16 + h * 8]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    b[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(pl * 128 + wn * (32 * NJ) + j * 32 + l31) * GB_LDP + ks * 16 + h * 8]);
+            }
+            // the six plane products with i + j <= 4, small terms first; the output tiles alternate (a dependent MFMA waits
+            // for its predecessor)
+#define GB_MF(PA, PB)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] =       \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[j][PB], acc[i][j], 0, 0, 0)
+            GB_MF(2, 0);
+            GB_MF(0, 2);
+            GB_MF(1, 1);
+            GB_MF(1, 0);
+            GB_MF(0, 1);
+            GB_MF(0, 0);
+#undef GB_MF
+        }
+        __syncthreads();                 // every wave is done with this slab
+        if (more) {
+            stage();
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = bn + wn * (32 * NJ) + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) {
+                    if constexpr (STREAM_C)
+                        __builtin_nontemporal_store(acc[i][j][r], &C[row * ldc + col]);
+                    else
+                        C[row * ldc + col] = acc[i][j][r];
+                }
+            }
+        }
+}
+
+static int bf16x3_ldp(int n) { return ((n + 31) / 32) * 32; }  // plane row length in features
+
+// room for the dictionary's three bf16 planes: n <= 64 -> [3][Kp][64] (alpha0_n64_bf16x3_kernel), else [3][Kp][ldp]
+size_t alpha0_bf16x3_scratch_bytes(int Kp, int n) {
+    return (size_t)3 * Kp * (n <= 64 ? 64 : bf16x3_ldp(n)) * sizeof(unsigned short);
+}
+bool alpha0_split_path(int n, int Kp) { return (Kp % 128) == 0 && n >= 1; }
+
+int gemm_nt_bf16x3(const float* A, int64_t lda, const void* Bsp, int n, float* C, int64_t ldc, int64_t M, int Nc,
+                   hipStream_t stream) {
+    if (M <= 0) return LYS_OK;
+    const int64_t blocks = ((M + 127) / 128) * (Nc / 128);
+    if ((Nc % 128) != 0 || blocks > 0x7fffffffLL) {
+        set_error("gemm_nt_bf16x3: Nc = %d, %lld blocks", Nc, (long long)blocks);
+        return LYS_ENOSUP;
+    }
+    static int waves = 0;
+    if (!waves) {
+        const char* e = getenv("LYS_GEMM_WAVES");
+        waves = (e && atoi(e) == 4) ? 4 : 8;
+    }
+    if (waves == 4)
+        hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, stream, A, lda,
+                           static_cast<const unsigned*>(Bsp), bf16x3_ldp(n), C, ldc, M, Nc, n);
+    else
+        hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<true, 8>), dim3((unsigned)blocks), dim3(512), 0, stream, A, lda,
+                           static_cast<const unsigned*>(Bsp), bf16x3_ldp(n), C, ldc, M, Nc, n);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 size_t alpha0_bf16x3_scratch_bytes(int Kp) { return (size_t)3 * Kp * 64 * sizeof(unsigned short); }
 
 // whole 128-signal tiles through the bf16x3 kernel, the tail through the fp32 kernel; `scratch`: alpha0_bf16x3_scratch_bytes
 int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, int Kp, int64_t N, int n, hipStream_t stream);
 // the dictionary's three bf16 planes, once per dictionary (callers that encode several tiles against one D split once)
 int alpha0_bf16x3_split(const float* D, int ldd, int Kp, int n, void* scratch, hipStream_t stream) {
+    if (n > 64) {
+        const int ldp = bf16x3_ldp(n);
+        const int64_t pairs = (int64_t)Kp * (ldp >> 1);
+        hipLaunchKernelGGL(split_bf16x3_rows_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, D, ldd, Kp, n,
+                           ldp, static_cast<unsigned*>(scratch));
+        LYS_LAUNCH_CHECK();
+        return LYS_OK;
+    }
     hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((Kp * 32 + 255) / 256)), dim3(256), 0, stream, D, ldd, Kp, n,
                        static_cast<unsigned*>(scratch));
     LYS_LAUNCH_CHECK();

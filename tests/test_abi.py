@@ -40,7 +40,7 @@ def test_host_only_entry_points(lib):
     planes = 3 * 1024 * 64 * 2            # the dictionary's three bf16 planes (alpha0 on the bf16 matrix cores, n <= 64)
     assert lib.lys_bomp_workspace_bytes(64, 1024, 10, 100) == 100 * 1024 * 4 + planes
     assert lib.lys_bomp_workspace_bytes(64, 1024, 10, 10 ** 9) == (4 << 30) + planes      # one 4 GiB alpha0 tile
-    assert lib.lys_bomp_workspace_bytes(100, 1024, 10, 100) == 100 * 1024 * 4        # n > 64: fp32 GEMM only
+    assert lib.lys_bomp_workspace_bytes(100, 1024, 10, 100) == 100 * 1024 * 4 + 3 * 1024 * 128 * 2   # n > 64: planes of [Kp][128]
     # argument validation happens before any HIP call
     assert lib.lys_gram(None, 64, 1024, None, None) == -1
     assert b"gram" in lib.lys_last_error()

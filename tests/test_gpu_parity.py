@@ -1649,7 +1649,7 @@ def test_alpha0_bf16_planes_wide_dynamic_range(eng, n, K, alpha0_mode):
     assert np.array_equal(nz[:, clear], top[:, clear])
 
 
-@pytest.mark.parametrize("n,K", [(64, 256), (48, 128)])
+@pytest.mark.parametrize("n,K", [(64, 256), (48, 128), (256, 512), (100, 256), (128, 4096)])
 def test_alpha0_every_correlation_1e36_range_and_non_finite_policy(eng, n, K, alpha0_mode):
     """ALL K correlations of every signal (lys_alpha0, not the top-k) over signal scales 1e-36 .. 1e+36, against the float64
     product under fp32's forward bound.  Policy pinned here:
@@ -1675,8 +1675,21 @@ def test_alpha0_every_correlation_1e36_range_and_non_finite_policy(eng, n, K, al
     Xs = torch.from_numpy(X).cuda()
     a0 = torch.empty((N, dd.Kp), dtype=torch.float32, device=dd.device)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(lib.lys_alpha0(ctypes.c_void_p(Xs.data_ptr()), Xs.stride(0), ctypes.c_void_p(dd.D.data_ptr()), n, K, N,
-                              ctypes.c_void_p(a0.data_ptr()), st), "lys_alpha0")
+    # alpha0_mode 1: the bf16-plane kernels the encode entry points run (n <= 64: alpha0_n64_bf16x3_kernel; n > 64: the
+    # k-looped gemm_nt_bf16x3_kernel of round 4) through lys_alpha0_bf16x3; mode 0: the fp32 MFMA kernels (lys_alpha0)
+    nsc = int(lib.lys_alpha0_scratch_bytes(n, K))
+    assert nsc > 0
+    scratch = torch.empty((nsc,), dtype=torch.uint8, device=dd.device)
+
+    def product(Xd, out, rows):
+        if alpha0_mode == 1:
+            _lib.check(lib.lys_alpha0_bf16x3(ctypes.c_void_p(Xd.data_ptr()), Xd.stride(0), ctypes.c_void_p(dd.D.data_ptr()), n, K,
+                                             rows, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(scratch.data_ptr()), nsc, st),
+                       "lys_alpha0_bf16x3")
+        else:
+            _lib.check(lib.lys_alpha0(ctypes.c_void_p(Xd.data_ptr()), Xd.stride(0), ctypes.c_void_p(dd.D.data_ptr()), n, K, rows,
+                                      ctypes.c_void_p(out.data_ptr()), st), "lys_alpha0")
+    product(Xs, a0, N)
     A = a0.cpu().numpy()[:, :K].astype(np.float64)
     Aref = X.astype(np.float64) @ D.astype(np.float64)
     bound = np.abs(X.astype(np.float64)) @ np.abs(D.astype(np.float64))
@@ -1688,24 +1701,30 @@ def test_alpha0_every_correlation_1e36_range_and_non_finite_policy(eng, n, K, al
     assert (np.abs(A - Aref)[fits & ~normal] <= 64 * tiny).all()
     assert not np.isnan(A[~fits]).any()                          # overflow gives inf, not NaN
     # non-finite / above-bf16-range operands
-    Xn = rs.randn(8, n).astype(np.float32)
+    # 136 rows: the bf16-plane kernels take whole 128-signal tiles (a shorter batch would fall to the fp32 tail kernel and the
+    # policy below would never see the plane kernels -- which is what this test did until round 4)
+    Xn = rs.randn(136, n).astype(np.float32)
     Xn[0, 3] = np.float32(3.4e38)        # finite in fp32, above bf16's largest finite value
     Xn[1, 5] = np.inf
     Xn[2, 7] = -np.inf
     Xn[3, 1] = np.nan
     Xs = torch.from_numpy(Xn).cuda()
-    a1 = torch.empty((8, dd.Kp), dtype=torch.float32, device=dd.device)
-    _lib.check(lib.lys_alpha0(ctypes.c_void_p(Xs.data_ptr()), Xs.stride(0), ctypes.c_void_p(dd.D.data_ptr()), n, K, 8,
-                              ctypes.c_void_p(a1.data_ptr()), st), "lys_alpha0")
+    a1 = torch.empty((136, dd.Kp), dtype=torch.float32, device=dd.device)
+    product(Xs, a1, 136)
     B = a1.cpu().numpy()[:, :K]
     with np.errstate(all='ignore'):
         Bref = Xn.astype(np.float64) @ D.astype(np.float64)
     ok_rows = B[4:]
     assert np.isfinite(ok_rows).all() and np.abs(ok_rows - Bref[4:]).max() < 1e-4      # rows without special values
     assert np.isnan(B[3]).all()                                                         # NaN in, NaN out
-    for r in (1, 2):                                                                    # +-inf: inf of the right sign (NaN
-        hit = np.abs(D[:, :].T[:, [5, 7][r - 1]]) > 1e-3                                 # only against a ~zero weight)
-        assert (np.isinf(B[r][hit]) & (np.sign(B[r][hit]) == np.sign(Bref[r][hit]))).all()
+    for r in (1, 2):
+        hit = np.abs(D[:, :].T[:, [5, 7][r - 1]]) > 1e-3
+        if alpha0_mode == 1:
+            # plane kernels: inf x (d1 + d2 + d3) -- the residual planes of the WEIGHT have either sign, so the sum of the six
+            # products is +-inf or inf - inf = NaN: non-finite in, non-finite out, never a finite number
+            assert (~np.isfinite(B[r][hit])).all()
+        else:                                                                           # fp32 MFMA: inf of the right sign
+            assert (np.isinf(B[r][hit]) & (np.sign(B[r][hit]) == np.sign(Bref[r][hit]))).all()
     big = np.abs(D.T[:, 3]) > 1e-3
     if alpha0_mode == 1:
         assert (~np.isfinite(B[0][big])).all() or (np.abs(B[0][big] - Bref[0][big]) <= 1e-5 * np.abs(Bref[0][big])).all()
