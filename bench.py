@@ -585,7 +585,10 @@ def config3_shard(synth, N=1 << 17, reps=5):
                          "traffic": _recorded("bomp_block_kernel_bytes_per_launch"),
                          "note": "one signal per CU, eight waves in lock-step: bound by the latency chain of a step "
                                  "(DESIGN 3.3), not by VALU throughput or by the Gram rows' bandwidth",
-                         "gemm_stage": {"kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": gemm_tf,
+                         "gemm_stage": {"kernel": "gemm_nt_bf16x3_kernel<8 waves> (three bf16 planes per operand, six "
+                                                  "v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; round 4)"
+                                        if os.environ.get("LYS_ALPHA0_BF16X3", "1") != "0" else
+                                        "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": gemm_tf,
                                         "frac": gemm_tf / PEAK_FP32_TFLOPS, "flop_per_patch": f_gemm,
                                         "avg_launch_ms": gemm_ms}}}
 
@@ -638,7 +641,10 @@ def config4_minibatch(synth, B=32768, lam=0.2, reps=3):
             t_upd += t_u
     t_code /= reps
     t_upd /= reps
-    # the coder's traffic model: every breakpoint re-reads the active Gram rows (Kp * 4 bytes each) out of L2
+    # ALGORITHMIC bytes of the coder: one NEW Gram row (4 K bytes) per breakpoint and signal -- what a coder that kept its
+    # orthogonalised directions on chip would move.  The kernel as built re-reads all |A| active rows at every breakpoint
+    # (sum over breakpoints of |A| rows: `reread_model`), so frac = efficiency against the algorithm, not busy-ness
+    alg_bytes = br_mean * K * 4.0 * B
     l2_bytes = br_sq * K * 4.0 * B
     return {"workload": "online-DL mini-batch: %d unit-norm 128-dim descriptors, 8192 atoms, LARS-lasso lambda=%.2f "
                         "(configs[3] per-GPU shape), mean of %d" % (B, lam, reps),
@@ -649,12 +655,18 @@ def config4_minibatch(synth, B=32768, lam=0.2, reps=3):
             # requests miss L2 (profiles/traffic.json): the re-read rows are fabric / HBM traffic, priced against HBM
             "roofline": {"bound": "hbm", "kernel": "lasso_lars_kernel (one workgroup per signal; active Gram rows re-read per "
                                                    "breakpoint)",
-                         "achieved": l2_bytes / (t_code * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": l2_bytes / (t_code * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "achieved": alg_bytes / (t_code * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / (t_code * 1e-3) / 1e9 / PEAK_HBM_GBS,
                          "traffic": _recorded("lasso_lars_kernel_bytes_per_launch"),
-                         "bytes_model": "sum over breakpoints of |A| Gram rows of 4 K bytes = %.3g GB per mini-batch; the "
-                                        "time is the whole coder (alpha0 GEMM + LARS path + coordinate-descent polish)"
-                                        % (l2_bytes / 1e9)}}
+                         "traffic_ratio": (_recorded("lasso_lars_kernel_bytes_per_launch") / alg_bytes)
+                         if _recorded("lasso_lars_kernel_bytes_per_launch") else None,
+                         "bytes_model": "algorithmic: one new Gram row of 4 K bytes per breakpoint = %.3g GB per mini-batch; "
+                                        "the time is the whole coder (alpha0 GEMM + LARS path + coordinate-descent polish)"
+                                        % (alg_bytes / 1e9),
+                         "reread_model": {"bytes": l2_bytes, "gbs": l2_bytes / (t_code * 1e-3) / 1e9,
+                                          "frac_of_hbm_peak": l2_bytes / (t_code * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                          "note": "what the kernel moves: sum over breakpoints of |A| active rows (the "
+                                                  "round-3 figure, a busy-ness number)"}}}
 
 
 def cpu_ksvd_sweep(Xs, n, K, k, sample=1 << 17):
