@@ -9,5 +9,5 @@ python bench.py > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err; e
 bash tools/profile.sh $TAG > /dev/null 2>&1; echo "profile rc=$?"
 bash tools/profile_aux.sh $TAG > /dev/null 2>&1; echo "profile_aux rc=$?"
 bash tools/profile_ksvd.sh $TAG > /dev/null 2>&1; echo "profile_ksvd rc=$?"
-bash tools/prof_cmd.sh exact_$TAG python tools/ksvd_bench.py 1048576 3 exact > /dev/null 2>&1; echo "profile_exact rc=$?"
+bash tools/prof_cmd.sh exact_$TAG python $PWD/tools/ksvd_bench.py 1048576 3 exact > /dev/null 2>&1; echo "profile_exact rc=$?"
 ls -la gpurun_out/*${TAG}* | head -20
