@@ -1312,9 +1312,11 @@ def test_bomp_direct_parity_262144_signals(eng, alpha0_mode):
 
 
 @pytest.mark.parametrize("n,K,k,N", [(256, 4096, 20, 6000), (64, 2048, 10, 30000), (64, 256, 5, 100000),
-                                     (128, 1024, 10, 40000)])
+                                     (128, 1024, 10, 40000), (70, 256, 5, 3001), (131, 512, 8, 2077), (97, 1500, 10, 1300)])
 def test_bomp_direct_parity_other_shapes(eng, n, K, k, N):
-    """Config-3 (n=256, K=4096, k=20) and config-1 (K=256, k=5) shapes at sizes the C oracle finishes in seconds."""
+    """Config-3 (n=256, K=4096, k=20) and config-1 (K=256, k=5) shapes at sizes the C oracle finishes in seconds; ragged
+    n > 64 (odd row strides: the scalar-load path of the k-looped bf16x3 GEMM, feature tails inside a 32-feature slab, signal
+    counts that are not a multiple of the 128-row tile, K padded to 2048)."""
     import torch
     from oracle import c_oracle
     gen = torch.Generator(device="cuda").manual_seed(K + k)
