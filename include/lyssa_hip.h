@@ -224,6 +224,20 @@ int lys_nn_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k,
                       double* work, size_t work_bytes, float* xbuf, float* D_packed, float* D_next,
                       int64_t max_support, int n_cycles, void* stream);
 /*
+ * nn_ksvd per atom on signal SHARDS (n <= 256; one process per GPU; dist.nn_ksvd_cycle_sharded): after lys_ksvd_exact_gram and
+ * the all-reduce of C, phase 0 runs the replicated eigen-solve (u -> D_next[atom]) and the first local x pass; the caller
+ * all-reduces the ONE double at work + lys_nn_ksvd_state_offset_bytes(n) (the x'x of the pass just run); phase 1 clips d and
+ * takes the skip decision of ksvd.py:79-82; per alternating projection: phase 2 (local sum x rk), all-reduce of the n doubles
+ * at state offset + 32 bytes, phase 3 (d from the sums, next x pass), all-reduce of the x'x double; phase 4 commits (the new
+ * atom is written on every shard, also one without non-zeros of it).  phase -1 zeroes the state (once per cycle).
+ * work: lys_ksvd_exact_workspace_bytes(n); xbuf: max local support floats; used_ptr as for lys_ksvd_exact_update.
+ */
+size_t lys_nn_ksvd_state_offset_bytes(int n);
+int lys_nn_ksvd_phase(int phase, int atom, float* R, int64_t ldr, int n, int k,
+                      const int32_t* row_ptr, const int32_t* used_ptr, const int32_t* entry, float* coef,
+                      const double* C, double* work, size_t work_bytes, float* xbuf,
+                      const float* D_packed, float* D_next, void* stream);
+/*
  * The same update per atom for signal SHARDS (n <= 256; one process per GPU): lys_ksvd_exact_gram writes this shard's
  * Rk Rk' into the fp64 n x n buffer C (zeroed inside); the caller all-reduces C over the ranks (the exchange step the
  * exact update needs: the Gram matrix IS the sufficient statistic); lys_ksvd_exact_update runs the eigen-solve on the

@@ -71,6 +71,9 @@ int ksvd_commit(int, int, const int32_t*, const float*, float*, hipStream_t);
 int ksvd_exact_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
                      int64_t, hipStream_t, int nn_cycles, float* xbuf);
 size_t ksvd_exact_work_doubles(int);
+size_t nn_ksvd_state_offset_doubles(int);
+int nn_ksvd_phase(int, int, float*, int64_t, int, int, const int32_t*, const int32_t*, const int32_t*, float*, const double*,
+                  double*, float*, const float*, float*, hipStream_t);
 int ksvd_exact_gram(int, const float*, int64_t, int, int, const int32_t*, const int32_t*, const float*, const float*, double*,
                     int64_t, hipStream_t);
 int ksvd_exact_update(int, float*, int64_t, int, int, const int32_t*, const int32_t*, const int32_t*, float*, const double*,
@@ -698,6 +701,19 @@ int lys_nn_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t*
     LYS_REQUIRE(work_bytes >= ksvd_exact_work_doubles(n) * sizeof(double), "nn_ksvd_sweep: work buffer too small");
     return ksvd_exact_sweep(R, ldr, n, K, k, row_ptr, entry, coef, work, D_packed, D_next, max_support, STREAM(stream),
                             n_cycles, xbuf);
+}
+
+size_t lys_nn_ksvd_state_offset_bytes(int n) { return nn_ksvd_state_offset_doubles(n) * sizeof(double); }
+
+int lys_nn_ksvd_phase(int phase, int atom, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr,
+                      const int32_t* used_ptr, const int32_t* entry, float* coef, const double* C, double* work,
+                      size_t work_bytes, float* xbuf, const float* D_packed, float* D_next, void* stream) {
+    LYS_REQUIRE(R && row_ptr && used_ptr && entry && coef && C && work && xbuf && D_packed && D_next && n > 0 && atom >= 0 &&
+                    k >= 1 && phase >= -1 && phase <= 4,
+                "nn_ksvd_phase: bad arguments");
+    LYS_REQUIRE(work_bytes >= ksvd_exact_work_doubles(n) * sizeof(double), "nn_ksvd_phase: work buffer too small");
+    return nn_ksvd_phase(phase, atom, R, ldr, n, k, row_ptr, used_ptr, entry, coef, C, work, xbuf, D_packed, D_next,
+                         STREAM(stream));
 }
 
 int lys_ksvd_exact_gram(int atom, const float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,

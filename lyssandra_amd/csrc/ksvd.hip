@@ -2315,11 +2315,14 @@ __global__ __launch_bounds__(256) void nn_commit_kernel(int atom, float* __restr
                                                         const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
                                                         float* __restrict__ coef, const float* __restrict__ D, int ldd,
                                                         const float* __restrict__ dwork, float* __restrict__ Dnext,
-                                                        const float* __restrict__ xbuf, double* __restrict__ st) {
+                                                        const float* __restrict__ xbuf, double* __restrict__ st,
+                                                        const int32_t* __restrict__ used_ptr) {
     const int beg = row_ptr[atom], end = row_ptr[atom + 1];
     const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
     const int gteam = blockIdx.x * 16 + team, nteams = gridDim.x * 16;
-    if (beg >= end || st[2] != 0.0) return;
+    // used_ptr: non-empty for an atom used on ANY shard (== row_ptr on one GPU): workgroup 0 publishes the new atom also when
+    // this shard holds none of its non-zeros
+    if (used_ptr[atom] >= used_ptr[atom + 1] || st[2] != 0.0) return;
     if (blockIdx.x != 0 && beg + blockIdx.x * 16 >= end) return;
     const double nrm = sqrt(st[1]);
     if (blockIdx.x == 0 && threadIdx.x == 0) st[0] = 0.0;  // the last x pass's x'x is never consumed: clean for the next atom
@@ -2374,7 +2377,39 @@ static int nn_atom_passes(int a, int nn_cycles, float* R, int64_t ldr, int n, in
                            ldd, dwork, xbuf, st);
     }
     hipLaunchKernelGGL(nn_commit_kernel<FB>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef, D,
-                       ldd, dwork, Dnext, xbuf, st);
+                       ldd, dwork, Dnext, xbuf, st, row_ptr);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
+// The same passes one at a time, for signal SHARDS (dist.nn_ksvd_cycle_sharded): between them the caller all-reduces
+// st[0] (x'x of the pass just run) or st[4 .. 4+n) (sum x_i rk_i).  used_ptr: see nn_commit_kernel.
+template <int FB>
+static int nn_atom_phase(int phase, int a, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* used_ptr,
+                         const int32_t* entry, float* coef, const float* D, int ldd, float* Dnext, float* xbuf, double* st,
+                         hipStream_t stream) {
+    float* dwork = reinterpret_cast<float*>(st + NN_ST + 256);
+    switch (phase) {
+        case 0:  // first x pass (u in Dnext[a])
+            hipLaunchKernelGGL(nn_x_kernel<FB>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, 1, R, ldr, n, k, row_ptr, entry, coef,
+                               D, ldd, Dnext + (int64_t)a * ldd, xbuf, st);
+            break;
+        case 1:  // d = max(u, 0), skip test on the (reduced) x'x
+            hipLaunchKernelGGL(nn_prep_kernel, dim3(1), dim3(256), 0, stream, a, 0, n, used_ptr, D, ldd, Dnext, dwork, st);
+            break;
+        case 2:
+            hipLaunchKernelGGL(nn_dacc_kernel<FB>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry, coef,
+                               D, ldd, xbuf, st);
+            break;
+        case 3:  // d from the (reduced) sums, then the next x pass
+            hipLaunchKernelGGL(nn_prep_kernel, dim3(1), dim3(256), 0, stream, a, 1, n, used_ptr, D, ldd, Dnext, dwork, st);
+            hipLaunchKernelGGL(nn_x_kernel<FB>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, 0, R, ldr, n, k, row_ptr, entry, coef,
+                               D, ldd, dwork, xbuf, st);
+            break;
+        default:
+            hipLaunchKernelGGL(nn_commit_kernel<FB>, dim3(KSVD_BLOCKS), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry,
+                               coef, D, ldd, dwork, Dnext, xbuf, st, used_ptr);
+    }
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -2505,6 +2540,44 @@ int ksvd_exact_update(int atom, float* R, int64_t ldr, int n, int k, const int32
     }
     LYS_LAUNCH_CHECK();
     return LYS_OK;
+}
+
+// nn_ksvd on signal shards, one phase of one atom (see nn_atom_phase): phase -1 zeroes the state (once per cycle), 0 runs the
+// replicated eigen-solve on the reduced Gram matrix C (u -> Dnext[atom]) and the first x pass, 1..4 the remaining passes.
+size_t nn_ksvd_state_offset_doubles(int n) { return exact_base_doubles(n); }
+int nn_ksvd_phase(int phase, int atom, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* used_ptr,
+                  const int32_t* entry, float* coef, const double* C, double* work, float* xbuf, const float* D, float* Dnext,
+                  hipStream_t stream) {
+    const int fb = fb_of(n);
+    if (!fb) {
+        set_error("sharded nn_ksvd needs n <= 256 (n = %d)", n);
+        return LYS_ENOSUP;
+    }
+    double* st = work + exact_base_doubles(n);
+    if (phase < 0) {
+        LYS_CHECK_HIP(hipMemsetAsync(st, 0, NN_STATE_DOUBLES * sizeof(double), stream));
+        return LYS_OK;
+    }
+    const int ldd = padded_features(n);
+    if (phase == 0) {
+        static bool attr_set[64] = {};
+        int dev = 0;
+        LYS_CHECK_HIP(hipGetDevice(&dev));
+        const int c_in_lds = (n <= 64) ? 1 : 0;
+        const size_t eig_lds = ((size_t)(EIG_M + 1) * n + (c_in_lds ? (size_t)n * n : 0)) * sizeof(double);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ksvd_eig_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              ((EIG_M + 1) * 256 + 64 * 64) * (int)sizeof(double)));
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(ksvd_eig_kernel, dim3(1), dim3(256), eig_lds, stream, atom, n, used_ptr, C, D, ldd, Dnext, c_in_lds);
+    }
+    switch (fb) {
+        case 1: return nn_atom_phase<1>(phase, atom, R, ldr, n, k, row_ptr, used_ptr, entry, coef, D, ldd, Dnext, xbuf, st, stream);
+        case 2: return nn_atom_phase<2>(phase, atom, R, ldr, n, k, row_ptr, used_ptr, entry, coef, D, ldd, Dnext, xbuf, st, stream);
+        default: return nn_atom_phase<4>(phase, atom, R, ldr, n, k, row_ptr, used_ptr, entry, coef, D, ldd, Dnext, xbuf, st, stream);
+    }
 }
 
 // The 2K+2 dependent launches of one cycle are captured once into a hipGraph and replayed while the buffer

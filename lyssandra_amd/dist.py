@@ -142,6 +142,43 @@ def ksvd_exact_cycle_sharded(ops, K, group=None):
     return [a for a in range(K) if host_counts[a] == 0]
 
 
+def nn_ksvd_cycle_sharded(ops, K, n_cycles, group=None):
+    """One pass of the NON-NEGATIVE K-SVD update (`nn_ksvd`, ksvd.py:46-95) over signal shards (round 4).  Per atom IN ORDER:
+    the Gram matrix of the restricted residual is all-reduced like for the exact update (replicated rank-1 solve), then every
+    projection pass exchanges the ONE quantity it needs from the other shards --
+
+        ops.gram(a)          -> fp64 [n, n]  this shard's Rk Rk'                                   (all-reduced here)
+        ops.nn_begin(a)      -> replicated eigen-solve u; local x = max(Rk'u, 0)
+        ops.nn_scalar()      -> fp64 [1]: the LOCAL x'x of the pass just run                        (all-reduced here)
+        ops.nn_project(a)    -> replicated: d = max(u, 0), the skip test of ksvd.py:79-82 on the global x'x
+        n_cycles times:
+          ops.nn_accumulate(a) ; ops.nn_vector() -> fp64 [n]: local Rk x                            (all-reduced here)
+          ops.nn_step(a)       -> replicated d = max(s / x'x, 0); local x = max(Rk'd / d'd, 0)     (then nn_scalar again)
+        ops.nn_commit(a)     -> d /= ||d||, x *= ||d||, residual rows (local); the new atom on every rank
+
+    plus `local_counts`, `set_used`, `commit` like the exact update.  2 + 2 n_cycles small collectives per atom on top of the
+    Gram matrix; a skipped atom still takes part in them (zeros), so no rank waits for another.  Returns the unused atoms."""
+    counts = ops.local_counts()
+    allreduce_sum_(counts, group)
+    ops.set_used(counts)
+    host_counts = counts.cpu().tolist()
+    for a in range(K):
+        if host_counts[a] == 0:
+            continue
+        allreduce_sum_(ops.gram(a), group)
+        ops.nn_begin(a)
+        allreduce_sum_(ops.nn_scalar(), group)
+        ops.nn_project(a)
+        for _ in range(int(n_cycles)):
+            ops.nn_accumulate(a)
+            allreduce_sum_(ops.nn_vector(), group)
+            ops.nn_step(a)
+            allreduce_sum_(ops.nn_scalar(), group)
+        ops.nn_commit(a)
+    ops.commit()
+    return [a for a in range(K) if host_counts[a] == 0]
+
+
 def ksvd_cycle_blocks(ops, group=None):
     """One cycle of the BLOCK sweep over signal shards (csrc/ksvd_block.hip).  Per block c of B atoms:
 

@@ -621,10 +621,63 @@ class HipExactKsvdOps(object):
         self.dd.invalidate()
 
 
+class HipNnKsvdOps(HipExactKsvdOps):
+    """`ops` of dist.nn_ksvd_cycle_sharded: nn_ksvd (ksvd.py:46-95) per atom on a signal shard -- the Gram matrix of the exact
+    update, then the projection passes of lys_nn_ksvd_phase; the tensors handed to the all-reduce are views into the state
+    behind the exact update's work area (one double: x'x of the pass just run; n doubles: sum x rk)."""
+
+    def __init__(self, R, dd, idx, coef, nnz, buffers=None):
+        torch = _torch()
+        HipExactKsvdOps.__init__(self, R, dd, idx, coef, nnz, buffers)
+        if buffers is None:
+            buffers = {}
+        need = int(self.lib.lys_ksvd_exact_workspace_bytes(dd.n)) // 8
+        work = buffers.get("exact_work")
+        if work is None or work.numel() < need:
+            work = buffers["exact_work"] = torch.zeros((need,), dtype=torch.float64, device=dd.device)
+        xbuf = buffers.get("nn_xbuf")
+        if xbuf is None or xbuf.numel() < max(1, self.max_support):
+            xbuf = buffers["nn_xbuf"] = torch.zeros((max(1, self.max_support),), dtype=torch.float32, device=dd.device)
+        self.work, self.xbuf = work, xbuf
+        off = int(self.lib.lys_nn_ksvd_state_offset_bytes(dd.n)) // 8
+        self._scalar = work[off:off + 1]
+        self._vector = work[off + 4:off + 4 + dd.n]
+        self._phase(-1, 0)
+
+    def _phase(self, phase, a):
+        _lib.check(self.lib.lys_nn_ksvd_phase(phase, a, _ptr(self.R), _ld(self.R), self.dd.n, self.k, _ptr(self.row_ptr),
+                                              _ptr(self.used if self.used is not None else self.row_ptr), _ptr(self.entry),
+                                              _ptr(self.coef), _ptr(self.C), _ptr(self.work), self.work.numel() * 8,
+                                              _ptr(self.xbuf), _ptr(self.dd.D), _ptr(self.Dnext), _stream()),
+                   "lys_nn_ksvd_phase")
+
+    def nn_begin(self, a):
+        self._phase(0, a)
+
+    def nn_scalar(self):
+        return self._scalar
+
+    def nn_vector(self):
+        return self._vector
+
+    def nn_project(self, a):
+        self._phase(1, a)
+
+    def nn_accumulate(self, a):
+        self._phase(2, a)
+
+    def nn_step(self, a):
+        self._phase(3, a)
+
+    def nn_commit(self, a):
+        self._phase(4, a)
+
+
 def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None, nn_cycles=None):
     """One cycle of the EXACT rank-1 K-SVD update (lyssa/dict_learning/ksvd.py:19-43), in place on R, coef, dd.D.
     ``nn_cycles`` (int >= 0): the non-negative variant instead (`nn_ksvd`, ksvd.py:46-95) with that many alternating
-    projections per atom (`lys_nn_ksvd_sweep`; single GPU, n <= 256).
+    projections per atom (`lys_nn_ksvd_sweep`, n <= 256; with ``group``: dist.nn_ksvd_cycle_sharded, one scalar / one n-vector
+    exchanged per projection pass).
 
     Per atom: Gram matrix of the restricted residual, its leading eigenvector (Lanczos + Rayleigh-Ritz in one
     workgroup), coefficient / residual update (the reference: sklearn ``randomized_svd(n_iter=10)``, random sign).
@@ -637,9 +690,9 @@ def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None, nn_cycles=
     if buffers is None:
         buffers = {}
     if group is not None:
-        if nn_cycles is not None:
-            raise _lib.LyssaHipError("nn_ksvd runs on one GPU (its per-atom projections are not exchanged between shards)")
         from . import dist as _d
+        if nn_cycles is not None:
+            return _d.nn_ksvd_cycle_sharded(HipNnKsvdOps(R, dd, idx, coef, nnz, buffers), dd.K, int(nn_cycles), group)
         return _d.ksvd_exact_cycle_sharded(HipExactKsvdOps(R, dd, idx, coef, nnz, buffers), dd.K, group)
     row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
     need = int(lib.lys_ksvd_exact_workspace_bytes(dd.n)) // 8

@@ -95,6 +95,64 @@ class NumpyExactKsvdOps(object):
         self.D[:, self.used] = self.Dnext[:, self.used]
 
 
+class NumpyNnKsvdOps(NumpyExactKsvdOps):
+    """Shard-local phases of nn_ksvd (ksvd.py:46-95) in numpy: stand-in for engine.HipNnKsvdOps."""
+
+    def __init__(self, Y, D, Z):
+        NumpyExactKsvdOps.__init__(self, Y, D, Z)
+        self.sc = torch.zeros((1,), dtype=torch.float64)
+        self.vec = torch.zeros((D.shape[0],), dtype=torch.float64)
+        self.eps = float(np.finfo(np.float64).eps)
+
+    def _rk(self, a):
+        om = self.Z[a] != 0
+        return om, self.R[:, om] + np.outer(self.D[:, a], self.Z[a, om])
+
+    def nn_begin(self, a):
+        w, V = np.linalg.eigh(self.C.numpy())
+        u = V[:, -1]
+        if np.dot(u, self.D[:, a]) < 0:
+            u = -u
+        self.u = u
+        self.om, self.Rk = self._rk(a)
+        self.x = np.maximum(self.Rk.T @ u, 0.0)
+        self.sc[0] = float(self.x @ self.x)
+
+    def nn_scalar(self):
+        return self.sc
+
+    def nn_vector(self):
+        return self.vec
+
+    def nn_project(self, a):
+        self.d = np.maximum(self.u, 0.0)
+        self.xtx = float(self.sc[0])
+        self.skip = (self.d @ self.d <= self.eps) or (self.xtx <= self.eps)
+
+    def nn_accumulate(self, a):
+        self.xtx = float(self.sc[0])          # the all-reduced x'x of the pass that produced self.x
+        self.vec[:] = torch.from_numpy(np.zeros_like(self.d) if self.skip else self.Rk @ self.x)
+
+    def nn_step(self, a):
+        if self.skip:
+            self.sc[0] = 0.0
+            return
+        self.d = np.maximum(self.vec.numpy() / self.xtx, 0.0)
+        self.x = np.maximum(self.d @ self.Rk / (self.d @ self.d), 0.0)
+        self.sc[0] = float(self.x @ self.x)
+
+    def nn_commit(self, a):
+        if self.skip:
+            return
+        nrm = np.sqrt(self.d @ self.d)
+        self.Dnext[:, a] = self.d / nrm
+        self.Z[a, self.om] = self.x * nrm
+        self.R[:, self.om] = self.Rk - np.outer(self.Dnext[:, a], self.Z[a, self.om])
+
+    def commit(self):
+        self.D[:, self.used] = self.Dnext[:, self.used]
+
+
 class NumpyBlockKsvdOps(object):
     """float64 numpy stand-in for engine.HipBlockKsvdOps: the block Gauss-Seidel sweep of csrc/ksvd_block.hip (B atoms
     per step, exact in-block coupling through tuple moments) with the same `ops` interface and the same slab layout
@@ -221,7 +279,7 @@ class NumpyOdlOps(object):
         self.D /= (np.sqrt((self.D * self.D).sum(0)) + EPS)[None, :]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out):  # noqa: C901
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -254,6 +312,24 @@ def _worker(rank, world, port, out):
         assert unused == list(ue) == [K - 1]
         assert np.max(np.abs(Dl - De)) < 1e-9, np.max(np.abs(Dl - De))
         assert np.max(np.abs(Zl - Ze[:, span[0]:span[1]])) < 1e-9
+        # ---- nn_ksvd on shards: Gram matrix + one scalar / one n-vector per projection pass == the oracle on the full data
+        rsn = np.random.RandomState(11)
+        Dn = np.abs(rsn.randn(n, K)) + 0.05
+        Dn /= np.sqrt((Dn * Dn).sum(0))
+        Zn = np.zeros((K, N))
+        for i in range(N):
+            Zn[rsn.choice(K - 1, k, replace=False), i] = np.abs(rsn.randn(k)) + 0.1
+        Xn = np.abs(Dn @ Zn + 0.05 * rsn.randn(n, N))
+        users = np.flatnonzero(Zn[0] != 0)
+        Xn[:, users] -= np.outer(Dn[:, 0], 3.0 * Zn[0, users])      # atom 0: x = max(Rk'u, 0) = 0 -> skipped (ksvd.py:79-82)
+        for cyc in (0, 2):
+            Dl, Zl = Dn.copy(), Zn[:, span[0]:span[1]].copy()
+            unused = ld.nn_ksvd_cycle_sharded(NumpyNnKsvdOps(Xn[:, span[0]:span[1]], Dl, Zl), K, cyc)
+            Dq, Zq, uq = orc.nn_ksvd(Xn, Dn.copy(), Zn.copy(), n_cycles=cyc)
+            assert unused == list(uq) == [K - 1]
+            assert np.array_equal(Dq[:, 0], Dn[:, 0]) and np.array_equal(Dl[:, 0], Dn[:, 0])     # the skipped atom
+            assert np.max(np.abs(Dl - Dq)) < 1e-9, (cyc, np.max(np.abs(Dl - Dq)))
+            assert np.max(np.abs(Zl - Zq[:, span[0]:span[1]])) < 1e-9
         # ---- the block sweep (one slab all-reduce per block of B atoms) == sequential reference semantics
         for B in (4, 8):
             Dl, Zl = D0.copy(), Z[:, span[0]:span[1]].copy()

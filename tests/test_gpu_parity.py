@@ -772,6 +772,16 @@ def _sharded_worker(rank, world, port, out, backend="gloo"):
         Dx, _ = ksvd_dict_learn(Xl, 48, init_dict='data', sparse_coder=se, max_iter=2, approx=False, verbose=False,
                                 return_codes=False, group=dist.group.WORLD, shard_span=span, n_total=X.shape[1])
         res.update(D_exact=dd2.to_host(), coef_exact=c2.cpu().numpy(), unused_exact=ux, Dx=Dx)
+        # ---- nn_ksvd on shards (golden F14's non-negative data): Gram matrix + one scalar / one n-vector per projection pass
+        g14 = load_golden("F14")
+        X14, D14, Z14 = g14["X"].astype(np.float64), g14["D0"].astype(np.float64), g14["Z0"].astype(np.float64)
+        Xl14, span14 = ld.local_shard(X14)
+        Xs14 = eng.signals_to_device(Xl14)
+        dd3 = eng.DeviceDictionary.from_host(D14)
+        i3, c3, z3 = eng.sparsify_host(Z14[:, span14[0]:span14[1]])
+        R3, _ = eng.residual(Xs14, dd3, i3, c3, z3, want_R=True, want_err=False)
+        un3 = eng.ksvd_exact_cycle(R3, dd3, i3, c3, z3, group=dist.group.WORLD, nn_cycles=1)
+        res.update(D_nn=dd3.to_host(), Z_nn=eng.densify(i3, c3, z3, D14.shape[1]), unused_nn=un3, span14=span14)
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -927,6 +937,14 @@ def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
                             return_codes=False)
     assert np.array_equal(r0["Dx"], r1["Dx"]) and _atom_err(r0["Dx"], Dx) < 1e-3
     assert np.max(np.abs(r0["Ao"] - Ao)) < 1e-4 * np.abs(Ao).max()
+    # nn_ksvd on 2 shards == the reference's own run on the full data (golden F14, n_cycles = 1)
+    g14 = load_golden("F14")
+    assert np.array_equal(r0["D_nn"], r1["D_nn"])                         # replicated, bit-identical
+    assert r0["unused_nn"] == r1["unused_nn"] == list(g14["c1_unused"])
+    assert _atom_err(r0["D_nn"], g14["c1_D"]) < 2e-5, _atom_err(r0["D_nn"], g14["c1_D"])
+    Znn = np.concatenate([r0["Z_nn"], r1["Z_nn"]], axis=1)
+    assert np.max(np.abs(Znn - g14["c1_Z"])) < 2e-5 * np.abs(g14["c1_Z"]).max()
+    assert np.array_equal(Znn != 0, g14["c1_Z"] != 0)
 
 
 # ------------------------------------------------------------------------------------------------ more shapes
