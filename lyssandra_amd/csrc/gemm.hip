@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void alpha0_n64_kernel(cons
 // Which feature a (register slot, lane half) pair of the MFMA's K = 16 carries is irrelevant as long as A and B use the
 // same assignment: slot s of half h carries feature 16 ks + 8 h + s for both.
 // ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int b3_slot(int k0) { return k0 < 3 ? k0 : k0 - 1; }  // store positions 0,1,2,4,5,6 of a k-step -> 0..5
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -417,6 +418,12 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 // atom planes go through LDS (3 x 64 x 144 B per buffer, double buffered: one barrier per iteration), which leaves room
 // for two workgroups per CU -- with one, every prologue / barrier / store drain is exposed (measured 0.39 ms against
 // 0.35 ms for the fp32 kernel).
+// XPOSE (round 4): the stores of a tile go through a wave-private 4-KB LDS transposition and leave as dwordx4 row
+// stores (8 per tile and wave instead of 32 dword stores), still spread between the MFMAs of the next tile.  The counters
+// say why (tools/pmc_store.sh): with dword stores the SQ -> TA address FIFO of the alpha0 kernel is full 97 % of the
+// kernel's duration (SQ_VMEM_TA_ADDR_FIFO_FULL) -- the kernel is bound by the NUMBER of store instructions the texture
+// addresser takes (one per ~38 cycles and CU = 3.6 TB/s), not by DRAM.
+template <bool XPOSE>
 __global__ __launch_bounds__(256, 2) void alpha0_n64_bf16x3_kernel(const float* __restrict__ X, int64_t ldx,
                                                                   const unsigned* __restrict__ Dsp,
                                                                   float* __restrict__ C, int Kp, int n) {
@@ -510,6 +517,33 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_bf16x3_kernel(const float* 
             }
         }
     };
+    // ---- XPOSE epilogue: 24 slots per tile (one behind every MFMA pair).  Signal block i = slot / 12: slots 0..7 write the
+    // block's 16 accumulator registers to the wave's LDS region [32 signals][32 atoms] (unpadded: the b128 lane groups of
+    // the read-back cover all 64 banks), slot 8 reads them back as four float4 (lane = (signal % 8, atom quad)), slot 10
+    // issues the four dwordx4 stores (8 signal rows x 128 B each)
+    float* Tw = reinterpret_cast<float*>(smem3) + BUF + wid * 1024;   // behind the two atom buffers (2 BUF shorts = BUF floats)
+    const int t_wr = (4 * h) * 32 + l31, t_rd = (lane >> 3) * 32 + (lane & 7) * 4;
+    const int lane_off4 = ((lane >> 3) * Kp + (lane & 7) * 4) * (int)sizeof(float);
+    f32x4v tq[4];
+    auto epi = [&](f32x16 (&acc)[2], int bn, int slot) __attribute__((always_inline)) {
+        const int i = slot / 12, sl = slot % 12;
+        if (sl < 8) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int r = 2 * sl + c;
+                Tw[((r & 3) + 8 * (r >> 2)) * 32 + t_wr] = acc[i][r];
+            }
+        } else if (sl == 8) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) tq[p] = *reinterpret_cast<const f32x4v*>(&Tw[t_rd + 8 * p * 32]);
+        } else if (sl == 10) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int soff = ((wsig * 64 + i * 32 + 8 * p) * Kp + bn + watom * 32) * (int)sizeof(float);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tq[p]), rsrc, lane_off4, soff, 2 /* nt */);
+            }
+        }
+    };
     int it = 0;
     auto tile = [&](f32x16 (&cur)[2], f32x16 (&prev)[2], int bn, bool have_prev) __attribute__((always_inline)) {
         const int buf = it & 1;
@@ -529,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_bf16x3_kernel(const float* 
                 b[pl] = *reinterpret_cast<const bf16x8*>(&Bs[buf * BUF + (pl * 64 + watom * 32 + l31) * B3_LD + ks * 16 + h * 8]);
             // small terms first; the two signal blocks alternate (a dependent MFMA waits for its predecessor); the
             // previous tile's stores are spread between the MFMA pairs (a store issues in the shadow of a running MFMA)
-#define B3_ST(k0, cnt) do { if (have_prev) store_some(prev, bn - 64, ks * 8 + (k0), (cnt)); } while (0)
+#define B3_ST(k0, cnt) do { if (have_prev) { if constexpr (XPOSE) epi(prev, bn - 64, ks * 6 + b3_slot(k0)); else store_some(prev, bn - 64, ks * 8 + (k0), (cnt)); } } while (0)
             cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks][2], b[0], cur[0], 0, 0, 0);
             cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks][2], b[0], cur[1], 0, 0, 0);
             B3_ST(0, 1);
@@ -563,13 +597,23 @@ __global__ __launch_bounds__(256, 2) void alpha0_n64_bf16x3_kernel(const float* 
             pending_b = true;
         } else {
             pending_b = false;
+            if constexpr (XPOSE) {
 #pragma unroll
-            for (int part = 0; part < 4; ++part) store_part(accA, bn, part);
+                for (int slot = 0; slot < 24; ++slot) epi(accA, bn, slot);
+            } else {
+#pragma unroll
+                for (int part = 0; part < 4; ++part) store_part(accA, bn, part);
+            }
         }
     }
     if (pending_b) {
+        if constexpr (XPOSE) {
 #pragma unroll
-        for (int part = 0; part < 4; ++part) store_part(accB, Kp - 64, part);
+            for (int slot = 0; slot < 24; ++slot) epi(accB, Kp - 64, slot);
+        } else {
+#pragma unroll
+            for (int part = 0; part < 4; ++part) store_part(accB, Kp - 64, part);
+        }
     }
 }
 
@@ -795,16 +839,24 @@ int alpha0_n64_bf16x3(const float* X, int64_t ldx, const float* D, int ldd, floa
         static bool attr_set[64] = {false};
         int dev = 0;
         LYS_CHECK_HIP(hipGetDevice(&dev));
-        const int lds = 2 * 3 * 64 * B3_LD * (int)sizeof(unsigned short);   // two atom-tile buffers (>= the one-off fp32 staging)
+        const int lds0 = 2 * 3 * 64 * B3_LD * (int)sizeof(unsigned short);   // two atom-tile buffers (>= the one-off fp32 staging)
+        const int lds1 = lds0 + 4 * 1024 * (int)sizeof(float);               // + the four waves' transposition regions
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_bf16x3_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_bf16x3_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds0));
+            LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_bf16x3_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+
             attr_set[dev] = true;
         }
         unsigned* Dsp = static_cast<unsigned*>(scratch);
         if (!presplit)
             hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((Kp * 32 + 255) / 256)), dim3(256), 0, stream, D, ldd, Kp, n, Dsp);
-        hipLaunchKernelGGL(alpha0_n64_bf16x3_kernel, dim3((unsigned)whole), dim3(256), lds, stream, X, ldx, Dsp, C, Kp, n);
+        const char* xe = getenv("LYS_A0_XPOSE");   // =0: the dword-store epilogue of rounds 2-3 (read per call: A/B inside one job)
+        if (xe && xe[0] == '0')
+            hipLaunchKernelGGL(alpha0_n64_bf16x3_kernel<false>, dim3((unsigned)whole), dim3(256), lds0, stream, X, ldx, Dsp, C, Kp, n);
+        else
+            hipLaunchKernelGGL(alpha0_n64_bf16x3_kernel<true>, dim3((unsigned)whole), dim3(256), lds1, stream, X, ldx, Dsp, C, Kp, n);
         LYS_LAUNCH_CHECK();
     }
     if (tail) return alpha0_n64(X + whole * 128 * ldx, ldx, D, ldd, C + whole * 128 * Kp, Kp, tail, n, stream);
