@@ -757,19 +757,30 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_bf16x3_kernel(const flo
             __syncthreads();
         }
     }
+    // epilogue: every 32 x 32 accumulator tile through a wave-private 4-KB LDS transposition (the staging buffers are free:
+    // the loop ended with a barrier), then four dwordx4 row stores of 8 rows x 128 B instead of 16 dword stores -- the dword
+    // form is bound by the number of store instructions the texture addresser takes (see alpha0_n64_bf16x3_kernel)
+    float* Tw = reinterpret_cast<float*>(As) + wid * 1024;   // 8 waves x 4 KB <= the 30 KB of As
+    const int t_wr = (4 * h) * 32 + l31, t_rd = (lane >> 3) * 32 + (lane & 7) * 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int col = bn + wn * (32 * NJ) + j * 32 + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int r = 0; r < 16; ++r) Tw[((r & 3) + 8 * (r >> 2)) * 32 + t_wr] = acc[i][j][r];
+            f32x4v tq[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) tq[p] = *reinterpret_cast<const f32x4v*>(&Tw[t_rd + 8 * p * 32]);
+            const int col = bn + wn * (32 * NJ) + j * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int64_t row = bm + wm * 64 + i * 32 + 8 * p + (lane >> 3);
                 if (row < M) {
+                    f32x4v* dst = reinterpret_cast<f32x4v*>(&C[row * ldc + col]);
                     if constexpr (STREAM_C)
-                        __builtin_nontemporal_store(acc[i][j][r], &C[row * ldc + col]);
+                        __builtin_nontemporal_store(tq[p], dst);
                     else
-                        C[row * ldc + col] = acc[i][j][r];
+                        *dst = tq[p];
                 }
             }
         }
