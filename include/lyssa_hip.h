@@ -211,6 +211,17 @@ int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k,
                          const int32_t* row_ptr, const int32_t* entry, float* coef,
                          double* work, size_t work_bytes, float* D_packed, float* D_next,
                          int64_t max_support, void* stream);
+/* The same cycle with the codes' atom indices idx [N][k] at hand (round 4).  For n <= 64, k <= 16 the sweep is PIPELINED: two
+ * dependent launches per atom instead of four -- the Gram products of the next used atom (over the signals that do not use
+ * this one) run beside this atom's eigen-solve; the signals that use both get the pending update and enter the Gram matrix
+ * in the next launch, beside the apply of the previous atom (csrc/ksvd.hip, exact_k1_kernel / exact_k2_kernel).  Same
+ * Gauss-Seidel order as lys_ksvd_exact_sweep; sums in a different fixed order (results agree to rounding).
+ * nnz_total >= row_ptr[K]; work: lys_ksvd_exact_idx_workspace_bytes(n, K, nnz_total) (16-byte aligned). */
+size_t lys_ksvd_exact_idx_workspace_bytes(int n, int K, int64_t nnz_total);
+int lys_ksvd_exact_sweep_idx(float* R, int64_t ldr, int n, int K, int k,
+                             const int32_t* row_ptr, const int32_t* entry, const int32_t* idx, float* coef,
+                             double* work, size_t work_bytes, float* D_packed, float* D_next,
+                             int64_t max_support, int64_t nnz_total, void* stream);
 /*
  * Non-negative K-SVD cycle, lyssa/dict_learning/ksvd.py:46-95 (`nn_ksvd`; ksvd_dict_learn(non_neg=True, approx=False),
  * :187-188, which passes the ITERATION INDEX as n_cycles): per atom the rank-1 solve of the exact update, then

@@ -69,7 +69,8 @@ int ksvd_atom_apply(int, float*, int64_t, int, int, const int32_t*, const int32_
                     const float*, float*, hipStream_t);
 int ksvd_commit(int, int, const int32_t*, const float*, float*, hipStream_t);
 int ksvd_exact_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
-                     int64_t, hipStream_t, int nn_cycles, float* xbuf);
+                     int64_t, hipStream_t, int, float*, const int32_t* = nullptr, void* = nullptr, int64_t = 0);
+size_t ksvd_exact_link_bytes(int, int64_t);
 size_t ksvd_exact_work_doubles(int);
 size_t nn_ksvd_state_offset_doubles(int);
 int nn_ksvd_phase(int, int, float*, int64_t, int, int, const int32_t*, const int32_t*, const int32_t*, float*, const double*,
@@ -690,6 +691,22 @@ int lys_ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32
     LYS_REQUIRE(work_bytes >= ksvd_exact_work_doubles(n) * sizeof(double), "ksvd_exact_sweep: work buffer too small");
     return ksvd_exact_sweep(R, ldr, n, K, k, row_ptr, entry, coef, work, D_packed, D_next, max_support, STREAM(stream), -1,
                             nullptr);
+}
+
+size_t lys_ksvd_exact_idx_workspace_bytes(int n, int K, int64_t nnz_total) {
+    if (K < 0 || nnz_total < 0) return 0;
+    return ksvd_exact_work_doubles(n) * sizeof(double) + ksvd_exact_link_bytes(K, nnz_total);
+}
+
+int lys_ksvd_exact_sweep_idx(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
+                             const int32_t* idx, float* coef, double* work, size_t work_bytes, float* D_packed,
+                             float* D_next, int64_t max_support, int64_t nnz_total, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && idx && coef && work && D_packed && D_next && (ldr % 4) == 0 && max_support >= 0 &&
+                    nnz_total >= 0 && K >= 0, "ksvd_exact_sweep_idx: bad arguments");
+    const size_t base = ksvd_exact_work_doubles(n) * sizeof(double);
+    LYS_REQUIRE(work_bytes >= base + ksvd_exact_link_bytes(K, nnz_total), "ksvd_exact_sweep_idx: work buffer too small");
+    return ksvd_exact_sweep(R, ldr, n, K, k, row_ptr, entry, coef, work, D_packed, D_next, max_support, STREAM(stream), -1,
+                            nullptr, idx, reinterpret_cast<char*>(work) + base, nnz_total);
 }
 
 int lys_nn_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,

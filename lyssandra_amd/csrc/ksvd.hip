@@ -1141,21 +1141,22 @@ int exact_debug_stamps(unsigned long long* out16) {
 // part[b][64][64] with plain stores and the eigen-solver sums the P partials in fp64 while it loads C.
 constexpr int G64_MAX_PARTS = 256;
 constexpr int G64_ROWS = 768;  // most signals one workgroup takes (descriptor staging area)
+constexpr int G64_SKIP = 0x7fc00001;
 
-__global__ __launch_bounds__(256) void ksvd_gram64_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n, int k,
-                                                          const int32_t* __restrict__ row_ptr,
-                                                          const int32_t* __restrict__ entry,
-                                                          const float* __restrict__ coef, const float* __restrict__ D,
-                                                          int ldd, float* __restrict__ part) {
+// eflag (may be null): per-entry flags of the pipelined sweep below; an entry with bit 0 set (its signal also uses the previous
+// used atom) contributes nothing here.
+__device__ __forceinline__ void gram64_part(int atom, int bx, int P, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                            const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+                                            const uint8_t* __restrict__ eflag, const float* __restrict__ coef,
+                                            const float* __restrict__ D, int ldd, float* __restrict__ part) {
     __shared__ float s_a[64][65];
     __shared__ int64_t s_off[G64_ROWS];
     __shared__ float s_x[G64_ROWS];
     const int beg = row_ptr[atom], m = row_ptr[atom + 1] - beg;
     if (m <= 0) return;
-    const int P = gridDim.x;
     int chunk = (m + P - 1) / P;
     chunk = ((chunk + 63) >> 6) << 6;
-    const int e0 = blockIdx.x * chunk, cnt = max(0, min(chunk, m - e0));
+    const int e0 = bx * chunk, cnt = max(0, min(chunk, m - e0));
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ti = wid >> 1, tj = wid & 1;
     const unsigned long long ts0 = wall_clock64();
@@ -1163,8 +1164,10 @@ __global__ __launch_bounds__(256) void ksvd_gram64_kernel(int atom, const float*
     f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < cnt; i += 256) {
         const int ss = entry[beg + e0 + i];
+        const int fl = eflag ? eflag[beg + e0 + i] : 0;
         s_off[i] = (int64_t)(ss / k) * ldr;
-        s_x[i] = coef[ss];
+        // this NaN pattern marks a row that is left out (x_i is finite: the coder's output); compared as bits below
+        s_x[i] = (fl & 1) ? __builtin_bit_cast(float, G64_SKIP) : coef[ss];
     }
     const float d = (lane < n) ? D[(int64_t)atom * ldd + lane] : 0.f;
     __syncthreads();
@@ -1186,7 +1189,9 @@ __global__ __launch_bounds__(256) void ksvd_gram64_kernel(int atom, const float*
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int i = r0 + wid + 4 * q;
-            s_a[wid + 4 * q][lane] = (i < cnt && lane < n) ? fmaf(d, s_x[min(i, cnt - 1)], cur[q]) : 0.f;
+            const float xi = s_x[min(i, cnt - 1)];
+            s_a[wid + 4 * q][lane] =
+                (i < cnt && lane < n && __builtin_bit_cast(int, xi) != G64_SKIP) ? fmaf(d, xi, cur[q]) : 0.f;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll 8
@@ -1199,19 +1204,38 @@ __global__ __launch_bounds__(256) void ksvd_gram64_kernel(int atom, const float*
         for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
     }
     const unsigned long long ts2 = wall_clock64();
-    float* out = part + (int64_t)blockIdx.x * 4096;
+    float* out = part + (int64_t)bx * 4096;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3), col = lane & 31;
         out[(32 * ti + row) * 64 + 32 * tj + col] = acc[r];
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (bx == 0 && tid == 0) {
         g_exact_stamp[8] = ts0;
         g_exact_stamp[9] = ts1;
         g_exact_stamp[10] = ts2;
         g_exact_stamp[11] = wall_clock64();
         g_exact_stamp[12] = (unsigned long long)cnt;
     }
+}
+
+__global__ __launch_bounds__(256) void ksvd_gram64_kernel(int atom, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                                          const int32_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ entry,
+                                                          const float* __restrict__ coef, const float* __restrict__ D,
+                                                          int ldd, float* __restrict__ part) {
+    gram64_part(atom, (int)blockIdx.x, (int)gridDim.x, R, ldr, n, k, row_ptr, entry, nullptr, coef, D, ldd, part);
+}
+
+__device__ __forceinline__ int prev_used_atom(const int32_t* __restrict__ row_ptr, int a) {
+    int p = a - 1;
+    while (p >= 0 && row_ptr[p] >= row_ptr[p + 1]) --p;  // uniform; unused atoms are rare
+    return p;  // -1: none
+}
+__device__ __forceinline__ int next_used_atom(const int32_t* __restrict__ row_ptr, int a, int K) {
+    int q = a + 1;
+    while (q < K && row_ptr[q] >= row_ptr[q + 1]) ++q;
+    return q;  // K: none
 }
 
 constexpr int EIG_M = 24;  // Lanczos steps (Krylov dimension)
@@ -1602,9 +1626,12 @@ __device__ __forceinline__ double wave_sum_d(double x) {
 // threads only share the load of C (sum of the fp32 partials in fp64), then waves 1..3 retire.
 constexpr int E64_QS = 65;  // row stride of the Krylov basis (doubles): lanes reading different rows hit different banks
 
-__global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const int32_t* __restrict__ row_ptr,
-                                                         const float* __restrict__ part, int parts,
-                                                         const float* __restrict__ D, int ldd, float* __restrict__ Dnext) {
+constexpr int XL_SH = 4;  // workgroups (= fp32 partials) of the shared-row Gram part of the pipelined sweep below
+
+// spart / ns: ns <= XL_SH more fp32 partials (64 x 64 each) to add to the fp64 sum (parts < 0 only)
+__device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __restrict__ row_ptr,
+                                           const float* __restrict__ part, int parts, const float* __restrict__ spart, int ns,
+                                           const float* __restrict__ D, int ldd, float* __restrict__ Dnext) {
     __shared__ double Cl[64 * 64];
     __shared__ double Q[(EIG_M + 1) * E64_QS];
     __shared__ double H[EIG_M][EIG_M], T[EIG_M][EIG_M], T2[EIG_M][EIG_M];
@@ -1618,6 +1645,21 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
         double2 v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = C2[tid + 256 * q];
+        if (ns > 0) {  // uniform; all loads issued from clamped partial indices, masked adds in a fixed order
+            const float2* S2 = reinterpret_cast<const float2*>(spart);
+            float2 w[XL_SH][8];
+#pragma unroll
+            for (int t = 0; t < XL_SH; ++t)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w[t][q] = S2[(int64_t)min(t, ns - 1) * 2048 + tid + 256 * q];
+#pragma unroll
+            for (int t = 0; t < XL_SH; ++t)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    v[q].x += (t < ns) ? (double)w[t][q].x : 0.0;
+                    v[q].y += (t < ns) ? (double)w[t][q].y : 0.0;
+                }
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             Cl[2 * (tid + 256 * q)] = v[q].x;
@@ -1760,6 +1802,252 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
         g_exact_stamp[3] = wall_clock64();
         g_exact_stamp[4] = (unsigned long long)m;
     }
+}
+
+__global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const int32_t* __restrict__ row_ptr,
+                                                         const float* __restrict__ part, int parts,
+                                                         const float* __restrict__ D, int ldd, float* __restrict__ Dnext) {
+    eig64_body(atom, n, row_ptr, part, parts, nullptr, 0, D, ldd, Dnext);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 4: the PIPELINED exact sweep (n <= 64, k <= 16, the codes' atom indices at hand): TWO dependent launches per atom
+// instead of four, with the Gram products of the NEXT atom beside the eigen-solve of this one.
+//   The Gram matrix of atom a only depends on the update of the previous used atom p through the signals that use BOTH
+//   (about 1 % of either list at configs[1]).  So the sweep splits every atom's list by two per-entry flags, set once per
+//   sweep by exact_link_kernel (bit 0: the signal also uses p, bit 1: it also uses the next used atom), and runs
+//     K2(p):  [eigen-solve of p -> u_p]  beside  [Gram partials of a over the rows WITHOUT bit 0]
+//     K1(a):  [fp64 sum of those partials]  beside  [the shared rows (a, p): p's pending update rk = R_i + d_p x_p,
+//             x_p' = rk . u_p, R_i = rk - u_p x_p' (ksvd.py:36-40) applied in place, then their Gram partials]  beside
+//             [the apply of p on its rows WITHOUT bit 1]
+//     K2(a):  [eigen-solve of a on sum + shared partials]  beside  [Gram partials of the next used atom] ...
+//   Every residual row is written by exactly one workgroup of one launch, and read by a Gram part only in a launch after
+//   the one that wrote it: the Gauss-Seidel order of ksvd.py:28-43 is kept exactly (the sums are taken in a different --
+//   fixed -- order than the four-launch path, so the two agree to rounding, not bit for bit).
+//   Unused atoms launch and retire at once; K2(-1) opens the sweep (Gram of the first used atom), K1(K) closes it (apply
+//   of the last used one).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void exact_link_kernel(int K, int k, const int32_t* __restrict__ row_ptr,
+                                                         const int32_t* __restrict__ entry, const int32_t* __restrict__ idx,
+                                                         const float* __restrict__ coef, uint8_t* __restrict__ eflag,
+                                                         int2* __restrict__ shpair, int32_t* __restrict__ nsh) {
+    __shared__ int s_w[4];
+    const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int beg = row_ptr[a], end = row_ptr[a + 1];
+    if (beg >= end) {
+        if (tid == 0) nsh[a] = 0;
+        return;
+    }
+    const int p = prev_used_atom(row_ptr, a), nx = next_used_atom(row_ptr, a, K);
+    int filled = 0;  // shared entries found so far (uniform)
+    for (int b0 = beg; b0 < end; b0 += 256) {
+        const int e = b0 + tid;
+        const bool valid = e < end;
+        const int ss = entry[min(e, end - 1)];
+        const int sig = ss / k;
+        int ps = -1, nsl = -1;
+        // membership as the CSR index defines it (csr_count_or_fill_kernel: coef != 0); all loads issued together
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t at = (int64_t)sig * k + min(j, k - 1);
+            const int aj = idx[at];
+            const bool live = j < k && coef[at] != 0.f;
+            ps = (live && aj == p) ? j : ps;
+            nsl = (live && aj == nx) ? j : nsl;
+        }
+        const bool shp = valid && p >= 0 && ps >= 0;
+        const bool shn = valid && nx < K && nsl >= 0;
+        if (valid) eflag[e] = (uint8_t)((shp ? 1 : 0) | (shn ? 2 : 0));
+        // stable compaction of the (a, p) shared entries: (coefficient position of a, of p), in list (= signal) order
+        const unsigned long long bal = __ballot(shp);
+        if (lane == 0) s_w[wid] = __popcll(bal);
+        __syncthreads();
+        int off = filled;
+        for (int w = 0; w < wid; ++w) off += s_w[w];
+        if (shp) shpair[beg + off + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(ss, sig * k + ps);
+        filled += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) nsh[a] = filled;
+}
+
+__device__ __forceinline__ int xl_shared_chunk(int ns) {  // shared rows per workgroup of K1's shared part
+    const int c = (ns + XL_SH - 1) / XL_SH;
+    return max(64, ((c + 63) >> 6) << 6);
+}
+
+// apply of atom p on the entries of its list without flag bit 1 (FB = 1: n <= 64)
+__device__ __forceinline__ void exact_apply_unshared(int p, int bx, int nblk, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                     const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+                                                     const uint8_t* __restrict__ eflag, float* __restrict__ coef,
+                                                     const float* __restrict__ D, int ldd, const float* __restrict__ Dnext) {
+    const int beg = row_ptr[p], end = row_ptr[p + 1];
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int gteam = bx * 16 + team, nteams = nblk * 16;
+    if (beg + bx * 16 >= end) return;
+    const int f = 4 * q;
+    float4 dold = make_float4(0.f, 0.f, 0.f, 0.f), u = dold;
+    if (f < n) {
+        dold = *reinterpret_cast<const float4*>(D + (int64_t)p * ldd + f);
+        u = *reinterpret_cast<const float4*>(Dnext + (int64_t)p * ldd + f);
+    }
+    for (int e = beg + gteam; e < end; e += nteams) {
+        const int ss = entry[e];
+        const int fl = eflag[e];
+        if (fl & 2) continue;  // uniform per team: K1's shared part owns this row
+        const int64_t sig = ss / k;
+        const float xo = coef[ss];
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < n) r = *reinterpret_cast<const float4*>(R + sig * ldr + f);
+        float4 rk;
+        rk.x = fmaf(dold.x, xo, r.x);
+        rk.y = fmaf(dold.y, xo, r.y);
+        rk.z = fmaf(dold.z, xo, r.z);
+        rk.w = fmaf(dold.w, xo, r.w);
+        float dot = fmaf(rk.x, u.x, 0.f);
+        dot = fmaf(rk.y, u.y, dot);
+        dot = fmaf(rk.z, u.z, dot);
+        dot = fmaf(rk.w, u.w, dot);
+        const float xn = row16_sum(dot);
+        if (f < n) {
+            float4 o;
+            o.x = fmaf(-u.x, xn, rk.x);
+            o.y = fmaf(-u.y, xn, rk.y);
+            o.z = fmaf(-u.z, xn, rk.z);
+            o.w = fmaf(-u.w, xn, rk.w);
+            *reinterpret_cast<float4*>(R + sig * ldr + f) = o;
+        }
+        if (q == 0) coef[ss] = xn;
+    }
+}
+
+// the (atom, p) shared rows: p's pending update in place, then their Gram partial (gram64_part's tiling)
+__device__ __forceinline__ void exact_shared_part(int atom, int p, int sb, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                  const int32_t* __restrict__ row_ptr, const int2* __restrict__ shpair,
+                                                  const int32_t* __restrict__ nsh, float* __restrict__ coef,
+                                                  const float* __restrict__ D, int ldd, const float* __restrict__ Dnext,
+                                                  float* __restrict__ spart) {
+    __shared__ float s_a[64][65];
+    __shared__ int64_t s_off[G64_ROWS];
+    __shared__ float s_x[G64_ROWS], s_xp[G64_ROWS];
+    __shared__ int s_pc[G64_ROWS];
+    const int ns = nsh[atom];
+    const int chunk = xl_shared_chunk(ns);
+    const int j0 = sb * chunk, total = min(chunk, ns - j0);
+    if (total <= 0) return;
+    const int beg = row_ptr[atom];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ti = wid >> 1, tj = wid & 1;
+    using f16v = __attribute__((ext_vector_type(16))) float;
+    f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float d = (lane < n) ? D[(int64_t)atom * ldd + lane] : 0.f;
+    const float dprev = (lane < n) ? D[(int64_t)p * ldd + lane] : 0.f;
+    const float uprev = (lane < n) ? Dnext[(int64_t)p * ldd + lane] : 0.f;
+    const int lf = min(lane, n - 1);
+    for (int b0 = 0; b0 < total; b0 += G64_ROWS) {  // one batch unless an atom shares > 768 * XL_SH signals with its predecessor
+        const int cnt = min(G64_ROWS, total - b0);
+        __syncthreads();
+        for (int i = tid; i < cnt; i += 256) {
+            const int2 pr = shpair[beg + j0 + b0 + i];
+            s_off[i] = (int64_t)(pr.x / k) * ldr;
+            s_x[i] = coef[pr.x];
+            s_pc[i] = pr.y;
+            s_xp[i] = coef[pr.y];
+        }
+        __syncthreads();
+        for (int r0 = 0; r0 < cnt; r0 += 64) {
+            float cur[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cur[q] = R[s_off[min(r0 + wid + 4 * q, cnt - 1)] + lf];
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the previous round's MFMAs have read s_a
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = r0 + wid + 4 * q;  // wave-uniform: a wave stages one row at a time
+                float v = 0.f;
+                if (i < cnt) {
+                    const float rk = (lane < n) ? fmaf(dprev, s_xp[i], cur[q]) : 0.f;
+                    const float xn = wave_sum_f(rk * uprev);
+                    const float rn = fmaf(-uprev, xn, rk);
+                    if (lane < n) R[s_off[i] + lane] = rn;
+                    if (lane == 0) coef[s_pc[i]] = xn;
+                    v = (lane < n) ? fmaf(d, s_x[i], rn) : 0.f;
+                }
+                s_a[wid + 4 * q][lane] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 8
+            for (int i = 0; i < 64; i += 2) {
+                const int kk = i + (lane >> 5);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_a[kk][32 * ti + (lane & 31)], s_a[kk][32 * tj + (lane & 31)], acc,
+                                                           0, 0, 0);
+            }
+        }
+    }
+    float* out = spart + (int64_t)sb * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3), col = lane & 31;
+        out[(32 * ti + row) * 64 + 32 * tj + col] = acc[r];
+    }
+}
+
+// K1(atom), atom in [0, K]: blocks [0, 16) sum the Gram partials, [16, 16 + XL_SH) take the shared rows, the rest apply p.
+// atom == K: only the apply (of the last used atom).
+__global__ __launch_bounds__(256) void exact_k1_kernel(int atom, int K, int parts, float* __restrict__ R, int64_t ldr, int n, int k,
+                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+                                                       const uint8_t* __restrict__ eflag, const int2* __restrict__ shpair,
+                                                       const int32_t* __restrict__ nsh, float* __restrict__ coef,
+                                                       const float* __restrict__ D, int ldd, const float* __restrict__ Dnext,
+                                                       const float* __restrict__ part, double* __restrict__ Csum,
+                                                       float* __restrict__ spart) {
+    if (atom < K && row_ptr[atom] >= row_ptr[atom + 1]) return;
+    const int bx = blockIdx.x;
+    if (bx < 16) {
+        if (atom >= K) return;
+        const int e = bx * 256 + threadIdx.x;  // ksvd_gram64_reduce_kernel's sum, same order
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < parts; p0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = part[(int64_t)min(p0 + u, parts - 1) * 4096 + e];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u & 3] += (p0 + u < parts) ? (double)v[u] : 0.0;
+        }
+        Csum[e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        return;
+    }
+    const int p = prev_used_atom(row_ptr, atom);
+    if (p < 0) return;
+    if (bx < 16 + XL_SH) {
+        if (atom < K)
+            exact_shared_part(atom, p, bx - 16, R, ldr, n, k, row_ptr, shpair, nsh, coef, D, ldd, Dnext, spart);
+        return;
+    }
+    exact_apply_unshared(p, bx - 16 - XL_SH, (int)gridDim.x - 16 - XL_SH, R, ldr, n, k, row_ptr, entry, eflag, coef, D, ldd, Dnext);
+}
+
+// K2(atom), atom in [-1, K): block 0 solves atom's eigenproblem, blocks [1, 1 + parts) form the Gram partials of the next
+// used atom over the rows its predecessor (= atom) does not touch.
+__global__ __launch_bounds__(256) void exact_k2_kernel(int atom, int K, const float* __restrict__ R, int64_t ldr, int n, int k,
+                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+                                                       const uint8_t* __restrict__ eflag, const int32_t* __restrict__ nsh,
+                                                       const float* __restrict__ coef, const float* __restrict__ D, int ldd,
+                                                       float* __restrict__ Dnext, float* __restrict__ part,
+                                                       const double* __restrict__ Csum, const float* __restrict__ spart) {
+    if (atom >= 0 && row_ptr[atom] >= row_ptr[atom + 1]) return;
+    if (blockIdx.x == 0) {
+        if (atom < 0) return;
+        int ns = 0;
+        if (prev_used_atom(row_ptr, atom) >= 0) {
+            const int tot = nsh[atom];
+            ns = (tot + xl_shared_chunk(tot) - 1) / xl_shared_chunk(tot);
+        }
+        eig64_body(atom, n, row_ptr, reinterpret_cast<const float*>(Csum), -1, spart, ns, D, ldd, Dnext);
+        return;
+    }
+    const int nx = next_used_atom(row_ptr, atom, K);
+    if (nx >= K) return;
+    gram64_part(nx, (int)blockIdx.x - 1, (int)gridDim.x - 1, R, ldr, n, k, row_ptr, entry, eflag, coef, D, ldd, part);
 }
 
 // x_i = rk_i . u (= sigma v_i), R_i = rk_i - u x_i with u = D_next[atom] (ksvd.py:36-40)
@@ -2067,6 +2355,11 @@ constexpr size_t NN_STATE_DOUBLES = 4 + 256 + 128;
 static size_t exact_base_doubles(int n) {
     if (n <= 64) return (size_t)G64_MAX_PARTS * 4096 / 2 + 4096;  // fp32 partial Gram matrices of ksvd_gram64_kernel + their fp64 sum
     return (size_t)n * n;
+}
+// bytes of the pipelined sweep's link area for an index of nnz entries over K atoms (see ksvd_exact_sweep)
+size_t ksvd_exact_link_bytes(int K, int64_t nnz) {
+    return (size_t)XL_SH * 4096 * sizeof(float) + (((size_t)K + 3) & ~(size_t)3) * sizeof(int32_t) +
+           (size_t)nnz * sizeof(int2) + (((size_t)nnz + 15) & ~(size_t)15);
 }
 size_t ksvd_exact_work_doubles(int n) {
     if (n <= 256) return exact_base_doubles(n) + NN_STATE_DOUBLES;
@@ -2419,7 +2712,7 @@ static int nn_atom_phase(int phase, int a, float* R, int64_t ldr, int n, int k, 
 // xbuf: max_support floats (nn only).
 int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
                      float* coef, double* work, float* D, float* Dnext, int64_t max_support, hipStream_t stream,
-                     int nn_cycles, float* xbuf) {
+                     int nn_cycles, float* xbuf, const int32_t* idx, void* link, int64_t link_nnz) {
     if (n > 256) {
         if (nn_cycles >= 0) {
             set_error("nn_ksvd: n = %d > 256 is outside the non-negative update", n);
@@ -2453,6 +2746,36 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     int parts = (int)std::min<int64_t>(G64_MAX_PARTS, std::max<int64_t>(1, (max_support + slice - 1) / slice));
     if ((max_support + parts - 1) / parts + 63 > G64_ROWS) parts = 0;  // an atom used by > 45k signals: atomics path
     if (n > 64) parts = 0;
+    // idx given (the codes' atom indices), n <= 64, k <= 16, plain exact update: the pipelined sweep (exact_k1_kernel /
+    // exact_k2_kernel: two dependent launches per atom instead of four)
+    static int pipe_env = -1;
+    if (pipe_env < 0) {
+        const char* e = getenv("LYS_EXACT_PIPELINED");
+        pipe_env = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (pipe_env && idx && link && parts > 0 && k <= 16 && nn_cycles < 0) {
+        double* Csum = work + (size_t)G64_MAX_PARTS * 4096 / 2;
+        float* gpart = reinterpret_cast<float*>(work);
+        // link area: [shared partials XL_SH x 64 x 64 floats | nsh K ints | shpair nnz int2 | eflag nnz bytes]
+        float* spart = reinterpret_cast<float*>(link);
+        int32_t* nsh = reinterpret_cast<int32_t*>(spart + (size_t)XL_SH * 4096);
+        int2* shpair = reinterpret_cast<int2*>(nsh + (((size_t)K + 3) & ~(size_t)3));
+        uint8_t* eflag = reinterpret_cast<uint8_t*>(shpair + link_nnz);
+        hipLaunchKernelGGL(exact_link_kernel, dim3((unsigned)K), dim3(256), 0, stream, K, k, row_ptr, entry, idx, coef, eflag,
+                           shpair, nsh);
+        const unsigned g1 = (unsigned)(16 + XL_SH + KSVD_BLOCKS), g2 = (unsigned)(1 + parts);
+        hipLaunchKernelGGL(exact_k2_kernel, dim3(g2), dim3(256), 0, stream, -1, K, R, ldr, n, k, row_ptr, entry, eflag, nsh, coef,
+                           D, ldd, Dnext, gpart, Csum, spart);
+        for (int a = 0; a <= K; ++a) {
+            hipLaunchKernelGGL(exact_k1_kernel, dim3(g1), dim3(256), 0, stream, a, K, parts, R, ldr, n, k, row_ptr, entry, eflag,
+                               shpair, nsh, coef, D, ldd, Dnext, gpart, Csum, spart);
+            if (a < K)
+                hipLaunchKernelGGL(exact_k2_kernel, dim3(g2), dim3(256), 0, stream, a, K, R, ldr, n, k, row_ptr, entry, eflag, nsh,
+                                   coef, D, ldd, Dnext, gpart, Csum, spart);
+        }
+        LYS_LAUNCH_CHECK();
+        return ksvd_commit(n, K, row_ptr, Dnext, D, stream);
+    }
     for (int a = 0; a < K; ++a) {
         if (parts > 0) {
             hipLaunchKernelGGL(ksvd_gram64_kernel, dim3((unsigned)parts), dim3(256), 0, stream, a, R, ldr, n, k, row_ptr, entry,

@@ -695,7 +695,11 @@ def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None, nn_cycles=
             return _d.nn_ksvd_cycle_sharded(HipNnKsvdOps(R, dd, idx, coef, nnz, buffers), dd.K, int(nn_cycles), group)
         return _d.ksvd_exact_cycle_sharded(HipExactKsvdOps(R, dd, idx, coef, nnz, buffers), dd.K, group)
     row_ptr, entry = csr_by_atom(idx, coef, nnz, dd.K)
-    need = int(lib.lys_ksvd_exact_workspace_bytes(dd.n)) // 8
+    nnz_total = int(entry.numel())
+    if nn_cycles is None:
+        need = (int(lib.lys_ksvd_exact_idx_workspace_bytes(dd.n, dd.K, nnz_total)) + 7) // 8
+    else:
+        need = int(lib.lys_ksvd_exact_workspace_bytes(dd.n)) // 8
     work = buffers.get("exact_work")
     if work is None or work.numel() < need:
         work = buffers["exact_work"] = torch.zeros((need,), dtype=torch.float64, device=dd.device)
@@ -712,9 +716,9 @@ def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None, nn_cycles=
                                          _ptr(work), work.numel() * 8, _ptr(xbuf), _ptr(dd.D), _ptr(Dnext), max_support,
                                          int(nn_cycles), _stream()), "lys_nn_ksvd_sweep")
     else:
-        _lib.check(lib.lys_ksvd_exact_sweep(_ptr(R), _ld(R), dd.n, dd.K, k, _ptr(row_ptr), _ptr(entry), _ptr(coef),
-                                            _ptr(work), work.numel() * 8, _ptr(dd.D), _ptr(Dnext), max_support,
-                                            _stream()), "lys_ksvd_exact_sweep")
+        _lib.check(lib.lys_ksvd_exact_sweep_idx(_ptr(R), _ld(R), dd.n, dd.K, k, _ptr(row_ptr), _ptr(entry), _ptr(idx),
+                                                _ptr(coef), _ptr(work), work.numel() * 8, _ptr(dd.D), _ptr(Dnext),
+                                                max_support, nnz_total, _stream()), "lys_ksvd_exact_sweep_idx")
     dd.invalidate()
     return torch.nonzero(counts == 0).flatten().cpu().numpy().tolist()
 
