@@ -1145,14 +1145,13 @@ constexpr int G64_SKIP = 0x7fc00001;
 
 // eflag (may be null): per-entry flags of the pipelined sweep below; an entry with bit 0 set (its signal also uses the previous
 // used atom) contributes nothing here.
-__device__ __forceinline__ void gram64_part(int atom, int bx, int P, const float* __restrict__ R, int64_t ldr, int n, int k,
-                                            const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+__device__ __forceinline__ void gram64_part(int atom, int beg, int m, int bx, int P, const float* __restrict__ R, int64_t ldr,
+                                            int n, int k, const int32_t* __restrict__ entry,
                                             const uint8_t* __restrict__ eflag, const float* __restrict__ coef,
                                             const float* __restrict__ D, int ldd, float* __restrict__ part) {
     __shared__ float s_a[64][65];
     __shared__ int64_t s_off[G64_ROWS];
     __shared__ float s_x[G64_ROWS];
-    const int beg = row_ptr[atom], m = row_ptr[atom + 1] - beg;
     if (m <= 0) return;
     int chunk = (m + P - 1) / P;
     chunk = ((chunk + 63) >> 6) << 6;
@@ -1224,7 +1223,9 @@ __global__ __launch_bounds__(256) void ksvd_gram64_kernel(int atom, const float*
                                                           const int32_t* __restrict__ entry,
                                                           const float* __restrict__ coef, const float* __restrict__ D,
                                                           int ldd, float* __restrict__ part) {
-    gram64_part(atom, (int)blockIdx.x, (int)gridDim.x, R, ldr, n, k, row_ptr, entry, nullptr, coef, D, ldd, part);
+    const int beg = row_ptr[atom];
+    gram64_part(atom, beg, row_ptr[atom + 1] - beg, (int)blockIdx.x, (int)gridDim.x, R, ldr, n, k, entry, nullptr, coef, D, ldd,
+                part);
 }
 
 __device__ __forceinline__ int prev_used_atom(const int32_t* __restrict__ row_ptr, int a) {
@@ -1626,6 +1627,7 @@ __device__ __forceinline__ double wave_sum_d(double x) {
 // threads only share the load of C (sum of the fp32 partials in fp64), then waves 1..3 retire.
 constexpr int E64_QS = 65;  // row stride of the Krylov basis (doubles): lanes reading different rows hit different banks
 
+constexpr int XK1_APPLY_BLOCKS = 1024;  // most apply workgroups of a K1 launch (16 entries each per pass)
 constexpr int XL_SH = 4;  // workgroups (= fp32 partials) of the shared-row Gram part of the pipelined sweep below
 
 // spart / ns: ns <= XL_SH more fp32 partials (64 x 64 each) to add to the fp64 sum (parts < 0 only)
@@ -1636,7 +1638,7 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
     __shared__ double Q[(EIG_M + 1) * E64_QS];
     __shared__ double H[EIG_M][EIG_M], T[EIG_M][EIG_M], T2[EIG_M][EIG_M];
     __shared__ double hh[EIG_M + 1], wv[64], cvec[EIG_M], ritz[2], rys[EIG_M];
-    if (row_ptr[atom] >= row_ptr[atom + 1]) return;
+    if (row_ptr && row_ptr[atom] >= row_ptr[atom + 1]) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long ts0 = wall_clock64();
     if (parts < 0) {
@@ -1785,6 +1787,9 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
             break;
         }
         Q[(j + 1) * E64_QS + lane] = w / beta;
+#ifdef LYS_EXACT_STEP_STAMPS
+        if (j < 3 && lane == 0) g_exact_stamp[5 + j] = wall_clock64();
+#endif
     }
     __builtin_amdgcn_wave_barrier();
     const unsigned long long ts2 = wall_clock64();
@@ -1815,7 +1820,7 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
 // instead of four, with the Gram products of the NEXT atom beside the eigen-solve of this one.
 //   The Gram matrix of atom a only depends on the update of the previous used atom p through the signals that use BOTH
 //   (about 1 % of either list at configs[1]).  So the sweep splits every atom's list by two per-entry flags, set once per
-//   sweep by exact_link_kernel (bit 0: the signal also uses p, bit 1: it also uses the next used atom), and runs
+//   sweep (exact_flag_kernel; bit 0: the signal also uses p, bit 1: it also uses the next used atom), and runs
 //     K2(p):  [eigen-solve of p -> u_p]  beside  [Gram partials of a over the rows WITHOUT bit 0]
 //     K1(a):  [fp64 sum of those partials]  beside  [the shared rows (a, p): p's pending update rk = R_i + d_p x_p,
 //             x_p' = rk . u_p, R_i = rk - u_p x_p' (ksvd.py:36-40) applied in place, then their Gram partials]  beside
@@ -1824,49 +1829,88 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
 //   Every residual row is written by exactly one workgroup of one launch, and read by a Gram part only in a launch after
 //   the one that wrote it: the Gauss-Seidel order of ksvd.py:28-43 is kept exactly (the sums are taken in a different --
 //   fixed -- order than the four-launch path, so the two agree to rounding, not bit for bit).
-//   Unused atoms launch and retire at once; K2(-1) opens the sweep (Gram of the first used atom), K1(K) closes it (apply
-//   of the last used one).
+//   The host reads row_ptr back once (K + 1 ints): unused atoms are skipped, and every launch gets its atoms' list bounds
+//   as kernel arguments instead of opening with a chain of dependent scalar loads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void exact_link_kernel(int K, int k, const int32_t* __restrict__ row_ptr,
+__device__ __forceinline__ float row16_max(float x) {  // max over the 16 lanes of a DPP row, in every lane
+    x = fmaxf(x, dpp_f<0xB1>(x));
+    x = fmaxf(x, dpp_f<0x4E>(x));
+    x = fmaxf(x, dpp_f<0x124>(x));
+    x = fmaxf(x, dpp_f<0x128>(x));
+    return x;
+}
+
+// pn[a] = previous used atom of a (-1: none), pn[K + a] = next used atom (K: none)
+__global__ void exact_neighbours_kernel(int K, const int32_t* __restrict__ row_ptr, int32_t* __restrict__ pn) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= K) return;
+    pn[a] = prev_used_atom(row_ptr, a);
+    pn[K + a] = next_used_atom(row_ptr, a, K);
+}
+
+// One 16-lane row per entry (lane = slot of the entry's signal): eflag[e], and plink[e] = coefficient position of the previous
+// used atom in the same signal (-1: not there).  Membership as the CSR index defines it (coef != 0).  Four entries per row
+// and pass, their loads issued together (the pass is a chain of three dependent gathers).
+__global__ __launch_bounds__(256) void exact_flag_kernel(int K, int k, const int32_t* __restrict__ row_ptr,
                                                          const int32_t* __restrict__ entry, const int32_t* __restrict__ idx,
-                                                         const float* __restrict__ coef, uint8_t* __restrict__ eflag,
-                                                         int2* __restrict__ shpair, int32_t* __restrict__ nsh) {
-    __shared__ int s_w[4];
+                                                         const float* __restrict__ coef, const int32_t* __restrict__ pn,
+                                                         uint8_t* __restrict__ eflag, int32_t* __restrict__ plink) {
+    constexpr int U = 4;
+    const int q = threadIdx.x & 15;
+    const int total = row_ptr[K];
+    const int nrows = gridDim.x * 16;
+    for (int e0 = blockIdx.x * 16 + (threadIdx.x >> 4); e0 < total; e0 += U * nrows) {
+        int ss[U], aj[U], a[U], p[U], nx[U];
+        float cj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) ss[u] = entry[min(e0 + u * nrows, total - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t at = (int64_t)(ss[u] / k) * k + min(q, k - 1);
+            aj[u] = idx[at];
+            cj[u] = coef[at];
+            a[u] = idx[ss[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            p[u] = pn[a[u]];
+            nx[u] = pn[K + a[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * nrows;
+            const bool live = q < k && cj[u] != 0.f;
+            const float ps = row16_max((live && aj[u] == p[u]) ? (float)(q + 1) : 0.f);  // p = -1 never matches a live slot
+            const float nsl = row16_max((live && aj[u] == nx[u]) ? 1.f : 0.f);           // nx = K neither
+            if (q == 0 && e < total) {
+                eflag[e] = (uint8_t)((ps > 0.f ? 1 : 0) | (nsl > 0.f ? 2 : 0));
+                plink[e] = (ps > 0.f) ? (ss[u] / k) * k + (int)ps - 1 : -1;
+            }
+        }
+    }
+}
+
+// One workgroup per atom: stable compaction of its (a, p) shared entries -- (coefficient position of a, of p) in list (=
+// signal) order -- behind row_ptr[a] of shpair, their number in nsh[a].
+__global__ __launch_bounds__(256) void exact_compact_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+                                                            const int32_t* __restrict__ plink, int2* __restrict__ shpair,
+                                                            int32_t* __restrict__ nsh) {
+    __shared__ int s_w[2][4];
     const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int beg = row_ptr[a], end = row_ptr[a + 1];
-    if (beg >= end) {
-        if (tid == 0) nsh[a] = 0;
-        return;
-    }
-    const int p = prev_used_atom(row_ptr, a), nx = next_used_atom(row_ptr, a, K);
     int filled = 0;  // shared entries found so far (uniform)
-    for (int b0 = beg; b0 < end; b0 += 256) {
+    int par = 0;
+    for (int b0 = beg; b0 < end; b0 += 256, par ^= 1) {
         const int e = b0 + tid;
-        const bool valid = e < end;
+        const int pl = (e < end) ? plink[e] : -1;
         const int ss = entry[min(e, end - 1)];
-        const int sig = ss / k;
-        int ps = -1, nsl = -1;
-        // membership as the CSR index defines it (csr_count_or_fill_kernel: coef != 0); all loads issued together
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int64_t at = (int64_t)sig * k + min(j, k - 1);
-            const int aj = idx[at];
-            const bool live = j < k && coef[at] != 0.f;
-            ps = (live && aj == p) ? j : ps;
-            nsl = (live && aj == nx) ? j : nsl;
-        }
-        const bool shp = valid && p >= 0 && ps >= 0;
-        const bool shn = valid && nx < K && nsl >= 0;
-        if (valid) eflag[e] = (uint8_t)((shp ? 1 : 0) | (shn ? 2 : 0));
-        // stable compaction of the (a, p) shared entries: (coefficient position of a, of p), in list (= signal) order
-        const unsigned long long bal = __ballot(shp);
-        if (lane == 0) s_w[wid] = __popcll(bal);
-        __syncthreads();
+        const unsigned long long bal = __ballot(pl >= 0);
+        if (lane == 0) s_w[par][wid] = __popcll(bal);
+        __syncthreads();  // (two count rows: the next round's writes cannot overtake this round's reads)
         int off = filled;
-        for (int w = 0; w < wid; ++w) off += s_w[w];
-        if (shp) shpair[beg + off + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(ss, sig * k + ps);
-        filled += s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        __syncthreads();
+        for (int w = 0; w < wid; ++w) off += s_w[par][w];
+        if (pl >= 0) shpair[beg + off + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(ss, pl);
+        filled += s_w[par][0] + s_w[par][1] + s_w[par][2] + s_w[par][3];
     }
     if (tid == 0) nsh[a] = filled;
 }
@@ -1876,12 +1920,11 @@ __device__ __forceinline__ int xl_shared_chunk(int ns) {  // shared rows per wor
     return max(64, ((c + 63) >> 6) << 6);
 }
 
-// apply of atom p on the entries of its list without flag bit 1 (FB = 1: n <= 64)
-__device__ __forceinline__ void exact_apply_unshared(int p, int bx, int nblk, float* __restrict__ R, int64_t ldr, int n, int k,
-                                                     const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+// apply of atom p (list [beg, end)) on its entries without flag bit 1 (FB = 1: n <= 64)
+__device__ __forceinline__ void exact_apply_unshared(int p, int beg, int end, int bx, int nblk, float* __restrict__ R, int64_t ldr,
+                                                     int n, int k, const int32_t* __restrict__ entry,
                                                      const uint8_t* __restrict__ eflag, float* __restrict__ coef,
                                                      const float* __restrict__ D, int ldd, const float* __restrict__ Dnext) {
-    const int beg = row_ptr[p], end = row_ptr[p + 1];
     const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
     const int gteam = bx * 16 + team, nteams = nblk * 16;
     if (beg + bx * 16 >= end) return;
@@ -1922,11 +1965,10 @@ __device__ __forceinline__ void exact_apply_unshared(int p, int bx, int nblk, fl
 }
 
 // the (atom, p) shared rows: p's pending update in place, then their Gram partial (gram64_part's tiling)
-__device__ __forceinline__ void exact_shared_part(int atom, int p, int sb, float* __restrict__ R, int64_t ldr, int n, int k,
-                                                  const int32_t* __restrict__ row_ptr, const int2* __restrict__ shpair,
-                                                  const int32_t* __restrict__ nsh, float* __restrict__ coef,
-                                                  const float* __restrict__ D, int ldd, const float* __restrict__ Dnext,
-                                                  float* __restrict__ spart) {
+__device__ __forceinline__ void exact_shared_part(int atom, int p, int beg, int sb, float* __restrict__ R, int64_t ldr, int n,
+                                                  int k, const int2* __restrict__ shpair, const int32_t* __restrict__ nsh,
+                                                  float* __restrict__ coef, const float* __restrict__ D, int ldd,
+                                                  const float* __restrict__ Dnext, float* __restrict__ spart) {
     __shared__ float s_a[64][65];
     __shared__ int64_t s_off[G64_ROWS];
     __shared__ float s_x[G64_ROWS], s_xp[G64_ROWS];
@@ -1935,7 +1977,6 @@ __device__ __forceinline__ void exact_shared_part(int atom, int p, int sb, float
     const int chunk = xl_shared_chunk(ns);
     const int j0 = sb * chunk, total = min(chunk, ns - j0);
     if (total <= 0) return;
-    const int beg = row_ptr[atom];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ti = wid >> 1, tj = wid & 1;
     using f16v = __attribute__((ext_vector_type(16))) float;
@@ -1991,19 +2032,18 @@ __device__ __forceinline__ void exact_shared_part(int atom, int p, int sb, float
     }
 }
 
-// K1(atom), atom in [0, K]: blocks [0, 16) sum the Gram partials, [16, 16 + XL_SH) take the shared rows, the rest apply p.
-// atom == K: only the apply (of the last used atom).
-__global__ __launch_bounds__(256) void exact_k1_kernel(int atom, int K, int parts, float* __restrict__ R, int64_t ldr, int n, int k,
-                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
-                                                       const uint8_t* __restrict__ eflag, const int2* __restrict__ shpair,
-                                                       const int32_t* __restrict__ nsh, float* __restrict__ coef,
-                                                       const float* __restrict__ D, int ldd, const float* __restrict__ Dnext,
-                                                       const float* __restrict__ part, double* __restrict__ Csum,
-                                                       float* __restrict__ spart) {
-    if (atom < K && row_ptr[atom] >= row_ptr[atom + 1]) return;
+// K1(atom; p = the used atom before it, -1: none): blocks [0, 16) sum atom's `parts` Gram partials, [16, 16 + XL_SH) take the
+// (atom, p) shared rows, the rest apply p.  atom < 0 closes the sweep: only the apply of p (the last used atom).
+__global__ __launch_bounds__(256) void exact_k1_kernel(int atom, int abeg, int parts, int p, int pbeg, int pend,
+                                                       float* __restrict__ R, int64_t ldr, int n, int k,
+                                                       const int32_t* __restrict__ entry, const uint8_t* __restrict__ eflag,
+                                                       const int2* __restrict__ shpair, const int32_t* __restrict__ nsh,
+                                                       float* __restrict__ coef, const float* __restrict__ D, int ldd,
+                                                       const float* __restrict__ Dnext, const float* __restrict__ part,
+                                                       double* __restrict__ Csum, float* __restrict__ spart) {
     const int bx = blockIdx.x;
     if (bx < 16) {
-        if (atom >= K) return;
+        if (atom < 0) return;
         const int e = bx * 256 + threadIdx.x;  // ksvd_gram64_reduce_kernel's sum, same order
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int p0 = 0; p0 < parts; p0 += 16) {
@@ -2016,38 +2056,32 @@ __global__ __launch_bounds__(256) void exact_k1_kernel(int atom, int K, int part
         Csum[e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         return;
     }
-    const int p = prev_used_atom(row_ptr, atom);
     if (p < 0) return;
     if (bx < 16 + XL_SH) {
-        if (atom < K)
-            exact_shared_part(atom, p, bx - 16, R, ldr, n, k, row_ptr, shpair, nsh, coef, D, ldd, Dnext, spart);
+        if (atom >= 0) exact_shared_part(atom, p, abeg, bx - 16, R, ldr, n, k, shpair, nsh, coef, D, ldd, Dnext, spart);
         return;
     }
-    exact_apply_unshared(p, bx - 16 - XL_SH, (int)gridDim.x - 16 - XL_SH, R, ldr, n, k, row_ptr, entry, eflag, coef, D, ldd, Dnext);
+    exact_apply_unshared(p, pbeg, pend, bx - 16 - XL_SH, (int)gridDim.x - 16 - XL_SH, R, ldr, n, k, entry, eflag, coef, D, ldd,
+                         Dnext);
 }
 
-// K2(atom), atom in [-1, K): block 0 solves atom's eigenproblem, blocks [1, 1 + parts) form the Gram partials of the next
-// used atom over the rows its predecessor (= atom) does not touch.
-__global__ __launch_bounds__(256) void exact_k2_kernel(int atom, int K, const float* __restrict__ R, int64_t ldr, int n, int k,
-                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
+// K2(atom, -1: none; nx = the used atom after it, -1: none): block 0 solves atom's eigenproblem, the other blocks form the Gram
+// partials of nx over the rows that atom does not touch.
+__global__ __launch_bounds__(256) void exact_k2_kernel(int atom, int nx, int nbeg, int nm, const float* __restrict__ R, int64_t ldr,
+                                                       int n, int k, const int32_t* __restrict__ entry,
                                                        const uint8_t* __restrict__ eflag, const int32_t* __restrict__ nsh,
                                                        const float* __restrict__ coef, const float* __restrict__ D, int ldd,
                                                        float* __restrict__ Dnext, float* __restrict__ part,
                                                        const double* __restrict__ Csum, const float* __restrict__ spart) {
-    if (atom >= 0 && row_ptr[atom] >= row_ptr[atom + 1]) return;
     if (blockIdx.x == 0) {
         if (atom < 0) return;
-        int ns = 0;
-        if (prev_used_atom(row_ptr, atom) >= 0) {
-            const int tot = nsh[atom];
-            ns = (tot + xl_shared_chunk(tot) - 1) / xl_shared_chunk(tot);
-        }
-        eig64_body(atom, n, row_ptr, reinterpret_cast<const float*>(Csum), -1, spart, ns, D, ldd, Dnext);
+        const int tot = nsh[atom];  // 0 for the first used atom
+        const int ns = (tot + xl_shared_chunk(tot) - 1) / xl_shared_chunk(tot);
+        eig64_body(atom, n, nullptr, reinterpret_cast<const float*>(Csum), -1, spart, ns, D, ldd, Dnext);
         return;
     }
-    const int nx = next_used_atom(row_ptr, atom, K);
-    if (nx >= K) return;
-    gram64_part(nx, (int)blockIdx.x - 1, (int)gridDim.x - 1, R, ldr, n, k, row_ptr, entry, eflag, coef, D, ldd, part);
+    if (nx < 0) return;
+    gram64_part(nx, nbeg, nm, (int)blockIdx.x - 1, (int)gridDim.x - 1, R, ldr, n, k, entry, eflag, coef, D, ldd, part);
 }
 
 // x_i = rk_i . u (= sigma v_i), R_i = rk_i - u x_i with u = D_next[atom] (ksvd.py:36-40)
@@ -2358,8 +2392,9 @@ static size_t exact_base_doubles(int n) {
 }
 // bytes of the pipelined sweep's link area for an index of nnz entries over K atoms (see ksvd_exact_sweep)
 size_t ksvd_exact_link_bytes(int K, int64_t nnz) {
-    return (size_t)XL_SH * 4096 * sizeof(float) + (((size_t)K + 3) & ~(size_t)3) * sizeof(int32_t) +
-           (size_t)nnz * sizeof(int2) + (((size_t)nnz + 15) & ~(size_t)15);
+    return (size_t)XL_SH * 4096 * sizeof(float) +
+           ((((size_t)K + 3) & ~(size_t)3) + (((size_t)2 * K + 3) & ~(size_t)3)) * sizeof(int32_t) +
+           (size_t)nnz * (sizeof(int2) + sizeof(int32_t)) + (((size_t)nnz + 15) & ~(size_t)15);
 }
 size_t ksvd_exact_work_doubles(int n) {
     if (n <= 256) return exact_base_doubles(n) + NN_STATE_DOUBLES;
@@ -2756,22 +2791,49 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     if (pipe_env && idx && link && parts > 0 && k <= 16 && nn_cycles < 0) {
         double* Csum = work + (size_t)G64_MAX_PARTS * 4096 / 2;
         float* gpart = reinterpret_cast<float*>(work);
-        // link area: [shared partials XL_SH x 64 x 64 floats | nsh K ints | shpair nnz int2 | eflag nnz bytes]
+        // link area: [shared partials XL_SH x 64 x 64 floats | nsh K ints | prev / next used atom 2K ints | shpair nnz int2 |
+        //             plink nnz ints | eflag nnz bytes]
         float* spart = reinterpret_cast<float*>(link);
         int32_t* nsh = reinterpret_cast<int32_t*>(spart + (size_t)XL_SH * 4096);
-        int2* shpair = reinterpret_cast<int2*>(nsh + (((size_t)K + 3) & ~(size_t)3));
-        uint8_t* eflag = reinterpret_cast<uint8_t*>(shpair + link_nnz);
-        hipLaunchKernelGGL(exact_link_kernel, dim3((unsigned)K), dim3(256), 0, stream, K, k, row_ptr, entry, idx, coef, eflag,
-                           shpair, nsh);
-        const unsigned g1 = (unsigned)(16 + XL_SH + KSVD_BLOCKS), g2 = (unsigned)(1 + parts);
-        hipLaunchKernelGGL(exact_k2_kernel, dim3(g2), dim3(256), 0, stream, -1, K, R, ldr, n, k, row_ptr, entry, eflag, nsh, coef,
-                           D, ldd, Dnext, gpart, Csum, spart);
-        for (int a = 0; a <= K; ++a) {
-            hipLaunchKernelGGL(exact_k1_kernel, dim3(g1), dim3(256), 0, stream, a, K, parts, R, ldr, n, k, row_ptr, entry, eflag,
-                               shpair, nsh, coef, D, ldd, Dnext, gpart, Csum, spart);
-            if (a < K)
-                hipLaunchKernelGGL(exact_k2_kernel, dim3(g2), dim3(256), 0, stream, a, K, R, ldr, n, k, row_ptr, entry, eflag, nsh,
-                                   coef, D, ldd, Dnext, gpart, Csum, spart);
+        int32_t* pn = nsh + (((size_t)K + 3) & ~(size_t)3);
+        int2* shpair = reinterpret_cast<int2*>(pn + (((size_t)2 * K + 3) & ~(size_t)3));
+        int32_t* plink = reinterpret_cast<int32_t*>(shpair + link_nnz);
+        uint8_t* eflag = reinterpret_cast<uint8_t*>(plink + link_nnz);
+        std::vector<int32_t> rp((size_t)K + 1);
+        LYS_CHECK_HIP(hipMemcpyAsync(rp.data(), row_ptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(exact_neighbours_kernel, dim3((unsigned)(K + 255) / 256), dim3(256), 0, stream, K, row_ptr, pn);
+        hipLaunchKernelGGL(exact_flag_kernel, dim3(2048), dim3(256), 0, stream, K, k, row_ptr, entry, idx, coef, pn, eflag, plink);
+        hipLaunchKernelGGL(exact_compact_kernel, dim3((unsigned)K), dim3(256), 0, stream, row_ptr, entry, plink, shpair, nsh);
+        LYS_LAUNCH_CHECK();
+        LYS_CHECK_HIP(hipStreamSynchronize(stream));  // (the copy; the two kernels above keep the GPU busy meanwhile)
+        if (rp[K] > link_nnz) {
+            set_error("ksvd_exact_sweep_idx: nnz_total = %lld < row_ptr[K] = %d", (long long)link_nnz, rp[K]);
+            return LYS_EINVAL;
+        }
+        std::vector<int> used;
+        for (int a = 0; a < K; ++a)
+            if (rp[a + 1] > rp[a]) used.push_back(a);
+        auto parts_of = [&](int a) {
+            const int64_t m = rp[a + 1] - rp[a];
+            return (int)std::min<int64_t>(G64_MAX_PARTS, std::max<int64_t>(1, (m + slice - 1) / slice));
+        };
+        const int L = (int)used.size();
+        if (L > 0)
+            hipLaunchKernelGGL(exact_k2_kernel, dim3(1u + (unsigned)parts_of(used[0])), dim3(256), 0, stream, -1, used[0], rp[used[0]],
+                               rp[used[0] + 1] - rp[used[0]], R, ldr, n, k, entry, eflag, nsh, coef, D, ldd, Dnext, gpart, Csum,
+                               spart);
+        for (int t = 0; t <= L && L > 0; ++t) {
+            const int a = (t < L) ? used[t] : -1, p = (t > 0) ? used[t - 1] : -1;
+            const int pbeg = (p >= 0) ? rp[p] : 0, pend = (p >= 0) ? rp[p + 1] : 0;
+            const unsigned ab = (unsigned)std::min<int64_t>(XK1_APPLY_BLOCKS, ((int64_t)(pend - pbeg) + 15) / 16);
+            hipLaunchKernelGGL(exact_k1_kernel, dim3(16u + XL_SH + ab), dim3(256), 0, stream, a, (a >= 0) ? rp[a] : 0,
+                               (a >= 0) ? parts_of(a) : 0, p, pbeg, pend, R, ldr, n, k, entry, eflag, shpair, nsh, coef, D, ldd,
+                               Dnext, gpart, Csum, spart);
+            if (a < 0) break;
+            const int nx = (t + 1 < L) ? used[t + 1] : -1;
+            hipLaunchKernelGGL(exact_k2_kernel, dim3(1u + (unsigned)(nx >= 0 ? parts_of(nx) : 0)), dim3(256), 0, stream, a, nx,
+                               (nx >= 0) ? rp[nx] : 0, (nx >= 0) ? rp[nx + 1] - rp[nx] : 0, R, ldr, n, k, entry, eflag, nsh, coef, D,
+                               ldd, Dnext, gpart, Csum, spart);
         }
         LYS_LAUNCH_CHECK();
         return ksvd_commit(n, K, row_ptr, Dnext, D, stream);

@@ -569,6 +569,39 @@ def test_lasso_non_unit_norm_and_ragged_shapes(eng):
         assert orc.lasso_kkt_violation(X, D, Z, lam) < 5e-5
 
 
+@pytest.mark.parametrize("n,K,k,N,unused", [(64, 8, 4, 20000, ()), (25, 40, 5, 3000, (0, 3, 4, 5, 39)),
+                                            (36, 12, 10, 800, (6,)), (64, 3, 2, 5000, (1,)), (49, 2, 2, 300, ())])
+def test_exact_ksvd_pipelined_sweep(eng, n, K, k, N, unused):
+    """The pipelined exact sweep (n <= 64, k <= 16: exact_k1_kernel / exact_k2_kernel, csrc/ksvd.hip) where its row split
+    matters: most signals of an atom ALSO use the previous one (K = 8, k = 4: 43 % of every list, more than one staging
+    batch of the shared part at N = 20000; K = 2, k = 2: every row is shared), unused atoms at the start, in a run in the
+    middle and at the end (previous / next USED atom), k = 10 -- against the oracle's exact float64 SVD update in the
+    reference's Gauss-Seidel order (ksvd.py:28-43)."""
+    from oracle import lyssa_oracle as orc
+    from lyssandra_amd.dict_learning.ksvd import ksvd
+    rs = np.random.RandomState(31 * n + K)
+    live = np.array([a for a in range(K) if a not in unused])
+    Dt = rs.randn(n, K)
+    Dt /= np.linalg.norm(Dt, axis=0)
+    D0 = Dt + 0.3 * rs.randn(n, K)
+    D0 = (D0 / np.linalg.norm(D0, axis=0)).astype(np.float32).astype(np.float64)
+    Z = np.zeros((K, N))
+    kk = min(k, len(live))
+    for i in range(N):
+        Z[rs.choice(live, kk, replace=False), i] = rs.randn(kk) + np.sign(rs.randn(kk))
+    Z = Z.astype(np.float32).astype(np.float64)
+    X = (Dt @ Z + 0.05 * rs.randn(n, N)).astype(np.float32).astype(np.float64)
+    Do, Zo, uo = orc.ksvd_exact(X, D0.copy(), Z.copy())
+    Dh, Zh = D0.copy(), Z.copy()
+    _, _, uh = ksvd(X, Dh, Zh, verbose=False)
+    assert list(uh) == list(uo) == list(unused)
+    for a in unused:
+        assert np.array_equal(Dh[:, a], D0[:, a])
+    assert _atom_err(Dh, Do) < 5e-5, _atom_err(Dh, Do)
+    assert np.max(np.abs(Zh - Zo)) < 5e-5 * np.abs(Zo).max()
+    assert np.array_equal(Zh != 0, Zo != 0)
+
+
 def test_exact_ksvd_tiny_supports(eng):
     """exact K-SVD when an atom is used by a single signal (rank-1 Rk: the eigen-solve's Krylov space is exhausted after
     one step) and with n = 5 features."""

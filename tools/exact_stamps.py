@@ -25,4 +25,6 @@ t = np.array(list(out), dtype=np.float64)
 e = t[16:24]
 print("eig : C loaded %.2f | lanczos %.2f | end %.2f us | steps %d" % ((e[1] - e[0]) / 100, (e[2] - e[0]) / 100, (e[3] - e[0]) / 100, int(e[4])))
 q = t[24:32]
+if e[5] > e[0]:
+    print("eig steps (build with -DLYS_EXACT_STEP_STAMPS): " + " | ".join("%.2f" % ((x - e[0]) / 100) for x in e[5:8]))
 print("gram: descriptors %.2f | rounds %.2f | end %.2f us | signals in wg0 %d" % ((q[1] - q[0]) / 100, (q[2] - q[0]) / 100, (q[3] - q[0]) / 100, int(q[4])))
