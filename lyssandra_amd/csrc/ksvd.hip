@@ -1490,8 +1490,52 @@ __global__ __launch_bounds__(256) void ksvd_eig_kernel(int atom, int n, const in
 // construction and the whole residual sits in row 0, so the test verifies itself: a Newton iteration that has not
 // converged just fails the test.  Every lane computes the same scalars; O(m) per Newton step.  Returns true when the
 // Ritz pair's residual sqrt(r_0^2 + (beta s_m)^2) <= tol * theta, with the normalised s in cvec.
-__device__ bool ritz_tridiag(int m, const double (*H)[EIG_M], double beta, double* cvec, double tol, int lane) {
-    double sc = 0.0, x = 1.0;  // x: largest eigenvalue of the scaled matrix, Newton from the (scaled) Gershgorin bound
+// Hardware reciprocal / reciprocal square root refined by two Newton steps each (full double precision for normal
+// arguments): a fraction of the IEEE division / sqrt sequences, which sat in the eigen-solver's serial chain a dozen times per
+// Lanczos step (round 4).
+__device__ __forceinline__ double fast_rcp(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double a) {
+    double r = __builtin_amdgcn_rsq(a);
+    r = fma(fma(-0.5 * a * r, r, 0.5), r, r);
+    r = fma(fma(-0.5 * a * r, r, 0.5), r, r);
+    return r;
+}
+
+// Newton's iteration on the characteristic polynomial of the scaled M x M tridiagonal (da: diagonal, db2: squared
+// sub-diagonal, db2[i] couples i-1 and i) from x >= its largest root
+template <int M>
+__device__ __forceinline__ double tridiag_newton(const double (&da)[6], const double (&db2)[6], double x) {
+    for (int it = 0; it < 48; ++it) {
+        double p0 = 1.0, d0 = 0.0, p1 = da[0] - x, d1 = -1.0;
+#pragma unroll
+        for (int i = 1; i < M; ++i) {
+            const double a = da[i] - x;
+            const double p2 = a * p1 - db2[i] * p0, d2 = a * d1 - p1 - db2[i] * d0;
+            p0 = p1;
+            d0 = d1;
+            p1 = p2;
+            d1 = d2;
+        }
+        if (d1 == 0.0) break;
+        const double dx = p1 * fast_rcp(d1);
+        x -= dx;
+        if (fabs(dx) <= 4e-16) break;
+    }
+    return x;
+}
+
+// theta_prev (in / out): the largest eigenvalue of the leading (m-1) x (m-1) block from the previous call, 0: not known.
+// With it the iteration starts from the secular-equation bound lambda <= ((alpha + theta') + sqrt((alpha - theta')^2 +
+// 4 b^2)) / 2 (alpha, b: the new row; every term of the secular sum is below its largest-pole term) instead of the
+// Gershgorin bound: two or three Newton steps instead of eight (round 4: the test was 1.5 of a Lanczos step's 3.5 us).
+__device__ bool ritz_tridiag(int m, const double (*H)[EIG_M], double beta, double* cvec, double tol, int lane,
+                             double& theta_prev) {
+    double sc = 0.0, x = 1.0;  // x: largest eigenvalue of the scaled matrix, Newton from an upper bound
     constexpr int RM = 6;      // K-SVD's restricted residuals stop at m = 3 .. 5
     if (m <= RM) {
         // small m: the tridiagonal goes to REGISTERS first (one batch of LDS broadcast reads) -- the Newton iteration of the
@@ -1509,29 +1553,41 @@ __device__ bool ritz_tridiag(int m, const double (*H)[EIG_M], double beta, doubl
             if (i + 1 < RM) row += fabs(db[i + 1]);
             sc = fmax(sc, row);
         }
-        if (!(sc > 0.0)) return false;
-        const double isc = 1.0 / sc;
+        if (!(sc > 0.0) || !(sc < 1e300)) return false;
+        // power-of-two scale: sc becomes 2^e >= the Gershgorin bound, 1 / sc is exact
+        const int ex = ilogb(sc) + 1;
+        sc = ldexp(1.0, ex);
+        const double isc = ldexp(1.0, -ex);
+        if (m >= 3) {
+            double tp = theta_prev;
+            if (!(tp > 0.0) && m == 3) {  // leading 2 x 2 block in closed form (inflated: any tp >= the true value keeps the bound)
+                const double h = da[0] - da[1], g = h * h + 4.0 * db[1] * db[1];
+                tp = 0.5 * ((da[0] + da[1]) + g * fast_rsqrt(fmax(g, 1e-300)) * (1.0 + 1e-12));
+            }
+            if (tp > 0.0) {
+                double al = da[2], b = db[2];
+#pragma unroll
+                for (int i = 3; i < RM; ++i) {
+                    al = (i == m - 1) ? da[i] : al;
+                    b = (i == m - 1) ? db[i] : b;
+                }
+                const double h = al - tp, g = h * h + 4.0 * b * b;
+                const double up = 0.5 * ((al + tp) + g * fast_rsqrt(fmax(g, 1e-300)) * (1.0 + 1e-12));
+                x = fmin(1.0, up * isc * (1.0 + 1e-12));
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
             da[i] *= isc;
             db[i] = (db[i] * isc) * (db[i] * isc);  // b^2 of the scaled matrix
         }
-        for (int it = 0; it < 48; ++it) {
-            double p0 = 1.0, d0 = 0.0, p1 = da[0] - x, d1 = -1.0;
-#pragma unroll
-            for (int i = 1; i < RM; ++i) {
-                const double a = da[i] - x, b2 = db[i];
-                const double p2 = a * p1 - b2 * p0, d2 = a * d1 - p1 - b2 * d0;
-                const bool on = i < m;  // uniform: selects, no branches
-                p0 = on ? p1 : p0;
-                d0 = on ? d1 : d0;
-                p1 = on ? p2 : p1;
-                d1 = on ? d2 : d1;
-            }
-            if (d1 == 0.0) break;
-            const double dx = p1 / d1;
-            x -= dx;
-            if (fabs(dx) <= 4e-16) break;
+        switch (m) {
+            case 1: x = da[0]; break;
+            case 2: x = tridiag_newton<2>(da, db, x); break;
+            case 3: x = tridiag_newton<3>(da, db, x); break;
+            case 4: x = tridiag_newton<4>(da, db, x); break;
+            case 5: x = tridiag_newton<5>(da, db, x); break;
+            default: x = tridiag_newton<6>(da, db, x); break;
         }
     } else {
         for (int i = 0; i < m; ++i) {
@@ -1542,6 +1598,10 @@ __device__ bool ritz_tridiag(int m, const double (*H)[EIG_M], double beta, doubl
         }
         if (!(sc > 0.0)) return false;
         const double isc = 1.0 / sc;
+        if (theta_prev > 0.0) {
+            const double al = H[m - 1][m - 1], b = H[m - 2][m - 1], h = al - theta_prev;
+            x = fmin(1.0, 0.5 * ((al + theta_prev) + sqrt(h * h + 4.0 * b * b)) * isc * (1.0 + 1e-14));
+        }
         for (int it = 0; it < 48; ++it) {
             double p0 = 1.0, d0 = 0.0, p1 = H[0][0] * isc - x, d1 = -1.0;
             for (int i = 1; i < m; ++i) {
@@ -1559,24 +1619,25 @@ __device__ bool ritz_tridiag(int m, const double (*H)[EIG_M], double beta, doubl
         }
     }
     const double theta = x * sc;
+    theta_prev = theta;
     // backward recurrence, s_{m-1} = 1
     double s1 = 1.0, s2 = 0.0, mine = (lane == m - 1) ? 1.0 : 0.0, nrm2 = 1.0;  // s1 = s_i, s2 = s_{i+1}
     for (int i = m - 1; i >= 1; --i) {
         const double b = H[i - 1][i];
         if (b == 0.0) return false;
         const double bi = (i < m - 1) ? H[i][i + 1] : 0.0;
-        const double s0 = ((theta - H[i][i]) * s1 - bi * s2) / b;
+        const double s0 = ((theta - H[i][i]) * s1 - bi * s2) * fast_rcp(b);  // (1 / b does not depend on s: off the chain)
         s2 = s1;
         s1 = s0;
         if (lane == i - 1) mine = s0;
         nrm2 = fma(s0, s0, nrm2);
     }
     if (!(nrm2 > 0.0) || !(nrm2 < 1e300)) return false;
-    const double inv = 1.0 / sqrt(nrm2);
+    const double inv = fast_rsqrt(nrm2);
     const double r0 = ((H[0][0] - theta) * s1 + ((m > 1) ? H[0][1] * s2 : 0.0)) * inv;
     const double tail = beta * inv;  // beta * s_{m-1}, s_{m-1} = 1 before normalisation
     if (lane < EIG_M) cvec[lane] = (lane < m) ? mine * inv : 0.0;
-    return sqrt(r0 * r0 + tail * tail) <= tol * fabs(theta);
+    return r0 * r0 + tail * tail <= (tol * theta) * (tol * theta);
 }
 
 // C = sum of the P fp32 partial Gram matrices, in fp64, spread over 16 workgroups (one matrix element per thread): the
@@ -1641,6 +1702,8 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
     if (row_ptr && row_ptr[atom] >= row_ptr[atom + 1]) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long ts0 = wall_clock64();
+    // the start vector's load is issued with the loads of C (after the barrier below it cost a round trip of its own)
+    const float d0f = (lane < n) ? D[(int64_t)atom * ldd + lane] : 0.f;
     if (parts < 0) {
         // C already summed in fp64 by ksvd_gram64_reduce_kernel (64 x 64 doubles behind the partials): 32 KB
         const double2* C2 = reinterpret_cast<const double2*>(part);
@@ -1697,13 +1760,13 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
     __syncthreads();
     if (tid >= 64) return;
     const unsigned long long ts1 = wall_clock64();
-    const double d0 = (lane < n) ? (double)D[(int64_t)atom * ldd + lane] : 0.0;
+    const double d0 = (double)d0f;
     auto sumsq64 = [&](double x) { return wave_sum_d(x * x); };  // (round 2: a 64-step loop of LDS broadcast reads, ~0.45 us)
     {
         const double nrm2 = sumsq64(d0);
         Q[lane] = (nrm2 > 0.0) ? d0 / sqrt(nrm2) : (lane == 0 ? 1.0 : 0.0);
     }
-    double scale0 = 0.0;
+    double scale0 = 0.0, theta_prev = 0.0;
     int m = 0;
     for (int j = 0; j < EIG_M; ++j) {
         __builtin_amdgcn_wave_barrier();
@@ -1735,8 +1798,13 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
 #pragma unroll
             for (int round = 0; round < 2; ++round) {
                 double hj[6];
+                // j is uniform: only the j + 1 live dot products are reduced (round 4; six every step before -- a
+                // reduction is ~25 dependent instructions)
 #pragma unroll
-                for (int i = 0; i < 6; ++i) hj[i] = wave_sum_d(qr[i] * w);
+                for (int i = 0; i < 6; ++i) {
+                    hj[i] = 0.0;
+                    if (i <= j) hj[i] = wave_sum_d(qr[i] * w);
+                }
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     w = fma(-hj[i], qr[i], w);
@@ -1772,7 +1840,9 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
 #pragma unroll 4
             for (int i = 0; i <= j; ++i) w = fma(-hh[i], Q[i * E64_QS + lane], w);
         }
-        const double beta = sqrt(sumsq64(w));
+        const double w2 = sumsq64(w);
+        const double ibeta = (w2 > 1e-300) ? fast_rsqrt(w2) : 0.0;
+        const double beta = w2 * ibeta;
         m = j + 1;
         if (j == 0) scale0 = fabs(H[0][0]) + beta;
         const bool last = !(beta > 1e-13 * scale0) || j == EIG_M - 1 || j + 1 >= n;
@@ -1782,11 +1852,11 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
             __builtin_amdgcn_wave_barrier();
             break;
         }
-        if (m >= 3 && ritz_tridiag(m, H, beta, cvec, 1e-9, lane)) {
+        if (m >= 3 && ritz_tridiag(m, H, beta, cvec, 1e-9, lane, theta_prev)) {
             __builtin_amdgcn_wave_barrier();
             break;
         }
-        Q[(j + 1) * E64_QS + lane] = w / beta;
+        Q[(j + 1) * E64_QS + lane] = w * ibeta;
 #ifdef LYS_EXACT_STEP_STAMPS
         if (j < 3 && lane == 0) g_exact_stamp[5 + j] = wall_clock64();
 #endif
@@ -1966,14 +2036,13 @@ __device__ __forceinline__ void exact_apply_unshared(int p, int beg, int end, in
 
 // the (atom, p) shared rows: p's pending update in place, then their Gram partial (gram64_part's tiling)
 __device__ __forceinline__ void exact_shared_part(int atom, int p, int beg, int sb, float* __restrict__ R, int64_t ldr, int n,
-                                                  int k, const int2* __restrict__ shpair, const int32_t* __restrict__ nsh,
+                                                  int k, const int2* __restrict__ shpair, int ns,
                                                   float* __restrict__ coef, const float* __restrict__ D, int ldd,
                                                   const float* __restrict__ Dnext, float* __restrict__ spart) {
     __shared__ float s_a[64][65];
     __shared__ int64_t s_off[G64_ROWS];
     __shared__ float s_x[G64_ROWS], s_xp[G64_ROWS];
     __shared__ int s_pc[G64_ROWS];
-    const int ns = nsh[atom];
     const int chunk = xl_shared_chunk(ns);
     const int j0 = sb * chunk, total = min(chunk, ns - j0);
     if (total <= 0) return;
@@ -2033,11 +2102,11 @@ __device__ __forceinline__ void exact_shared_part(int atom, int p, int beg, int 
 }
 
 // K1(atom; p = the used atom before it, -1: none): blocks [0, 16) sum atom's `parts` Gram partials, [16, 16 + XL_SH) take the
-// (atom, p) shared rows, the rest apply p.  atom < 0 closes the sweep: only the apply of p (the last used atom).
-__global__ __launch_bounds__(256) void exact_k1_kernel(int atom, int abeg, int parts, int p, int pbeg, int pend,
+// nsa (atom, p) shared rows, the rest apply p.  atom < 0 closes the sweep: only the apply of p (the last used atom).
+__global__ __launch_bounds__(256) void exact_k1_kernel(int atom, int abeg, int parts, int nsa, int p, int pbeg, int pend,
                                                        float* __restrict__ R, int64_t ldr, int n, int k,
                                                        const int32_t* __restrict__ entry, const uint8_t* __restrict__ eflag,
-                                                       const int2* __restrict__ shpair, const int32_t* __restrict__ nsh,
+                                                       const int2* __restrict__ shpair,
                                                        float* __restrict__ coef, const float* __restrict__ D, int ldd,
                                                        const float* __restrict__ Dnext, const float* __restrict__ part,
                                                        double* __restrict__ Csum, float* __restrict__ spart) {
@@ -2058,7 +2127,7 @@ __global__ __launch_bounds__(256) void exact_k1_kernel(int atom, int abeg, int p
     }
     if (p < 0) return;
     if (bx < 16 + XL_SH) {
-        if (atom >= 0) exact_shared_part(atom, p, abeg, bx - 16, R, ldr, n, k, shpair, nsh, coef, D, ldd, Dnext, spart);
+        if (atom >= 0) exact_shared_part(atom, p, abeg, bx - 16, R, ldr, n, k, shpair, nsa, coef, D, ldd, Dnext, spart);
         return;
     }
     exact_apply_unshared(p, pbeg, pend, bx - 16 - XL_SH, (int)gridDim.x - 16 - XL_SH, R, ldr, n, k, entry, eflag, coef, D, ldd,
@@ -2067,16 +2136,15 @@ __global__ __launch_bounds__(256) void exact_k1_kernel(int atom, int abeg, int p
 
 // K2(atom, -1: none; nx = the used atom after it, -1: none): block 0 solves atom's eigenproblem, the other blocks form the Gram
 // partials of nx over the rows that atom does not touch.
-__global__ __launch_bounds__(256) void exact_k2_kernel(int atom, int nx, int nbeg, int nm, const float* __restrict__ R, int64_t ldr,
-                                                       int n, int k, const int32_t* __restrict__ entry,
-                                                       const uint8_t* __restrict__ eflag, const int32_t* __restrict__ nsh,
+__global__ __launch_bounds__(256) void exact_k2_kernel(int atom, int nsa, int nx, int nbeg, int nm, const float* __restrict__ R,
+                                                       int64_t ldr, int n, int k, const int32_t* __restrict__ entry,
+                                                       const uint8_t* __restrict__ eflag,
                                                        const float* __restrict__ coef, const float* __restrict__ D, int ldd,
                                                        float* __restrict__ Dnext, float* __restrict__ part,
                                                        const double* __restrict__ Csum, const float* __restrict__ spart) {
     if (blockIdx.x == 0) {
         if (atom < 0) return;
-        const int tot = nsh[atom];  // 0 for the first used atom
-        const int ns = (tot + xl_shared_chunk(tot) - 1) / xl_shared_chunk(tot);
+        const int ns = (nsa + xl_shared_chunk(nsa) - 1) / xl_shared_chunk(nsa);  // shared partials (nsa = 0 for the first used atom)
         eig64_body(atom, n, nullptr, reinterpret_cast<const float*>(Csum), -1, spart, ns, D, ldd, Dnext);
         return;
     }
@@ -2799,13 +2867,15 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
         int2* shpair = reinterpret_cast<int2*>(pn + (((size_t)2 * K + 3) & ~(size_t)3));
         int32_t* plink = reinterpret_cast<int32_t*>(shpair + link_nnz);
         uint8_t* eflag = reinterpret_cast<uint8_t*>(plink + link_nnz);
-        std::vector<int32_t> rp((size_t)K + 1);
-        LYS_CHECK_HIP(hipMemcpyAsync(rp.data(), row_ptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        std::vector<int32_t> rp((size_t)K + 1), hns((size_t)K);
         hipLaunchKernelGGL(exact_neighbours_kernel, dim3((unsigned)(K + 255) / 256), dim3(256), 0, stream, K, row_ptr, pn);
         hipLaunchKernelGGL(exact_flag_kernel, dim3(2048), dim3(256), 0, stream, K, k, row_ptr, entry, idx, coef, pn, eflag, plink);
         hipLaunchKernelGGL(exact_compact_kernel, dim3((unsigned)K), dim3(256), 0, stream, row_ptr, entry, plink, shpair, nsh);
         LYS_LAUNCH_CHECK();
-        LYS_CHECK_HIP(hipStreamSynchronize(stream));  // (the copy; the two kernels above keep the GPU busy meanwhile)
+        // one read-back per sweep: the lists' bounds and the shared-row counts become kernel ARGUMENTS of the 2 L launches below
+        LYS_CHECK_HIP(hipMemcpyAsync(rp.data(), row_ptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        LYS_CHECK_HIP(hipMemcpyAsync(hns.data(), nsh, hns.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        LYS_CHECK_HIP(hipStreamSynchronize(stream));
         if (rp[K] > link_nnz) {
             set_error("ksvd_exact_sweep_idx: nnz_total = %lld < row_ptr[K] = %d", (long long)link_nnz, rp[K]);
             return LYS_EINVAL;
@@ -2819,20 +2889,21 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
         };
         const int L = (int)used.size();
         if (L > 0)
-            hipLaunchKernelGGL(exact_k2_kernel, dim3(1u + (unsigned)parts_of(used[0])), dim3(256), 0, stream, -1, used[0], rp[used[0]],
-                               rp[used[0] + 1] - rp[used[0]], R, ldr, n, k, entry, eflag, nsh, coef, D, ldd, Dnext, gpart, Csum,
-                               spart);
+            hipLaunchKernelGGL(exact_k2_kernel, dim3(1u + (unsigned)parts_of(used[0])), dim3(256), 0, stream, -1, 0, used[0],
+                               rp[used[0]], rp[used[0] + 1] - rp[used[0]], R, ldr, n, k, entry, eflag, coef, D, ldd, Dnext, gpart,
+                               Csum, spart);
         for (int t = 0; t <= L && L > 0; ++t) {
             const int a = (t < L) ? used[t] : -1, p = (t > 0) ? used[t - 1] : -1;
             const int pbeg = (p >= 0) ? rp[p] : 0, pend = (p >= 0) ? rp[p + 1] : 0;
             const unsigned ab = (unsigned)std::min<int64_t>(XK1_APPLY_BLOCKS, ((int64_t)(pend - pbeg) + 15) / 16);
+            const int nsa = (a >= 0 && p >= 0) ? hns[a] : 0;
             hipLaunchKernelGGL(exact_k1_kernel, dim3(16u + XL_SH + ab), dim3(256), 0, stream, a, (a >= 0) ? rp[a] : 0,
-                               (a >= 0) ? parts_of(a) : 0, p, pbeg, pend, R, ldr, n, k, entry, eflag, shpair, nsh, coef, D, ldd,
+                               (a >= 0) ? parts_of(a) : 0, nsa, p, pbeg, pend, R, ldr, n, k, entry, eflag, shpair, coef, D, ldd,
                                Dnext, gpart, Csum, spart);
             if (a < 0) break;
             const int nx = (t + 1 < L) ? used[t + 1] : -1;
-            hipLaunchKernelGGL(exact_k2_kernel, dim3(1u + (unsigned)(nx >= 0 ? parts_of(nx) : 0)), dim3(256), 0, stream, a, nx,
-                               (nx >= 0) ? rp[nx] : 0, (nx >= 0) ? rp[nx + 1] - rp[nx] : 0, R, ldr, n, k, entry, eflag, nsh, coef, D,
+            hipLaunchKernelGGL(exact_k2_kernel, dim3(1u + (unsigned)(nx >= 0 ? parts_of(nx) : 0)), dim3(256), 0, stream, a, nsa, nx,
+                               (nx >= 0) ? rp[nx] : 0, (nx >= 0) ? rp[nx + 1] - rp[nx] : 0, R, ldr, n, k, entry, eflag, coef, D,
                                ldd, Dnext, gpart, Csum, spart);
         }
         LYS_LAUNCH_CHECK();
