@@ -262,6 +262,22 @@ int lys_ksvd_exact_gram(int atom, const float* R, int64_t ldr, int n, int k,
 int lys_ksvd_exact_update(int atom, float* R, int64_t ldr, int n, int k,
                           const int32_t* row_ptr, const int32_t* used_ptr, const int32_t* entry, float* coef,
                           const double* C, const float* D_packed, float* D_next, void* stream);
+/*
+ * The exact update per atom for signal SHARDS when n > 256 (round 4; LC-KSVD's stacked signals): neither Gram matrix can be
+ * exchanged, so the leading pair comes from the matrix-free power iteration of the single-GPU path with ONE all-reduce of n
+ * floats per iteration.  Phases of one atom (every rank runs every phase of every atom that is used on ANY rank):
+ *   0: u = d_old                                  1: un = this shard's sum_i (rk_i . u / ||u||) rk_i  -> all-reduce un
+ *   2: s2 = (||un||^2, un . d_old, sin^2(un, u)); u = un   -- stop when s2[2] <= 1e-12 (1e-6 rad), read by the caller
+ *   3: coefficients / residual rows of the local signals, the new atom in D_next on every rank.
+ * lys_ksvd_exact_mf_offsets: byte offsets into `work` of u (n floats), un (n floats), s2 (3 doubles), the scratch s2'.
+ * work: lys_ksvd_exact_workspace_bytes(n); local_support = this shard's row_ptr[atom + 1] - row_ptr[atom].
+ * lys_ksvd_commit(used_ptr) publishes the atoms at the end of the cycle.     (ksvd.py:19-43, per shard)
+ */
+int lys_ksvd_exact_mf_offsets(int n, int64_t* out4);
+int lys_ksvd_exact_mf_phase(int phase, int atom, float* R, int64_t ldr, int n, int k,
+                            const int32_t* row_ptr, const int32_t* entry, float* coef,
+                            double* work, size_t work_bytes, const float* D_packed, float* D_next,
+                            int64_t local_support, void* stream);
 /* Whole cycle on one GPU (atoms 0..K-1 in order, both phases, then commit); sbuf is zeroed inside. */
 int lys_ksvd_sweep(float* R, int64_t ldr, int n, int K, int k,
                    const int32_t* row_ptr, const int32_t* entry, float* coef,

@@ -67,6 +67,8 @@ SIGNATURES = {
     "lys_ksvd_exact_update": (_I, [_I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lys_ksvd_exact_sweep": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _Z, _P, _P, _L, _P]),
     "lys_ksvd_exact_idx_workspace_bytes": (_Z, [_I, _I, _L]),
+    "lys_ksvd_exact_mf_offsets": (_I, [_I, _P]),
+    "lys_ksvd_exact_mf_phase": (_I, [_I, _I, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P, _P, _L, _P]),
     "lys_ksvd_exact_sweep_idx": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P, _P, _L, _L, _P]),
     "lys_nn_ksvd_state_offset_bytes": (_Z, [_I]),
     "lys_nn_ksvd_phase": (_I, [_I, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P]),

@@ -71,6 +71,9 @@ int ksvd_commit(int, int, const int32_t*, const float*, float*, hipStream_t);
 int ksvd_exact_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
                      int64_t, hipStream_t, int, float*, const int32_t* = nullptr, void* = nullptr, int64_t = 0);
 size_t ksvd_exact_link_bytes(int, int64_t);
+void ksvd_exact_mf_offsets(int, int64_t*);
+int ksvd_exact_mf_phase(int, int, float*, int64_t, int, int, const int32_t*, const int32_t*, float*, double*, const float*, float*,
+                        int64_t, hipStream_t);
 size_t ksvd_exact_work_doubles(int);
 size_t nn_ksvd_state_offset_doubles(int);
 int nn_ksvd_phase(int, int, float*, int64_t, int, int, const int32_t*, const int32_t*, const int32_t*, float*, const double*,
@@ -731,6 +734,22 @@ int lys_nn_ksvd_phase(int phase, int atom, float* R, int64_t ldr, int n, int k, 
     LYS_REQUIRE(work_bytes >= ksvd_exact_work_doubles(n) * sizeof(double), "nn_ksvd_phase: work buffer too small");
     return nn_ksvd_phase(phase, atom, R, ldr, n, k, row_ptr, used_ptr, entry, coef, C, work, xbuf, D_packed, D_next,
                          STREAM(stream));
+}
+
+int lys_ksvd_exact_mf_offsets(int n, int64_t* out4) {
+    LYS_REQUIRE(out4 && n > 256, "ksvd_exact_mf_offsets: bad arguments (n > 256 only)");
+    ksvd_exact_mf_offsets(n, out4);
+    return LYS_OK;
+}
+
+int lys_ksvd_exact_mf_phase(int phase, int atom, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr,
+                            const int32_t* entry, float* coef, double* work, size_t work_bytes, const float* D_packed,
+                            float* D_next, int64_t local_support, void* stream) {
+    LYS_REQUIRE(R && row_ptr && entry && coef && work && D_packed && D_next && n > 256 && atom >= 0 && phase >= 0 &&
+                    phase <= 3 && local_support >= 0, "ksvd_exact_mf_phase: bad arguments (n > 256 only)");
+    LYS_REQUIRE(work_bytes >= ksvd_exact_work_doubles(n) * sizeof(double), "ksvd_exact_mf_phase: work buffer too small");
+    return ksvd_exact_mf_phase(phase, atom, R, ldr, n, k, row_ptr, entry, coef, work, D_packed, D_next, local_support,
+                               STREAM(stream));
 }
 
 int lys_ksvd_exact_gram(int atom, const float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,

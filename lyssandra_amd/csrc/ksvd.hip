@@ -2998,6 +2998,79 @@ int ksvd_exact_update(int atom, float* R, int64_t ldr, int n, int k, const int32
     return LYS_OK;
 }
 
+// ---- n > 256 on signal SHARDS (round 4): the n x n Gram matrix is no statistic one can all-reduce (24 635^2 doubles for
+// LC-KSVD's stack) and the column Gram matrix couples the shards; the matrix-free power iteration of ksvd_exact_sweep_tall
+// needs ONE n-vector from the other shards per iteration: u' = sum over shards of sum_i (rk_i . u) rk_i.  Phases of one atom
+// (dist.ksvd_exact_cycle_sharded_mf):
+//   0  u = d_old, s2 = (||u||^2, u . d_old, 1)                                            (replicated)
+//   1  un = this shard's sum_i (rk_i . u / ||u||) rk_i      -> the caller all-reduces the n floats of un
+//   2  s2' = (||un||^2, un . d_old, sin^2 of the angle to u); u = un, s2 = s2'            (replicated; the caller reads s2[2])
+//   3  x_i = rk_i . u / ||u||, R_i = rk_i - u x_i / ||u|| on the local rows, the new atom on every shard
+// Work layout = ksvd_exact_sweep_tall's: [s2 (8 doubles) | M | v | u | 8 spare doubles | un | s2'].
+struct MfLayout {
+    double* s2;
+    float* u;
+    float* un;
+    double* s2n;
+};
+static MfLayout mf_layout(double* work, int n) {
+    MfLayout l;
+    l.s2 = work;
+    double* M = work + 8;
+    float* v = reinterpret_cast<float*>(M + (size_t)TALL_MAX * TALL_MAX);
+    l.u = v + TALL_MAX;
+    l.un = l.u + 2 * (((size_t)n + 1) / 2) + 16;
+    l.s2n = reinterpret_cast<double*>(l.un + 2 * (((size_t)n + 1) / 2));
+    return l;
+}
+void ksvd_exact_mf_offsets(int n, int64_t* out4) {  // byte offsets of u, un, s2, s2' in the work area
+    const uintptr_t base = (uintptr_t)1 << 30;
+    MfLayout l = mf_layout(reinterpret_cast<double*>(base), n);
+    out4[0] = (int64_t)(reinterpret_cast<uintptr_t>(l.u) - base);
+    out4[1] = (int64_t)(reinterpret_cast<uintptr_t>(l.un) - base);
+    out4[2] = 0;
+    out4[3] = (int64_t)(reinterpret_cast<uintptr_t>(l.s2n) - base);
+}
+
+__global__ __launch_bounds__(256) void ksvd_mf_atom_kernel(int atom, int n, const float* __restrict__ D, int ldd,
+                                                           const float* __restrict__ uraw, const double* __restrict__ s2,
+                                                           float* __restrict__ Dnext) {
+    const double s2v = s2[0];
+    const float inv = (s2v > 0.0) ? (float)((s2[1] < 0.0 ? -1.0 : 1.0) / sqrt(s2v)) : 0.f;  // ksvd_tall_apply_kernel's
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < n; f += gridDim.x * 256)
+        Dnext[(int64_t)atom * ldd + f] = (s2v > 0.0) ? uraw[f] * inv : D[(int64_t)atom * ldd + f];
+}
+
+int ksvd_exact_mf_phase(int phase, int atom, float* R, int64_t ldr, int n, int k, const int32_t* row_ptr, const int32_t* entry,
+                        float* coef, double* work, const float* D, float* Dnext, int64_t local_support, hipStream_t stream) {
+    const int ldd = padded_features(n);
+    MfLayout l = mf_layout(work, n);
+    switch (phase) {
+        case 0:
+            hipLaunchKernelGGL(ksvd_mf_init_kernel, dim3(1), dim3(256), 0, stream, atom, n, D, ldd, l.u, l.s2);
+            break;
+        case 1:
+            LYS_CHECK_HIP(hipMemsetAsync(l.un, 0, (size_t)n * sizeof(float), stream));
+            if (local_support > 0)
+                hipLaunchKernelGGL(ksvd_mf_iter_kernel, dim3((unsigned)((local_support + MF_SPW - 1) / MF_SPW)), dim3(256), 0, stream,
+                                   atom, R, ldr, n, k, row_ptr, entry, coef, D, ldd, l.u, l.s2, l.un);
+            break;
+        case 2:
+            hipLaunchKernelGGL(ksvd_mf_norm_kernel, dim3(1), dim3(256), 0, stream, atom, n, D, ldd, l.un, l.u, l.s2, l.s2n);
+            LYS_CHECK_HIP(hipMemcpyAsync(l.u, l.un, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            LYS_CHECK_HIP(hipMemcpyAsync(l.s2, l.s2n, 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            break;
+        default:
+            if (local_support > 0)
+                hipLaunchKernelGGL(ksvd_tall_apply_kernel, dim3((unsigned)local_support), dim3(256), 0, stream, atom, R, ldr, n, k,
+                                   row_ptr, entry, coef, D, ldd, l.u, l.s2, Dnext);
+            hipLaunchKernelGGL(ksvd_mf_atom_kernel, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, stream, atom, n, D,
+                               ldd, l.u, l.s2, Dnext);
+    }
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 // nn_ksvd on signal shards, one phase of one atom (see nn_atom_phase): phase -1 zeroes the state (once per cycle), 0 runs the
 // replicated eigen-solve on the reduced Gram matrix C (u -> Dnext[atom]) and the first x pass, 1..4 the remaining passes.
 size_t nn_ksvd_state_offset_doubles(int n) { return exact_base_doubles(n); }

@@ -37,12 +37,14 @@ def approx_ksvd(Y, D, X, n_cycles=1, verbose=True):
     return D, X, unused_atoms
 
 
-def ksvd(Y, D, X, n_cycles=1, verbose=True):
+def ksvd(Y, D, X, n_cycles=1, verbose=True, group=None):
     """lyssa/dict_learning/ksvd.py:19-43 -- the exact K-SVD update (rank-1 SVD of every atom's restricted residual).
 
     Same in-place contract as ``approx_ksvd``.  The reference's ``randomized_svd(n_iter=10, flip_sign=False)`` is
     replaced by a deterministic device eigen-solve (Gram matrix + Lanczos started from the old atom), so atoms agree with the
     reference up to the sign of (d_k, x_k) and the accuracy of the randomized solver; D X is sign-invariant.
+    ``group`` (extension): a torch.distributed process group -- Y and X then hold THIS rank's columns (signal shard), D is
+    replicated; per atom the ranks exchange the n x n Gram matrix (n <= 256) or one n-vector per power iteration (n > 256).
     """
     Ys = engine.signals_to_device(Y)
     dd = engine.DeviceDictionary.from_host(D)
@@ -51,7 +53,7 @@ def ksvd(Y, D, X, n_cycles=1, verbose=True):
     unused_atoms = []
     buffers = {}
     for _ in range(n_cycles):
-        unused_atoms += engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=buffers)
+        unused_atoms += engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=buffers, group=group)
     D[:] = dd.to_host()
     _scatter_codes(X, idx, coef, nnz)
     return D, X, unused_atoms

@@ -41,13 +41,22 @@ def _stack(D, G, W, alpha, beta):
 
 
 def lc_ksvd(X, y, D, Q, alpha=1, beta=1, lambda1=1, lambda2=1,
-            sparse_coder=None, max_iter=2, approx=False, mmap=False, verbose=False, n_jobs=1):
+            sparse_coder=None, max_iter=2, approx=False, mmap=False, verbose=False, n_jobs=1, group=None):
     """lyssa/dict_learning/lc_ksvd.py:105-216.  X (n_features, n_samples), y labels 0..C-1, D (n_features, n_atoms)
     initial dictionary, Q (n_atoms, n_samples) with Q[k, i] = 1 iff atom k and sample i share a class.
     Returns ``(D, Z, W)``: Z are the last iteration's codes AFTER the K-SVD coefficient update (the reference hands its
-    Z to `ksvd`, which updates it in place)."""
+    Z to `ksvd`, which updates it in place).
+    ``group`` (extension, round 4): a torch.distributed process group -- X, y, Q then hold THIS rank's samples, D is
+    replicated; the stacked exact K-SVD runs on signal shards (n > 256: one n-vector all-reduce per power iteration,
+    dist.ksvd_exact_cycle_sharded_mf), everything else of the loop is per sample or replicated.  Returns this rank's Z."""
     n_features, K = X.shape[0], D.shape[1]
     n_classes = len(set(np.asarray(y).tolist()))
+    if group is not None:  # a shard need not hold every class: the labels are 0 .. C-1
+        import torch
+        import torch.distributed as tdist
+        top = torch.tensor([int(np.max(np.asarray(y).astype(int))) + 1 if np.size(y) else 0], dtype=torch.int64)
+        tdist.all_reduce(top, op=tdist.ReduceOp.MAX, group=group)
+        n_classes = int(top.item())
     H = _label_matrix(y, n_classes)
     Z = np.zeros((K, X.shape[1]))
     # with Z = 0 these are zero matrices (:136-139) -- kept as the reference computes them
@@ -58,7 +67,7 @@ def lc_ksvd(X, y, D, Q, alpha=1, beta=1, lambda1=1, lambda2=1,
     last_error = 0
     for it in range(max_iter):
         Z = sparse_coder(X, D)
-        stacked_D, _, unused_atoms = ksvd(stacked_X, stacked_D, Z, verbose=False)
+        stacked_D, _, unused_atoms = ksvd(stacked_X, stacked_D, Z, verbose=False, group=group)
         if verbose:
             print("iteration %d: number of unused atoms: %d" % (it, len(unused_atoms)))
         D, G, W, stacked_D = _stack(stacked_D[:n_features], stacked_D[n_features:n_features + K],

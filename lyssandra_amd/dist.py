@@ -129,6 +129,8 @@ def ksvd_exact_cycle_sharded(ops, K, group=None):
     plus `ops.local_counts()`, `ops.set_used(global_counts)` and `ops.commit()`.  K collectives of n^2 doubles per cycle
     (32 KB at n = 64): latency-bound, like the reference semantics demand (atom a+1 reads the residual atom a left).
     Returns the atoms unused on every rank."""
+    if getattr(ops, "matrix_free", False):           # n > 256: no Gram matrix to exchange
+        return ksvd_exact_cycle_sharded_mf(ops, K, group)
     counts = ops.local_counts()
     allreduce_sum_(counts, group)
     ops.set_used(counts)
@@ -138,6 +140,38 @@ def ksvd_exact_cycle_sharded(ops, K, group=None):
             continue                                   # unused everywhere: keeps its column (ksvd.py:27-29)
         allreduce_sum_(ops.gram(a), group)
         ops.update(a)
+    ops.commit()
+    return [a for a in range(K) if host_counts[a] == 0]
+
+
+def ksvd_exact_cycle_sharded_mf(ops, K, group=None, max_it=400, poll=4, sin2_tol=1e-12):
+    """One cycle of the EXACT rank-1 update (ksvd.py:19-43) over signal shards when n is large (n > 256 on the device:
+    LC-KSVD's stacked signals, lc_ksvd.py:165).  Neither Gram matrix can be exchanged there -- n x n is 4.8 GB at n = 24 635
+    and the column Gram matrix couples the shards -- so the leading pair comes from a matrix-free power iteration on
+    Rk Rk' started at d_old, with ONE all-reduce of an n-vector per iteration.  Per atom IN ORDER
+
+        ops.mf_begin(a)        -> u = d_old                                                  (replicated)
+        repeat:  ops.mf_iterate(a) -> fp32 / fp64 tensor [n]: this shard's sum_i (rk_i . u / ||u||) rk_i   (all-reduced here)
+                 ops.mf_norm(a)    -> u = the reduced vector; norms and the angle to the previous iterate    (replicated)
+                 every `poll` iterations: stop when ops.mf_sin2() <= sin2_tol (successive iterates within 1e-6 rad) -- the
+                 number is computed from the reduced vector, so every rank takes the same decision
+        ops.mf_apply(a)        -> x_i = rk_i . u, R_i = rk_i - u x_i on the local rows; the new atom on every rank
+
+    plus `local_counts`, `set_used`, `commit` like ksvd_exact_cycle_sharded.  Returns the atoms unused on every rank."""
+    counts = ops.local_counts()
+    allreduce_sum_(counts, group)
+    ops.set_used(counts)
+    host_counts = counts.cpu().tolist()
+    for a in range(K):
+        if host_counts[a] == 0:
+            continue
+        ops.mf_begin(a)
+        for it in range(int(max_it)):
+            allreduce_sum_(ops.mf_iterate(a), group)
+            ops.mf_norm(a)
+            if (it + 1) % int(poll) == 0 and not (ops.mf_sin2() > sin2_tol):
+                break
+        ops.mf_apply(a)
     ops.commit()
     return [a for a in range(K) if host_counts[a] == 0]
 

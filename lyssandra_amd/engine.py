@@ -570,22 +570,22 @@ def ksvd_cycle(R, dd, idx, coef, nnz, group=None, buffers=None, block=None):
 
 
 class HipExactKsvdOps(object):
-    """`ops` of dist.ksvd_exact_cycle_sharded: the exact rank-1 update per atom on a signal shard (n <= 256).  The Gram
+    """`ops` of dist.ksvd_exact_cycle_sharded: the exact rank-1 update per atom on a signal shard.  n <= 256: the Gram
     matrix Rk Rk' of an atom's restricted residual is its sufficient statistic: local part -> all-reduce -> replicated
-    eigen-solve -> local coefficient / residual update."""
+    eigen-solve -> local coefficient / residual update.  n > 256 (`matrix_free`, round 4): the matrix-free power iteration
+    of lys_ksvd_exact_mf_phase, one all-reduce of n floats per iteration (dist.ksvd_exact_cycle_sharded_mf)."""
 
     def __init__(self, R, dd, idx, coef, nnz, buffers=None):
         torch = _torch()
         self.lib = _lib.load()
-        if dd.n > 256:
-            raise _lib.LyssaHipError("the sharded exact K-SVD update needs n <= 256 (n = %d)" % dd.n)
+        self.matrix_free = dd.n > 256
         self.R, self.dd, self.coef = R, dd, coef
         self.k = int(idx.shape[1])
         self.row_ptr, self.entry = csr_by_atom(idx, coef, nnz, dd.K)
         if buffers is None:
             buffers = {}
-        C = buffers.get("exact_C")
-        if C is None or C.numel() != dd.n * dd.n:
+        C = None if self.matrix_free else buffers.get("exact_C")
+        if not self.matrix_free and (C is None or C.numel() != dd.n * dd.n):
             C = buffers["exact_C"] = torch.zeros((dd.n, dd.n), dtype=torch.float64, device=dd.device)
         Dnext = buffers.get("exact_Dnext")
         if Dnext is None or Dnext.shape != dd.D.shape:
@@ -594,6 +594,40 @@ class HipExactKsvdOps(object):
         counts = self.row_ptr[1:] - self.row_ptr[:-1]
         self.max_support = int(counts.max().item()) if counts.numel() else 0
         self.used = None
+        if self.matrix_free:
+            need = int(self.lib.lys_ksvd_exact_workspace_bytes(dd.n)) // 8
+            work = buffers.get("exact_work")
+            if work is None or work.numel() < need:
+                work = buffers["exact_work"] = torch.zeros((need,), dtype=torch.float64, device=dd.device)
+            self.work = work
+            off = (ctypes.c_int64 * 4)()
+            _lib.check(self.lib.lys_ksvd_exact_mf_offsets(dd.n, off), "lys_ksvd_exact_mf_offsets")
+            self._un = work.view(torch.float32)[off[1] // 4:off[1] // 4 + dd.n]
+            self._s2 = work[off[2] // 8:off[2] // 8 + 3]
+            self._counts = counts.cpu().tolist()
+
+    # ---- n > 256: phases of dist.ksvd_exact_cycle_sharded_mf
+    def _mf(self, phase, a):
+        _lib.check(self.lib.lys_ksvd_exact_mf_phase(phase, a, _ptr(self.R), _ld(self.R), self.dd.n, self.k, _ptr(self.row_ptr),
+                                                    _ptr(self.entry), _ptr(self.coef), _ptr(self.work), self.work.numel() * 8,
+                                                    _ptr(self.dd.D), _ptr(self.Dnext), int(self._counts[a]), _stream()),
+                   "lys_ksvd_exact_mf_phase")
+
+    def mf_begin(self, a):
+        self._mf(0, a)
+
+    def mf_iterate(self, a):
+        self._mf(1, a)
+        return self._un
+
+    def mf_norm(self, a):
+        self._mf(2, a)
+
+    def mf_sin2(self):
+        return float(self._s2[2].item())
+
+    def mf_apply(self, a):
+        self._mf(3, a)
 
     def local_counts(self):
         torch = _torch()
@@ -682,7 +716,8 @@ def ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=None, group=None, nn_cycles=
     Per atom: Gram matrix of the restricted residual, its leading eigenvector (Lanczos + Rayleigh-Ritz in one
     workgroup), coefficient / residual update (the reference: sklearn ``randomized_svd(n_iter=10)``, random sign).
     Returns the unused atoms.  ``group``: signals sharded over the ranks of a torch.distributed group -- one all-reduce
-    of the atom's n x n Gram matrix per atom (dist.ksvd_exact_cycle_sharded; n <= 256).
+    of the atom's n x n Gram matrix per atom (dist.ksvd_exact_cycle_sharded; n <= 256), or of an n-vector per power iteration
+    (n > 256, dist.ksvd_exact_cycle_sharded_mf).
     """
     torch = _torch()
     lib = _lib.load()

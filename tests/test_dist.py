@@ -95,6 +95,48 @@ class NumpyExactKsvdOps(object):
         self.D[:, self.used] = self.Dnext[:, self.used]
 
 
+class NumpyExactMfOps(NumpyExactKsvdOps):
+    """Shard-local phases of the matrix-free exact update (dist.ksvd_exact_cycle_sharded_mf) in numpy: stand-in for
+    engine.HipExactKsvdOps at n > 256 (lys_ksvd_exact_mf_phase)."""
+    matrix_free = True
+
+    def _rk(self, a):
+        om = self.Z[a] != 0
+        return om, self.R[:, om] + np.outer(self.D[:, a], self.Z[a, om])
+
+    def mf_begin(self, a):
+        self.u = self.D[:, a].copy()
+        self.sin2 = 1.0
+        self.un = torch.zeros((self.D.shape[0],), dtype=torch.float64)
+
+    def mf_iterate(self, a):
+        om, Rk = self._rk(a)
+        v = Rk.T @ (self.u / np.linalg.norm(self.u))
+        self.un[:] = torch.from_numpy(Rk @ v)
+        return self.un
+
+    def mf_norm(self, a):
+        un = self.un.numpy().copy()
+        den = (un @ un) * (self.u @ self.u)
+        self.sin2 = max(0.0, 1.0 - (un @ self.u) ** 2 / den) if den > 0 else 0.0
+        self.u = un
+
+    def mf_sin2(self):
+        return self.sin2
+
+    def mf_apply(self, a):
+        nrm = np.linalg.norm(self.u)
+        u = self.u / nrm if nrm > 0 else self.D[:, a].copy()
+        if np.dot(u, self.D[:, a]) < 0:
+            u = -u
+        self.Dnext[:, a] = u
+        om, Rk = self._rk(a)
+        if om.any():
+            x = Rk.T @ u
+            self.R[:, om] = Rk - np.outer(u, x)
+            self.Z[a, om] = x
+
+
 class NumpyNnKsvdOps(NumpyExactKsvdOps):
     """Shard-local phases of nn_ksvd (ksvd.py:46-95) in numpy: stand-in for engine.HipNnKsvdOps."""
 
@@ -312,6 +354,13 @@ def _worker(rank, world, port, out):  # noqa: C901
         assert unused == list(ue) == [K - 1]
         assert np.max(np.abs(Dl - De)) < 1e-9, np.max(np.abs(Dl - De))
         assert np.max(np.abs(Zl - Ze[:, span[0]:span[1]])) < 1e-9
+        # ---- the same update without a Gram matrix (n > 256 on the device): power iteration, one n-vector all-reduce per
+        # iteration, stopped at 1e-6 rad between successive iterates == the exact SVD to the iteration's accuracy
+        Dl, Zl = D0.copy(), Z[:, span[0]:span[1]].copy()
+        unused = ld.ksvd_exact_cycle_sharded(NumpyExactMfOps(Xl, Dl, Zl), K)
+        assert unused == list(ue) == [K - 1]
+        assert np.max(np.abs(Dl - De)) < 2e-5, np.max(np.abs(Dl - De))
+        assert np.max(np.abs(Zl - Ze[:, span[0]:span[1]])) < 2e-5 * np.abs(Ze).max()
         # ---- nn_ksvd on shards: Gram matrix + one scalar / one n-vector per projection pass == the oracle on the full data
         rsn = np.random.RandomState(11)
         Dn = np.abs(rsn.randn(n, K)) + 0.05

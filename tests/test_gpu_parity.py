@@ -749,6 +749,38 @@ def test_online_dict_learn_golden(eng):
 
 
 # ------------------------------------------------------------------------------------------------ sharded (N > 1) path
+def _tall_sharded_problem():
+    """n = 300 features, 10 atoms (one unused), 3 atoms per signal, 240 signals: every atom is used on both shards."""
+    rs = np.random.RandomState(44)
+    n, K, k, N = 300, 10, 3, 240
+    Dt = rs.randn(n, K)
+    Dt /= np.linalg.norm(Dt, axis=0)
+    D0 = Dt + 0.3 * rs.randn(n, K)
+    D0 = (D0 / np.linalg.norm(D0, axis=0)).astype(np.float32).astype(np.float64)
+    Z = np.zeros((K, N))
+    for i in range(N):
+        Z[rs.choice(K - 1, k, replace=False), i] = rs.randn(k) + np.sign(rs.randn(k))
+    Z = Z.astype(np.float32).astype(np.float64)
+    X = (Dt @ Z + 0.05 * rs.randn(n, N)).astype(np.float32).astype(np.float64)
+    return X, D0, Z
+
+
+def _lc_problem():
+    """Golden F13's 'spm' LC-KSVD training problem (ScSPM features; test_lc_ksvd_golden)."""
+    g = load_golden("F13")
+    X, y = g["features_normed"], g["labels"]
+    train = g["spm_train"]
+    nca = int(g["spm_n_class_atoms"])
+    Xtr, ytr = X[:, train], y[train]
+    n_classes = len(set(y.tolist()))
+    Q = np.zeros((nca * n_classes, Xtr.shape[1]))
+    for c in range(n_classes):
+        Q[c * nca:(c + 1) * nca, ytr == c] = 1
+    par = dict(k=int(g["spm_k"]), alpha=float(g["spm_alpha"]), beta=float(g["spm_beta"]),
+               tol=max(5e-5, 2e-6 / (1.0 - float(g["spm_max_sv_ratio"])) / float(g["spm_min_top_norm"])))
+    return Xtr, ytr, Q, g["spm_D0"], par
+
+
 def _sharded_worker(rank, world, port, out, backend="gloo"):
     """gloo: two ranks share cuda:0 (gloo moves the CUDA tensors); nccl: one rank per GPU over RCCL.  Either way the
     product protocol code + HIP kernels on shards."""
@@ -815,6 +847,24 @@ def _sharded_worker(rank, world, port, out, backend="gloo"):
         R3, _ = eng.residual(Xs14, dd3, i3, c3, z3, want_R=True, want_err=False)
         un3 = eng.ksvd_exact_cycle(R3, dd3, i3, c3, z3, group=dist.group.WORLD, nn_cycles=1)
         res.update(D_nn=dd3.to_host(), Z_nn=eng.densify(i3, c3, z3, D14.shape[1]), unused_nn=un3, span14=span14)
+        # ---- exact update on shards for n > 256 (LC-KSVD's stacked shape): matrix-free power iteration, one all-reduce of n
+        # floats per iteration (dist.ksvd_exact_cycle_sharded_mf, lys_ksvd_exact_mf_phase)
+        Xt, Dt0, Zt = _tall_sharded_problem()
+        Xlt, spant = ld.local_shard(Xt)
+        Xst = eng.signals_to_device(Xlt)
+        dd4 = eng.DeviceDictionary.from_host(Dt0)
+        i4, c4, z4 = eng.sparsify_host(Zt[:, spant[0]:spant[1]])
+        R4, _ = eng.residual(Xst, dd4, i4, c4, z4, want_R=True, want_err=False)
+        ut = eng.ksvd_exact_cycle(R4, dd4, i4, c4, z4, group=dist.group.WORLD)
+        res.update(D_tall=dd4.to_host(), Z_tall=eng.densify(i4, c4, z4, Dt0.shape[1]), unused_tall=ut)
+        # ---- LC-KSVD on sample shards (golden F13 'spm': a stack of 672 + 12 + 4 rows): lc_ksvd(group=...)
+        from lyssandra_amd.dict_learning.lc_ksvd import lc_ksvd
+        Xtr, ytr, Q, D13, p13 = _lc_problem()
+        Xl13, span13 = ld.local_shard(Xtr)
+        se13 = sparse_encoder(algorithm='bomp', params={'n_nonzero_coefs': p13["k"]}, verbose=False)
+        Dl, Zl, Wl = lc_ksvd(Xl13, ytr[span13[0]:span13[1]], D13.copy(), Q[:, span13[0]:span13[1]], alpha=p13["alpha"],
+                             beta=p13["beta"], sparse_coder=se13, max_iter=2, group=dist.group.WORLD)
+        res.update(D_lc=Dl, Z_lc=Zl, W_lc=Wl)
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -970,6 +1020,29 @@ def test_sharded_ksvd_and_odl_two_ranks_one_gpu(eng):
                             return_codes=False)
     assert np.array_equal(r0["Dx"], r1["Dx"]) and _atom_err(r0["Dx"], Dx) < 1e-3
     assert np.max(np.abs(r0["Ao"] - Ao)) < 1e-4 * np.abs(Ao).max()
+    # exact update at n = 300 on 2 shards (matrix-free, one n-vector all-reduce per power iteration) == the float64 exact SVD
+    # on the full data, to the iteration's stop (1e-6 rad between successive iterates)
+    from oracle import lyssa_oracle as orc
+    Xt, Dt0, Zt = _tall_sharded_problem()
+    Do, Zo, uo = orc.ksvd_exact(Xt, Dt0.copy(), Zt.copy())
+    assert np.array_equal(r0["D_tall"], r1["D_tall"])                     # replicated, bit-identical
+    assert r0["unused_tall"] == r1["unused_tall"] == list(uo) == [Dt0.shape[1] - 1]
+    assert _atom_err(r0["D_tall"], Do) < 2e-5, _atom_err(r0["D_tall"], Do)
+    Zt2 = np.concatenate([r0["Z_tall"], r1["Z_tall"]], axis=1)
+    assert np.max(np.abs(Zt2 - Zo)) < 2e-5 * np.abs(Zo).max()
+    # LC-KSVD on 2 sample shards == the REFERENCE's own run on the full data (golden F13 'spm', 2 iterations), up to the sign of
+    # each stacked atom; same tolerance as test_lc_ksvd_golden
+    g13 = load_golden("F13")
+    p13 = _lc_problem()[4]
+    Dr, Zr, Wr = g13["spm_it2_D"], g13["spm_it2_Z"], g13["spm_it2_W"]
+    assert np.array_equal(r0["D_lc"], r1["D_lc"]) and np.array_equal(r0["W_lc"], r1["W_lc"])
+    sgn = np.sign(np.sum(r0["D_lc"] * Dr, axis=0))
+    sgn[sgn == 0] = 1
+    Zlc = np.concatenate([r0["Z_lc"], r1["Z_lc"]], axis=1)
+    assert np.array_equal(Zlc != 0, Zr != 0)
+    assert _atom_err(r0["D_lc"], Dr * sgn) < p13["tol"], (_atom_err(r0["D_lc"], Dr * sgn), p13["tol"])
+    assert np.max(np.abs(r0["W_lc"] - Wr * sgn)) < p13["tol"] * max(1.0, np.abs(Wr).max())
+    assert np.max(np.abs(Zlc - Zr * sgn[:, None])) < p13["tol"] * np.abs(Zr).max()
     # nn_ksvd on 2 shards == the reference's own run on the full data (golden F14, n_cycles = 1)
     g14 = load_golden("F14")
     assert np.array_equal(r0["D_nn"], r1["D_nn"])                         # replicated, bit-identical
