@@ -421,6 +421,24 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
                                    "note": "error evaluated (and read back) every iteration like the reference does"}
     except Exception as e:  # pragma: no cover
         res["fifty_iterations"] = {"error": repr(e)}
+    if ws == 1:
+        # the EXACT rank-1 sweep (ksvd.py:19-43) of the same shape: per-atom Gauss-Seidel chain, latency-bound
+        try:
+            dd.set(D0.t().contiguous())
+            xb, ts = {}, []
+            for it in range(3):
+                out = engine.bomp_encode(Xs, dd, k, out=out)
+                idx, coef, nnz = out
+                R, _ = engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False, out=R)
+                _, t_x = timed(lambda: engine.ksvd_exact_cycle(R, dd, idx, coef, nnz, buffers=xb))
+                ts.append(t_x)
+            t_x = min(ts[1:])
+            res["exact_sweep"] = {"ms": t_x, "achieved_GBs_8n_model": 8 * n * int(nnz.sum().item()) / (t_x * 1e-3) / 1e9,
+                                  "kernel": "exact_k1_kernel + exact_k2_kernel (pipelined: two dependent launches per atom; "
+                                            "index build included)",
+                                  "bound": "latency (a chain of 2 K dependent launches)"}
+        except Exception as e:  # pragma: no cover
+            res["exact_sweep"] = {"error": repr(e)}
     if ws > 1:
         stride = engine.HipBlockKsvdOps(R, dd, idx, coef, nnz, buffers).stride
         res["exchange"] = {"collectives_per_sweep": nb, "bytes_per_collective": stride * 8,

@@ -1688,6 +1688,8 @@ __device__ __forceinline__ double wave_sum_d(double x) {
 // threads only share the load of C (sum of the fp32 partials in fp64), then waves 1..3 retire.
 constexpr int E64_QS = 65;  // row stride of the Krylov basis (doubles): lanes reading different rows hit different banks
 
+__device__ int g_eig_mmin = 3;  // first Lanczos step the Ritz test runs at (LYS_EIG_MMIN)
+__device__ int g_eig_pre = 2;  // power steps before the Lanczos recurrence of the single-wave solver (LYS_EIG_PRE)
 constexpr int XK1_APPLY_BLOCKS = 1024;  // most apply workgroups of a K1 launch (16 entries each per pass)
 constexpr int XL_SH = 4;  // workgroups (= fp32 partials) of the shared-row Gram part of the pipelined sweep below
 
@@ -1763,8 +1765,29 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
     const double d0 = (double)d0f;
     auto sumsq64 = [&](double x) { return wave_sum_d(x * x); };  // (round 2: a 64-step loop of LDS broadcast reads, ~0.45 us)
     {
-        const double nrm2 = sumsq64(d0);
-        Q[lane] = (nrm2 > 0.0) ? d0 / sqrt(nrm2) : (lane == 0 ? 1.0 : 0.0);
+        // start vector: g_eig_pre power steps on d_old first (a matrix-vector product + one reduction is ~0.6 us, a Lanczos
+        // step 2-3 us)
+        double sv = d0;
+        double nrm2 = sumsq64(sv);
+        for (int ps = 0; ps < g_eig_pre && nrm2 > 0.0; ++ps) {
+            __builtin_amdgcn_wave_barrier();
+            wv[lane] = sv * fast_rsqrt(nrm2);
+            __builtin_amdgcn_wave_barrier();
+            double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < 64; c += 4) {
+                w0 = fma(Cl[c * 64 + lane], wv[c], w0);
+                w1 = fma(Cl[(c + 1) * 64 + lane], wv[c + 1], w1);
+                w2 = fma(Cl[(c + 2) * 64 + lane], wv[c + 2], w2);
+                w3 = fma(Cl[(c + 3) * 64 + lane], wv[c + 3], w3);
+            }
+            const double nv = (w0 + w1) + (w2 + w3);
+            const double n2 = sumsq64(nv);
+            if (!(n2 > 0.0)) break;  // C = 0 (or the vector in its null space): keep the previous one
+            sv = nv;
+            nrm2 = n2;
+        }
+        Q[lane] = (nrm2 > 0.0) ? sv * fast_rsqrt(nrm2) : (lane == 0 ? 1.0 : 0.0);
     }
     double scale0 = 0.0, theta_prev = 0.0;
     int m = 0;
@@ -1852,7 +1875,7 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
             __builtin_amdgcn_wave_barrier();
             break;
         }
-        if (m >= 3 && ritz_tridiag(m, H, beta, cvec, 1e-9, lane, theta_prev)) {
+        if (m >= g_eig_mmin && ritz_tridiag(m, H, beta, cvec, 1e-9, lane, theta_prev)) {
             __builtin_amdgcn_wave_barrier();
             break;
         }
@@ -1876,6 +1899,8 @@ __device__ __forceinline__ void eig64_body(int atom, int n, const int32_t* __res
         g_exact_stamp[2] = ts2;
         g_exact_stamp[3] = wall_clock64();
         g_exact_stamp[4] = (unsigned long long)m;
+        g_exact_stamp[13] += (unsigned long long)m;  // running sum of the steps and number of solves (tools/exact_stamps.py)
+        g_exact_stamp[14] += 1ull;
     }
 }
 
@@ -2855,6 +2880,18 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     if (pipe_env < 0) {
         const char* e = getenv("LYS_EXACT_PIPELINED");
         pipe_env = (e && e[0] == '0') ? 0 : 1;
+    }
+    static int pre_set[64] = {};
+    if (dev >= 0 && dev < 64 && !pre_set[dev]) {
+        const char* e = getenv("LYS_EIG_PRE");
+        // default 2 (configs[1], same box: 0 / 1 / 2 / 3 pre-steps -> 4.7 / 4.0 / 3.0 / 3.0 Lanczos steps per solve, sweep
+        // 24.0 / 24.8 / 22.6-23.3 / 23.8 ms; with the Ritz test from m = 2: 3 / 4 / 5 pre-steps -> 22.9 / 22.6 / 23.3 ms)
+        const int pre = (e && atoi(e) >= 0 && atoi(e) <= 8) ? atoi(e) : 2;
+        LYS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eig_pre), &pre, sizeof(int)));
+        const char* e2 = getenv("LYS_EIG_MMIN");
+        const int mmin = (e2 && atoi(e2) >= 2 && atoi(e2) <= 8) ? atoi(e2) : 3;
+        LYS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eig_mmin), &mmin, sizeof(int)));
+        pre_set[dev] = 1;
     }
     if (pipe_env && idx && link && parts > 0 && k <= 16 && nn_cycles < 0) {
         double* Csum = work + (size_t)G64_MAX_PARTS * 4096 / 2;
