@@ -2841,6 +2841,7 @@ static int nn_atom_phase(int phase, int a, float* R, int64_t ldr, int n, int k, 
 int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
                      float* coef, double* work, float* D, float* Dnext, int64_t max_support, hipStream_t stream,
                      int nn_cycles, float* xbuf, const int32_t* idx, void* link, int64_t link_nnz) {
+    if (K <= 0) return LYS_OK;
     if (n > 256) {
         if (nn_cycles >= 0) {
             set_error("nn_ksvd: n = %d > 256 is outside the non-negative update", n);
