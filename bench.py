@@ -54,6 +54,27 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def probe_sclk(enqueue, spin_us):
+    """Core clock in MHz while `enqueue()`'s work runs on the current stream: lys_debug_clock_probe on a side stream (one wave
+    spinning spin_us of the 100-MHz clock; enqueue at least that much work).  None if the probe is unavailable."""
+    import ctypes
+    import torch
+    from lyssandra_amd import _lib
+    try:
+        lib = _lib.load()
+        side = torch.cuda.Stream()
+        buf = torch.zeros((2,), dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+        torch.cuda.synchronize()
+        _lib.check(lib.lys_debug_clock_probe(ctypes.c_void_p(buf.data_ptr()), int(spin_us), ctypes.c_void_p(side.cuda_stream)),
+                   "lys_debug_clock_probe")
+        enqueue()
+        torch.cuda.synchronize()
+        t = buf.cpu().tolist()
+        return 100.0 * t[0] / t[1] if t[1] > 0 else None
+    except Exception:  # pragma: no cover
+        return None
+
+
 def flops_per_signal(n, K, k):
     """F = 2nK (alpha0) + K k (k+1) (correlation updates) + k^3 (Cholesky/solves)."""
     return 2 * n * K, K * k * (k + 1) + k ** 3
@@ -176,6 +197,9 @@ def main():
     _lib.check(lib.lys_profile_collect(ctypes.byref(g_ms), ctypes.byref(o_ms), ctypes.byref(launches),
                                        ctypes.byref(psig)), "lys_profile_collect")
     _lib.check(lib.lys_profile_enable(0), "lys_profile_enable")
+    # outside the timed region: the core clock the step really runs at (power management moves it; the roofline's peaks
+    # assume the nominal 2.4 GHz) -- one wave on a side stream compares the shader-clock counter with the 100-MHz clock
+    sclk_step = probe_sclk(lambda: [step() for _ in range(6)], 16000) if rank == 0 else None
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,6 +274,11 @@ def main():
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": omp_tf / PEAK_FP32_TFLOPS,
+                "sclk_mhz": {"step_loop": sclk_step, "nominal": 2400,
+                             "note": "core clock measured beside 6 more steps after the timed region (shader-clock counter "
+                                     "against the 100-MHz clock, one wave on a side stream); `peak` assumes the nominal clock, "
+                                     "so frac * nominal / step_loop is the fraction of what the chip offers at the clock its "
+                                     "power management grants this kernel mix"},
                 "traffic": traffic,
                 "traffic_stale": traffic_stale,
                 "bytes_8d_per_launch": bytes_8d * sig_per_launch,
@@ -375,6 +404,12 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
         t = torch.tensor([err], dtype=torch.float64)
         ld.allreduce_sum_(t, group)
         err = float(t.item())
+    if rk == 0:
+        # one more (untimed) alternation with the clock probe beside its encode: the same kernels run ~20 % slower here than in the
+        # step loop of `value` -- same instruction and cycle counts (profiles/), a lower core clock behind the low-power sweep
+        sclk_enc = probe_sclk(lambda: engine.bomp_encode(Xs, dd, k, out=out), 3000)
+    else:
+        sclk_enc = None
     ms = {kk: v / iters for kk, v in acc.items()}
     if ws > 1:
         ms["sweep_without_exchange"] = t_local / iters
@@ -397,6 +432,7 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
                                           "read + one row write per non-zero = the 8(d) bytes); LYS_BKSVD_LAZY=0 = the "
                                           "eager round-2 schedule (12*n bytes per non-zero)",
                               "includes": "index build (csr + block index), 257 step launches, final pass, D copy"},
+           "sclk_mhz_encode": sclk_enc,
            "final_error": err}
     # configs[1] as BASELINE.md states it: 50 alternations (encode, residual, sweep, error -- what ksvd_dict_learn runs per
     # iteration, ksvd.py:169-229) driven directly on the device-resident batch, one synchronisation at the end

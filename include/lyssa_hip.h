@@ -325,6 +325,10 @@ int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, f
 int lys_bksvd_block_size(int n);
 /* debugging aid: 64 phase timestamps (100 MHz device wall clock) of the last block-sweep launches (host buffer) */
 int lys_debug_timestamps(uint64_t* out64);
+/* debugging aid: one wave spins spin_us microseconds of the 100-MHz device clock on `stream` and writes to the DEVICE buffer
+ * out2 [0] the ticks of the shader (core) clock counter over that time, [1] the 100-MHz ticks: core MHz = 100 * out2[0] /
+ * out2[1].  Launched on a side stream beside a kernel it reports the clock that kernel runs at (bench.py: `sclk_mhz`). */
+int lys_debug_clock_probe(uint64_t* out2_device, int spin_us, void* stream);
 int lys_bksvd_layout(int n, int B, int32_t* out6);
 size_t lys_bksvd_stats_bytes(int n, int K, int B);
 size_t lys_bksvd_index_workspace_bytes(int K, int k, int64_t N, int B);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "lys_ksvd_commit": (_I, [_I, _I, _P, _P, _P, _P]),
     "lys_bksvd_block_size": (_I, [_I]),
     "lys_debug_timestamps": (_I, [_P]),
+    "lys_debug_clock_probe": (_I, [_P, _I, _P]),
     "lys_bksvd_layout": (_I, [_I, _I, _P]),
     "lys_bksvd_stats_bytes": (_Z, [_I, _I, _I]),
     "lys_bksvd_index_workspace_bytes": (_Z, [_I, _I, _L, _I]),

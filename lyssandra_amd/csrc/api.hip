@@ -627,6 +627,32 @@ int lys_ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, co
 // ---- block Gauss-Seidel sweep (ksvd_block.hip)
 int lys_bksvd_block_size(int n) { return bksvd_default_block(n); }
 
+// One wave spins for spin_us microseconds of the constant 100-MHz clock (s_memrealtime) and reports how far the shader-clock
+// counter (s_memtime: ticks of the core clock, which power management moves) advanced meanwhile: out[0] = core-clock ticks,
+// out[1] = 100-MHz ticks.  Launched on a side stream BESIDE a kernel it measures the clock that kernel really runs at.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out, int spin_us) {
+    const unsigned long long r0 = wall_clock64();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < (unsigned long long)spin_us * 100ull) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = wall_clock64();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = t1 - t0;
+        out[1] = r1 - r0;
+    }
+}
+
+int lys_debug_clock_probe(uint64_t* out2_device, int spin_us, void* stream) {
+    LYS_REQUIRE(out2_device && spin_us > 0 && spin_us <= 1000000, "debug_clock_probe: bad arguments");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, STREAM(stream),
+                       reinterpret_cast<unsigned long long*>(out2_device), spin_us);
+    LYS_LAUNCH_CHECK();
+    return LYS_OK;
+}
+
 int lys_debug_timestamps(uint64_t* out64) {
     LYS_REQUIRE(out64, "debug_timestamps: null pointer");
     const int rc = bk_debug_timestamps(reinterpret_cast<unsigned long long*>(out64));
