@@ -392,7 +392,12 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
             dd.D.copy_(D2)
             dd.invalidate()
         _, t_s = timed(lambda: engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group, buffers=buffers))
-        err, t_x = timed(lambda: engine.approx_error(Xs, dd, idx, coef, nnz))
+        # what ksvd_dict_learn does (ksvd.py:220): single GPU -- the ||R||^2 the sweep's final pass left behind; shards -- a pass
+        # of its own over X, D, Z (then all-reduced)
+        def learner_error():
+            e = engine.sweep_error(buffers) if ws == 1 else None
+            return e if e is not None else engine.approx_error(Xs, dd, idx, coef, nnz)
+        err, t_x = timed(learner_error)
         if it > 0:
             acc["encode"] += t_e
             acc["residual"] += t_r
@@ -449,12 +454,15 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
             idx, coef, nnz = out
             R, _ = engine.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False, out=R)
             engine.ksvd_cycle(R, dd, idx, coef, nnz, group=group, buffers=buffers)
-            e50 = engine.approx_error(Xs, dd, idx, coef, nnz)
+            e50 = engine.sweep_error(buffers) if ws == 1 else None
+            if e50 is None:
+                e50 = engine.approx_error(Xs, dd, idx, coef, nnz)
         torch.cuda.synchronize()
         t50 = (time.perf_counter() - t0) * 1e3
         res["fifty_iterations"] = {"iterations": n50, "ms_total": t50, "ms_per_iteration": t50 / n50,
                                    "final_error_this_rank": float(e50),
-                                   "note": "error evaluated (and read back) every iteration like the reference does"}
+                                   "note": "error evaluated (and read back) every iteration like the reference does (single GPU: "
+                                           "the sum of squared residual rows from the sweep's final pass, round 4)"}
     except Exception as e:  # pragma: no cover
         res["fifty_iterations"] = {"error": repr(e)}
     if ws == 1:

@@ -331,6 +331,11 @@ int lys_debug_timestamps(uint64_t* out64);
 int lys_debug_clock_probe(uint64_t* out2_device, int spin_us, void* stream);
 int lys_bksvd_layout(int n, int B, int32_t* out6);
 size_t lys_bksvd_stats_bytes(int n, int K, int B);
+/* Byte offset into `stats` of two doubles written by lys_bksvd_sweep's final pass (lazy schedule, k <= 16): [0] = sum of
+ * ||R_i||^2 over the rows it leaves = the approximation error ||X - D Z||^2 after the sweep (dict_learning/utils.py:14-19,
+ * evaluated by ksvd.py:225 every iteration) as a by-product of the pass that touches every row last; [1] = 1.0 when [0] was
+ * written (0.0: eager schedule -- evaluate the error with lys_residual). */
+size_t lys_bksvd_error_offset_bytes(int n, int K, int B);
 size_t lys_bksvd_index_workspace_bytes(int K, int k, int64_t N, int B);
 int lys_bksvd_index(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int B,
                     int32_t* row_ptr, void* entry_records, int32_t* cg_ptr, int32_t* cg_entry,

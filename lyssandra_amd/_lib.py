@@ -56,6 +56,7 @@ SIGNATURES = {
     "lys_debug_clock_probe": (_I, [_P, _I, _P]),
     "lys_bksvd_layout": (_I, [_I, _I, _P]),
     "lys_bksvd_stats_bytes": (_Z, [_I, _I, _I]),
+    "lys_bksvd_error_offset_bytes": (_Z, [_I, _I, _I]),
     "lys_bksvd_index_workspace_bytes": (_Z, [_I, _I, _L, _I]),
     "lys_bksvd_index": (_I, [_P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "lys_bksvd_step": (_I, [_I, _I, _I, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -102,7 +102,9 @@ struct BkLayout {
 BkLayout bk_layout(int n, int B);
 int bksvd_step(int, int, int, float*, int64_t, int, int, int, const int32_t*, const void*, const int32_t*, const int32_t*,
                const int32_t*, float*, const float*, float*, double*, hipStream_t);
-int bksvd_finish(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const float*, const float*, int, hipStream_t);
+int bksvd_finish(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const float*, const float*, int, hipStream_t,
+                 double* = nullptr);
+size_t bksvd_error_offset_doubles(int, int, int);
 int64_t sym_packed_count(int, int);
 int sym_pack(const float*, int, int, float*, hipStream_t);
 int sym_unpack(const float*, int, int, float*, hipStream_t);
@@ -658,6 +660,11 @@ int lys_debug_timestamps(uint64_t* out64) {
     const int rc = bk_debug_timestamps(reinterpret_cast<unsigned long long*>(out64));
     if (rc) return rc;
     return exact_debug_stamps(reinterpret_cast<unsigned long long*>(out64) + 16);  // slots 16..31: exact K-SVD kernels
+}
+
+size_t lys_bksvd_error_offset_bytes(int n, int K, int B) {
+    if (n < 1 || K < 1 || (B != 4 && B != 8)) return 0;
+    return bksvd_error_offset_doubles(n, K, B) * sizeof(double);
 }
 
 int lys_bksvd_layout(int n, int B, int32_t* out6) {

@@ -1147,10 +1147,24 @@ template <int FB, int LOGB, int SL, bool FULL>
 __global__ __launch_bounds__(256) void bksvd_final_kernel(int64_t N, float* __restrict__ R, int64_t ldr, int n, int k,
                                                           const int32_t* __restrict__ idx, float* __restrict__ coef,
                                                           const float* __restrict__ D, const float* __restrict__ Dnext,
-                                                          int ldd) {
+                                                          int ldd, double* __restrict__ err_out) {
     constexpr int B = 1 << LOGB;
     const int tid = threadIdx.x, team = tid >> 4, q = tid & 15;
     const int64_t nteams = (int64_t)gridDim.x * 16;
+    // err_out (may be null): [0] += sum of ||R_i||^2 over the FINAL rows -- the sweep's approximation error ||X - D Z||^2
+    // (ksvd.py:225, dict_learning/utils.py:14-19) as a by-product of the one pass that touches every row last; [1] = 1 marks it
+    double esum = 0.0;
+    auto row_sq = [&](const float4 (&r)[FB]) {
+        float sq = 0.f;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            sq = fmaf(r[b].x, r[b].x, sq);
+            sq = fmaf(r[b].y, r[b].y, sq);
+            sq = fmaf(r[b].z, r[b].z, sq);
+            sq = fmaf(r[b].w, r[b].w, sq);
+        }
+        esum += (double)bk_row16_sum(sq);
+    };
     for (int64_t sig = (int64_t)blockIdx.x * 16 + team; sig < N; sig += nteams) {
         float4 r[FB];
         int a[SL];
@@ -1176,7 +1190,10 @@ __global__ __launch_bounds__(256) void bksvd_final_kernel(int64_t N, float* __re
         lb = max(lb, bk_dpp_i<0x4E>(lb));
         lb = max(lb, bk_dpp_i<0x124>(lb));
         lb = max(lb, bk_dpp_i<0x128>(lb));
-        if (lb < 0) continue;  // uniform per team: the signal uses no atom
+        if (lb < 0) {  // uniform per team: the signal uses no atom (its row is the signal itself)
+            if (err_out) row_sq(r);
+            continue;
+        }
         unsigned m = 0;
 #pragma unroll
         for (int s = 0; s < SL; ++s) m |= (a[s] >= 0 && (a[s] >> LOGB) == lb) ? (1u << (a[s] & (B - 1))) : 0u;
@@ -1225,6 +1242,19 @@ __global__ __launch_bounds__(256) void bksvd_final_kernel(int64_t N, float* __re
         for (int b = 0; b < FB; ++b) {
             const int f = 64 * b + 4 * q;
             if (FULL || f < n) *reinterpret_cast<float4*>(R + sig * ldr + f) = r[b];
+        }
+        if (err_out) row_sq(r);
+    }
+    if (err_out) {
+        __shared__ double s_e[16];
+        if (q == 0) s_e[team] = esum;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += s_e[i];
+            atomicAdd(err_out, t);
+            if (blockIdx.x == 0) err_out[1] = 1.0;
         }
     }
 }
@@ -1334,7 +1364,7 @@ int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int 
 
 // Lazy schedule: the pending update of every signal's last block (no-op for the eager schedule).  Call once after X(nb).
 int bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef, const float* D,
-                 const float* Dnext, int B, hipStream_t stream) {
+                 const float* Dnext, int B, hipStream_t stream, double* err_out) {
     if (!bksvd_lazy(k, K) || N <= 0) return LYS_OK;
     if (n > 256 || (B != 4 && B != 8) || (B == 8 && n > 128)) {
         set_error("bksvd_finish: unsupported shape n=%d k=%d B=%d", n, k, B);
@@ -1350,10 +1380,10 @@ int bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, const in
     do {                                                                                                               \
         if (full)                                                                                                      \
             hipLaunchKernelGGL((bksvd_final_kernel<FBv, LOGBv, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, N, R, \
-                               ldr, n, k, idx, coef, D, Dnext, ldd);                                                   \
+                               ldr, n, k, idx, coef, D, Dnext, ldd, err_out);                                          \
         else                                                                                                           \
             hipLaunchKernelGGL((bksvd_final_kernel<FBv, LOGBv, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, N, R, \
-                               ldr, n, k, idx, coef, D, Dnext, ldd);                                                   \
+                               ldr, n, k, idx, coef, D, Dnext, ldd, err_out);                                          \
     } while (0)
     if (fb == 1) {
         if (B == 8) BK_FIN(1, 3); else BK_FIN(1, 2);
@@ -1376,8 +1406,9 @@ int bk_debug_timestamps(unsigned long long* out64) {
 size_t bksvd_stats_doubles(int n, int K, int B) {
     const BkLayout lay = bk_layout(n, B);
     const size_t nb = (size_t)((K + B - 1) / B);
-    return nb * (size_t)lay.stride + (nb + 2) * 8;  // 16 ints per block
+    return nb * (size_t)lay.stride + (nb + 2) * 8 + 8;  // 16 ints per block, then [||R||^2 of the final pass, its valid flag, spare]
 }
+size_t bksvd_error_offset_doubles(int n, int K, int B) { return bksvd_stats_doubles(n, K, B) - 8; }
 
 int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K, int k, int64_t N, int32_t* row_ptr,
                 int32_t* entry, void* ws, size_t ws_bytes, hipStream_t stream, int logb, int32_t* cg_ptr,
@@ -1412,7 +1443,7 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
                 const int r = bksvd_step(2, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, st);
                 if (r) return r;
             }
-            return bksvd_finish(R, ldr, n, K, k, N, idx, coef, D, Dnext, B, st);
+            return bksvd_finish(R, ldr, n, K, k, N, idx, coef, D, Dnext, B, st, bbuf + bksvd_error_offset_doubles(n, K, B));
         }
         for (int c = 0; c <= nb; ++c) {
             int r = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, st);
@@ -1422,7 +1453,7 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
                 if (r) return r;
             }
         }
-        return bksvd_finish(R, ldr, n, K, k, N, idx, coef, D, Dnext, B, st);
+        return bksvd_finish(R, ldr, n, K, k, N, idx, coef, D, Dnext, B, st, bbuf + bksvd_error_offset_doubles(n, K, B));
     };
     // LYS_BKSVD_GRAPH=1: the 2 K/B + 1 dependent launches replayed as one hipGraph while the buffers stay the same (the
     // learners allocate them once per fit).  The first sweep on a device always runs eagerly (function attributes).

@@ -169,8 +169,11 @@ def ksvd_dict_learn(X, n_atoms, init_dict='data', sparse_coder=None,
             else:   # replicated decision: code-row norms all-reduced, candidate columns fetched by global index
                 Dh, unused_data = _dist.force_mi_sharded(Dh, X, (idx, coef, nnz), shard_span, unused_data, eta, group)
             dd.set(Dh)
-        # ---- error with the updated codes (ksvd.py:220)
-        error = engine.approx_error(Xs, dd, idx, coef, nnz)
+        # ---- error with the updated codes (ksvd.py:220).  The single-GPU block sweep's final pass leaves ||R||^2 = ||X - D Z||^2
+        # behind (engine.sweep_error); replaced UNUSED atoms have all-zero code rows and do not change it, `eta` does
+        error = engine.sweep_error(buffers) if (group is None and not (eta is not None and it < max_iter - 1)) else None
+        if error is None:
+            error = engine.approx_error(Xs, dd, idx, coef, nnz)
         if group is not None:
             error = _allreduce_scalar(error, dd.device, group)
         if verbose:

@@ -481,6 +481,7 @@ class HipBlockKsvdOps(object):
             buffers["stats_all"] = torch.zeros((nd,), dtype=torch.float64, device=dd.device)
             buffers["stats"] = buffers["stats_all"][:self.nb * self.stride].view(self.nb, self.stride)
             buffers["bDnext"] = torch.zeros_like(dd.D)
+        self.buffers = buffers
         self.row_ptr, self.erec = buffers["brow_ptr"], buffers["berec"]
         self.cg_ptr, self.cg_entry = buffers["bcg_ptr"], buffers["bcg_entry"]
         self.stats, self.stats_all, self.Dnext = buffers["stats"], buffers["stats_all"], buffers["bDnext"]
@@ -511,6 +512,9 @@ class HipBlockKsvdOps(object):
                                             self.ws.numel(), _ptr(self.stats_all), _ptr(dd.D), _ptr(self.Dnext),
                                             _stream()), "lys_bksvd_sweep")
         dd.invalidate()
+        # the final pass of the lazy schedule leaves ||R||^2 = ||X - D Z||^2 behind the slabs (see sweep_error)
+        off = int(self.lib.lys_bksvd_error_offset_bytes(dd.n, dd.K, self.B)) // 8
+        self.buffers["sweep_error_view"] = self.stats_all[off:off + 2]
         return self.unused()
 
     # -- the `ops` interface of dist.ksvd_cycle_blocks
@@ -542,6 +546,18 @@ class HipBlockKsvdOps(object):
         self.dd.D[:self.dd.K].copy_(self.Dnext[:self.dd.K])
         self.dd.invalidate()
         return self.unused()
+
+
+def sweep_error(buffers):
+    """||X - D Z||^2 (dict_learning/utils.py:14-19) right after the LAST single-GPU ksvd_cycle that used ``buffers``, as left by
+    the sweep's final pass (sum of the squared residual rows it wrote: the same quantity lys_residual evaluates from X, D and Z
+    in a pass of its own), or None when that sweep did not produce it (eager schedule, legacy / sharded sweep).  One use per
+    sweep: anything that changes D or the codes afterwards (eta / force_mi) invalidates it -- call approx_error then."""
+    v = buffers.pop("sweep_error_view", None) if buffers is not None else None
+    if v is None:
+        return None
+    e, flag = v.cpu().tolist()
+    return float(e) if flag == 1.0 else None
 
 
 def ksvd_cycle(R, dd, idx, coef, nnz, group=None, buffers=None, block=None):

@@ -1079,6 +1079,43 @@ def test_approx_ksvd_other_feature_sizes(eng, n, K, k, N):
     assert np.array_equal(D[:, K // 2], D0[:, K // 2])             # unused atom keeps its column
 
 
+@pytest.mark.parametrize("n,K,k,N", [(64, 256, 5, 30000), (30, 40, 3, 2570), (100, 96, 4, 1700), (200, 150, 6, 900),
+                                     (64, 1024, 10, 50000)])
+def test_sweep_error_equals_approx_error(eng, n, K, k, N):
+    """engine.sweep_error: the sum of the squared residual rows the block sweep's final pass writes IS the approximation error
+    ||X - D Z||^2 (dict_learning/utils.py:14-19) that ksvd_dict_learn evaluates after every update (ksvd.py:220-225) -- against
+    lys_residual's own pass over X, D and the updated codes, on full and ragged feature counts (zero padding of the rows must not
+    leak in), signals without atoms included; one use per sweep; the eager schedule reports None."""
+    import os
+    import torch
+    rs = np.random.RandomState(n + K)
+    D0 = rs.randn(n, K)
+    D0 /= np.linalg.norm(D0, axis=0, keepdims=True)
+    X = rs.randn(n, N)
+    X[:, ::97] = 0.0                                   # zero signals: no atom selected, their rows still count (as zero)
+    Xs = eng.signals_to_device(X)
+    dd = eng.DeviceDictionary.from_host(D0)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    nnz[5::53] = 0                                     # signals whose codes were dropped: R_i = x_i
+    coef[5::53] = 0
+    buffers = {}
+    for cyc in range(2):
+        R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+        eng.ksvd_cycle(R, dd, idx, coef, nnz, buffers=buffers)
+        e_sweep = eng.sweep_error(buffers)
+        e_ref = eng.approx_error(Xs, dd, idx, coef, nnz)
+        assert e_sweep is not None and abs(e_sweep - e_ref) <= 2e-6 * e_ref, (cyc, e_sweep, e_ref)
+        assert abs(float((R.double() ** 2).sum().item()) - e_sweep) <= 1e-6 * e_ref
+        assert eng.sweep_error(buffers) is None        # consumed
+    os.environ["LYS_BKSVD_LAZY"] = "0"
+    try:
+        R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+        eng.ksvd_cycle(R, dd, idx, coef, nnz, buffers=buffers)
+        assert eng.sweep_error(buffers) is None        # the eager schedule has no final pass
+    finally:
+        del os.environ["LYS_BKSVD_LAZY"]
+
+
 @pytest.mark.parametrize("Kp,block", [(2048, 1024), (640, 256), (1024, 1024), (192, 64), (8192, 1024)])
 def test_symmetric_exchange_pack_unpack_round_trip(eng, Kp, block):
     """The exchange format of Z Z' (online_dict_learn.py:84 per shard; lys_sym_pack / lys_sym_unpack): only the block-upper
