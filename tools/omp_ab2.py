@@ -65,7 +65,7 @@ for v in [-1] + variants:
 order = [0, -1] + [v for v in variants if v in names]
 times = {v: [] for v in order}
 o = outs()
-for rnd in range(24):
+for rnd in range(int(os.environ.get("AB_ROUNDS", "24"))):
     for v in order:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
