@@ -1924,8 +1924,8 @@ __global__ __launch_bounds__(256) void ksvd_eig64_kernel(int atom, int n, const 
 //   Every residual row is written by exactly one workgroup of one launch, and read by a Gram part only in a launch after
 //   the one that wrote it: the Gauss-Seidel order of ksvd.py:28-43 is kept exactly (the sums are taken in a different --
 //   fixed -- order than the four-launch path, so the two agree to rounding, not bit for bit).
-//   The host reads row_ptr back once (K + 1 ints): unused atoms are skipped, and every launch gets its atoms' list bounds
-//   as kernel arguments instead of opening with a chain of dependent scalar loads.
+//   The host reads row_ptr and the shared-row counts back (two short synchronisations per sweep): unused atoms are skipped, and
+//   every launch gets its atoms' list bounds as kernel arguments instead of opening with a chain of dependent scalar loads.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float row16_max(float x) {  // max over the 16 lanes of a DPP row, in every lane
     x = fmaxf(x, dpp_f<0xB1>(x));
@@ -2906,18 +2906,20 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
         int32_t* plink = reinterpret_cast<int32_t*>(shpair + link_nnz);
         uint8_t* eflag = reinterpret_cast<uint8_t*>(plink + link_nnz);
         std::vector<int32_t> rp((size_t)K + 1), hns((size_t)K);
-        hipLaunchKernelGGL(exact_neighbours_kernel, dim3((unsigned)(K + 255) / 256), dim3(256), 0, stream, K, row_ptr, pn);
-        hipLaunchKernelGGL(exact_flag_kernel, dim3(2048), dim3(256), 0, stream, K, k, row_ptr, entry, idx, coef, pn, eflag, plink);
-        hipLaunchKernelGGL(exact_compact_kernel, dim3((unsigned)K), dim3(256), 0, stream, row_ptr, entry, plink, shpair, nsh);
-        LYS_LAUNCH_CHECK();
-        // one read-back per sweep: the lists' bounds and the shared-row counts become kernel ARGUMENTS of the 2 L launches below
+        // the index size first (its own short synchronisation): the link kernels below write row_ptr[K] entries of the link area
         LYS_CHECK_HIP(hipMemcpyAsync(rp.data(), row_ptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        LYS_CHECK_HIP(hipMemcpyAsync(hns.data(), nsh, hns.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         LYS_CHECK_HIP(hipStreamSynchronize(stream));
         if (rp[K] > link_nnz) {
             set_error("ksvd_exact_sweep_idx: nnz_total = %lld < row_ptr[K] = %d", (long long)link_nnz, rp[K]);
             return LYS_EINVAL;
         }
+        hipLaunchKernelGGL(exact_neighbours_kernel, dim3((unsigned)(K + 255) / 256), dim3(256), 0, stream, K, row_ptr, pn);
+        hipLaunchKernelGGL(exact_flag_kernel, dim3(2048), dim3(256), 0, stream, K, k, row_ptr, entry, idx, coef, pn, eflag, plink);
+        hipLaunchKernelGGL(exact_compact_kernel, dim3((unsigned)K), dim3(256), 0, stream, row_ptr, entry, plink, shpair, nsh);
+        LYS_LAUNCH_CHECK();
+        // the second read-back: with the lists' bounds, the shared-row counts become kernel ARGUMENTS of the 2 L launches below
+        LYS_CHECK_HIP(hipMemcpyAsync(hns.data(), nsh, hns.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        LYS_CHECK_HIP(hipStreamSynchronize(stream));
         std::vector<int> used;
         for (int a = 0; a < K; ++a)
             if (rp[a + 1] > rp[a]) used.push_back(a);

@@ -600,6 +600,42 @@ def test_exact_ksvd_pipelined_sweep(eng, n, K, k, N, unused):
     assert _atom_err(Dh, Do) < 5e-5, _atom_err(Dh, Do)
     assert np.max(np.abs(Zh - Zo)) < 5e-5 * np.abs(Zo).max()
     assert np.array_equal(Zh != 0, Zo != 0)
+    if (n, K) == (25, 40):   # two cycles: the second sweep starts from the first one's residual, codes and index buffers
+        Do2, Zo2, _ = orc.ksvd_exact(X, D0.copy(), Z.copy(), n_cycles=2)
+        Dh2, Zh2 = D0.copy(), Z.copy()
+        ksvd(X, Dh2, Zh2, n_cycles=2, verbose=False)
+        assert _atom_err(Dh2, Do2) < 1e-4 and np.max(np.abs(Zh2 - Zo2)) < 1e-4 * np.abs(Zo2).max()
+
+
+def test_exact_ksvd_sweep_idx_rejects_short_workspace(eng):
+    """lys_ksvd_exact_sweep_idx: a work buffer without the link area, or an nnz_total below row_ptr[K], is an error, not an
+    overrun."""
+    import ctypes
+    import torch
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(1)
+    n, K, k, N = 32, 16, 3, 400
+    D0 = rs.randn(n, K)
+    D0 /= np.linalg.norm(D0, axis=0)
+    Xs = eng.signals_to_device(rs.randn(n, N))
+    dd = eng.DeviceDictionary.from_host(D0)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+    row_ptr, entry = eng.csr_by_atom(idx, coef, nnz, K)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    Dn = torch.zeros_like(dd.D)
+    base = int(lib.lys_ksvd_exact_workspace_bytes(n))
+    full = int(lib.lys_ksvd_exact_idx_workspace_bytes(n, K, N * k))
+    assert full > base
+    work = torch.zeros(((full + 7) // 8,), dtype=torch.float64, device="cuda")
+    args = lambda wb, nt: (P(R), int(R.stride(0)), n, K, k, P(row_ptr), P(entry), P(idx), P(coef), P(work), wb, P(dd.D), P(Dn),
+                           N, nt, st)
+    assert lib.lys_ksvd_exact_sweep_idx(*args(base, N * k)) != 0            # no room for the link area
+    assert lib.lys_ksvd_exact_sweep_idx(*args(full, 1)) != 0                # nnz_total below the index size
+    assert lib.lys_ksvd_exact_sweep_idx(*args(full, N * k)) == 0
+    torch.cuda.synchronize()
 
 
 def test_exact_ksvd_tiny_supports(eng):
@@ -750,7 +786,7 @@ def test_online_dict_learn_golden(eng):
 
 # ------------------------------------------------------------------------------------------------ sharded (N > 1) path
 def _tall_sharded_problem():
-    """n = 300 features, 10 atoms (one unused), 3 atoms per signal, 240 signals: every atom is used on both shards."""
+    """n = 300 features, 10 atoms (one unused), 3 atoms per signal, 240 signals; atoms 0 and 1 are used on one shard each."""
     rs = np.random.RandomState(44)
     n, K, k, N = 300, 10, 3, 240
     Dt = rs.randn(n, K)
@@ -760,6 +796,8 @@ def _tall_sharded_problem():
     Z = np.zeros((K, N))
     for i in range(N):
         Z[rs.choice(K - 1, k, replace=False), i] = rs.randn(k) + np.sign(rs.randn(k))
+    Z[0, N // 2:] = 0.0            # atom 0 lives on the first shard only: the second shard runs its phases with no local rows
+    Z[1, :N // 2] = 0.0            # ... and atom 1 on the second shard only
     Z = Z.astype(np.float32).astype(np.float64)
     X = (Dt @ Z + 0.05 * rs.randn(n, N)).astype(np.float32).astype(np.float64)
     return X, D0, Z
