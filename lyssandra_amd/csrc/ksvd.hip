@@ -1690,6 +1690,7 @@ constexpr int E64_QS = 65;  // row stride of the Krylov basis (doubles): lanes r
 
 __device__ int g_eig_mmin = 3;  // first Lanczos step the Ritz test runs at (LYS_EIG_MMIN)
 __device__ int g_eig_pre = 2;  // power steps before the Lanczos recurrence of the single-wave solver (LYS_EIG_PRE)
+constexpr int XK1_RED = 64;            // workgroups of K1's partial-sum role (64 matrix elements each)
 constexpr int XK1_APPLY_BLOCKS = 1024;  // most apply workgroups of a K1 launch (16 entries each per pass)
 constexpr int XL_SH = 4;  // workgroups (= fp32 partials) of the shared-row Gram part of the pipelined sweep below
 
@@ -1985,10 +1986,13 @@ __global__ __launch_bounds__(256) void exact_flag_kernel(int K, int k, const int
     }
 }
 
-// One workgroup per atom: stable compaction of its (a, p) shared entries -- (coefficient position of a, of p) in list (=
-// signal) order -- behind row_ptr[a] of shpair, their number in nsh[a].
-__global__ __launch_bounds__(256) void exact_compact_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ entry,
-                                                            const int32_t* __restrict__ plink, int2* __restrict__ shpair,
+// One workgroup per atom: stable compaction of its (a, p) shared entries, in list (= signal) order, behind row_ptr[a] of shrec;
+// their number in nsh[a].  A record = {signal, position of p's coefficient, x_a, x_p}: both coefficients still hold their
+// sweep-start values when K1(a) uses them (x_a changes in apply(a), x_p -- for exactly these rows -- in K1(a) itself), so the
+// shared part reads ONE record per row and then the residual row: two dependent loads instead of four.
+__global__ __launch_bounds__(256) void exact_compact_kernel(int k, const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ entry, const int32_t* __restrict__ plink,
+                                                            const float* __restrict__ coef, int4* __restrict__ shrec,
                                                             int32_t* __restrict__ nsh) {
     __shared__ int s_w[2][4];
     const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -2004,15 +2008,19 @@ __global__ __launch_bounds__(256) void exact_compact_kernel(const int32_t* __res
         __syncthreads();  // (two count rows: the next round's writes cannot overtake this round's reads)
         int off = filled;
         for (int w = 0; w < wid; ++w) off += s_w[par][w];
-        if (pl >= 0) shpair[beg + off + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(ss, pl);
+        if (pl >= 0)  // ~1 % of the entries
+            shrec[beg + off + __popcll(bal & ((1ull << lane) - 1ull))] =
+                make_int4(ss / k, pl, __builtin_bit_cast(int, coef[ss]), __builtin_bit_cast(int, coef[pl]));
         filled += s_w[par][0] + s_w[par][1] + s_w[par][2] + s_w[par][3];
     }
     if (tid == 0) nsh[a] = filled;
 }
 
 __device__ __forceinline__ int xl_shared_chunk(int ns) {  // shared rows per workgroup of K1's shared part
+    // spread evenly over the XL_SH workgroups (multiples of 8 rows = 4 MFMA steps): with whole rounds of 64 the first
+    // workgroup carried 64 of ~100 rows -- 1.1 us of fp32 matrix products on the critical role of the launch
     const int c = (ns + XL_SH - 1) / XL_SH;
-    return max(64, ((c + 63) >> 6) << 6);
+    return max(8, ((c + 7) >> 3) << 3);
 }
 
 // apply of atom p (list [beg, end)) on its entries without flag bit 1 (FB = 1: n <= 64)
@@ -2059,15 +2067,14 @@ __device__ __forceinline__ void exact_apply_unshared(int p, int beg, int end, in
     }
 }
 
-// the (atom, p) shared rows: p's pending update in place, then their Gram partial (gram64_part's tiling)
+// the (atom, p) shared rows: p's pending update in place, then their Gram partial (gram64_part's tiling).  Every wave reads the
+// records of its own rows (wave-uniform addresses) and then the rows: no staging pass, no workgroup barrier before the loads;
+// the sixteen rows of a wave go through one branch-free block, so their sixteen wave reductions interleave.
 __device__ __forceinline__ void exact_shared_part(int atom, int p, int beg, int sb, float* __restrict__ R, int64_t ldr, int n,
-                                                  int k, const int2* __restrict__ shpair, int ns,
-                                                  float* __restrict__ coef, const float* __restrict__ D, int ldd,
-                                                  const float* __restrict__ Dnext, float* __restrict__ spart) {
+                                                  const int4* __restrict__ shrec, int ns, float* __restrict__ coef,
+                                                  const float* __restrict__ D, int ldd, const float* __restrict__ Dnext,
+                                                  float* __restrict__ spart) {
     __shared__ float s_a[64][65];
-    __shared__ int64_t s_off[G64_ROWS];
-    __shared__ float s_x[G64_ROWS], s_xp[G64_ROWS];
-    __shared__ int s_pc[G64_ROWS];
     const int chunk = xl_shared_chunk(ns);
     const int j0 = sb * chunk, total = min(chunk, ns - j0);
     if (total <= 0) return;
@@ -2079,40 +2086,32 @@ __device__ __forceinline__ void exact_shared_part(int atom, int p, int beg, int 
     const float dprev = (lane < n) ? D[(int64_t)p * ldd + lane] : 0.f;
     const float uprev = (lane < n) ? Dnext[(int64_t)p * ldd + lane] : 0.f;
     const int lf = min(lane, n - 1);
-    for (int b0 = 0; b0 < total; b0 += G64_ROWS) {  // one batch unless an atom shares > 768 * XL_SH signals with its predecessor
-        const int cnt = min(G64_ROWS, total - b0);
-        __syncthreads();
-        for (int i = tid; i < cnt; i += 256) {
-            const int2 pr = shpair[beg + j0 + b0 + i];
-            s_off[i] = (int64_t)(pr.x / k) * ldr;
-            s_x[i] = coef[pr.x];
-            s_pc[i] = pr.y;
-            s_xp[i] = coef[pr.y];
+    const int4* rec = shrec + beg + j0;
+    for (int r0 = 0; r0 < total; r0 += 64) {
+        int4 rc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rc[q] = rec[min(r0 + wid + 4 * q, total - 1)];
+        float cur[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cur[q] = R[(int64_t)rc[q].x * ldr + lf];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the previous round's MFMAs have read s_a
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const bool on = (r0 + wid + 4 * q < total) && lane < n;  // (row valid: wave-uniform)
+            const float xa = __builtin_bit_cast(float, rc[q].z), xp = __builtin_bit_cast(float, rc[q].w);
+            const float rk = on ? fmaf(dprev, xp, cur[q]) : 0.f;
+            const float xn = wave_sum_f(rk * uprev);
+            const float rn = fmaf(-uprev, xn, rk);
+            if (on) R[(int64_t)rc[q].x * ldr + lane] = rn;
+            if (on && lane == 0) coef[rc[q].y] = xn;
+            s_a[wid + 4 * q][lane] = on ? fmaf(d, xa, rn) : 0.f;
         }
-        __syncthreads();
-        for (int r0 = 0; r0 < cnt; r0 += 64) {
-            float cur[16];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int kmax = min(64, (total - r0 + 7) & ~7);  // the rows past `total` of this round are zero: skip their products
+        for (int i0 = 0; i0 < kmax; i0 += 8) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) cur[q] = R[s_off[min(r0 + wid + 4 * q, cnt - 1)] + lf];
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the previous round's MFMAs have read s_a
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int i = r0 + wid + 4 * q;  // wave-uniform: a wave stages one row at a time
-                float v = 0.f;
-                if (i < cnt) {
-                    const float rk = (lane < n) ? fmaf(dprev, s_xp[i], cur[q]) : 0.f;
-                    const float xn = wave_sum_f(rk * uprev);
-                    const float rn = fmaf(-uprev, xn, rk);
-                    if (lane < n) R[s_off[i] + lane] = rn;
-                    if (lane == 0) coef[s_pc[i]] = xn;
-                    v = (lane < n) ? fmaf(d, s_x[i], rn) : 0.f;
-                }
-                s_a[wid + 4 * q][lane] = v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll 8
-            for (int i = 0; i < 64; i += 2) {
-                const int kk = i + (lane >> 5);
+            for (int i = 0; i < 8; i += 2) {
+                const int kk = i0 + i + (lane >> 5);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_a[kk][32 * ti + (lane & 31)], s_a[kk][32 * tj + (lane & 31)], acc,
                                                            0, 0, 0);
             }
@@ -2126,36 +2125,52 @@ __device__ __forceinline__ void exact_shared_part(int atom, int p, int beg, int 
     }
 }
 
-// K1(atom; p = the used atom before it, -1: none): blocks [0, 16) sum atom's `parts` Gram partials, [16, 16 + XL_SH) take the
+// K1(atom; p = the used atom before it, -1: none): blocks [0, XK1_RED) sum atom's `parts` Gram partials, the next XL_SH take the
 // nsa (atom, p) shared rows, the rest apply p.  atom < 0 closes the sweep: only the apply of p (the last used atom).
 __global__ __launch_bounds__(256) void exact_k1_kernel(int atom, int abeg, int parts, int nsa, int p, int pbeg, int pend,
                                                        float* __restrict__ R, int64_t ldr, int n, int k,
                                                        const int32_t* __restrict__ entry, const uint8_t* __restrict__ eflag,
-                                                       const int2* __restrict__ shpair,
+                                                       const int4* __restrict__ shrec,
                                                        float* __restrict__ coef, const float* __restrict__ D, int ldd,
                                                        const float* __restrict__ Dnext, const float* __restrict__ part,
                                                        double* __restrict__ Csum, float* __restrict__ spart) {
     const int bx = blockIdx.x;
-    if (bx < 16) {
-        if (atom < 0) return;
-        const int e = bx * 256 + threadIdx.x;  // ksvd_gram64_reduce_kernel's sum, same order
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int p0 = 0; p0 < parts; p0 += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = part[(int64_t)min(p0 + u, parts - 1) * 4096 + e];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc[u & 3] += (p0 + u < parts) ? (double)v[u] : 0.0;
+#ifdef LYS_EXACT_K1_STAMPS
+    struct K1Stamp {  // in-kernel duration of the first workgroup of each role (tools/exact_stamps.py, K1_STAMPS=1)
+        unsigned long long t0;
+        int slot;
+        __device__ ~K1Stamp() {
+            if (slot >= 0 && threadIdx.x == 0) g_exact_stamp[slot] = wall_clock64() - t0;
         }
-        Csum[e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    } k1s;
+    k1s.t0 = wall_clock64();
+    k1s.slot = atom < 0 ? -1 : bx == 0 ? 5 : bx == XK1_RED ? 6 : bx == XK1_RED + XL_SH ? 7 : -1;
+#endif
+    if (bx < XK1_RED) {
+        if (atom < 0) return;
+        // 64 matrix elements per workgroup, the partials split over its four waves (each has all its <= 64 loads in flight at
+        // once), the four sums added in wave order: 16 workgroups of 256 elements pulled 106 KB each through one CU (3.4 us)
+        __shared__ double s_r[4][64];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int e = bx * 64 + lane;
+        const int per = (parts + 3) / 4, p0 = w * per, p1 = min(parts, p0 + per);
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        float v[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) v[u] = part[(int64_t)min(p0 + u, parts - 1) * 4096 + e];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) acc[u & 3] += (p0 + u < p1) ? (double)v[u] : 0.0;
+        s_r[w][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        __syncthreads();
+        if (w == 0) Csum[e] = (s_r[0][lane] + s_r[1][lane]) + (s_r[2][lane] + s_r[3][lane]);
         return;
     }
     if (p < 0) return;
-    if (bx < 16 + XL_SH) {
-        if (atom >= 0) exact_shared_part(atom, p, abeg, bx - 16, R, ldr, n, k, shpair, nsa, coef, D, ldd, Dnext, spart);
+    if (bx < XK1_RED + XL_SH) {
+        if (atom >= 0) exact_shared_part(atom, p, abeg, bx - XK1_RED, R, ldr, n, shrec, nsa, coef, D, ldd, Dnext, spart);
         return;
     }
-    exact_apply_unshared(p, pbeg, pend, bx - 16 - XL_SH, (int)gridDim.x - 16 - XL_SH, R, ldr, n, k, entry, eflag, coef, D, ldd,
+    exact_apply_unshared(p, pbeg, pend, bx - XK1_RED - XL_SH, (int)gridDim.x - XK1_RED - XL_SH, R, ldr, n, k, entry, eflag, coef, D, ldd,
                          Dnext);
 }
 
@@ -2487,7 +2502,7 @@ static size_t exact_base_doubles(int n) {
 size_t ksvd_exact_link_bytes(int K, int64_t nnz) {
     return (size_t)XL_SH * 4096 * sizeof(float) +
            ((((size_t)K + 3) & ~(size_t)3) + (((size_t)2 * K + 3) & ~(size_t)3)) * sizeof(int32_t) +
-           (size_t)nnz * (sizeof(int2) + sizeof(int32_t)) + (((size_t)nnz + 15) & ~(size_t)15);
+           (size_t)nnz * (sizeof(int4) + sizeof(int32_t)) + (((size_t)nnz + 15) & ~(size_t)15);
 }
 size_t ksvd_exact_work_doubles(int n) {
     if (n <= 256) return exact_base_doubles(n) + NN_STATE_DOUBLES;
@@ -2897,13 +2912,13 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     if (pipe_env && idx && link && parts > 0 && k <= 16 && nn_cycles < 0) {
         double* Csum = work + (size_t)G64_MAX_PARTS * 4096 / 2;
         float* gpart = reinterpret_cast<float*>(work);
-        // link area: [shared partials XL_SH x 64 x 64 floats | nsh K ints | prev / next used atom 2K ints | shpair nnz int2 |
+        // link area: [shared partials XL_SH x 64 x 64 floats | nsh K ints | prev / next used atom 2K ints | shrec nnz int4 |
         //             plink nnz ints | eflag nnz bytes]
         float* spart = reinterpret_cast<float*>(link);
         int32_t* nsh = reinterpret_cast<int32_t*>(spart + (size_t)XL_SH * 4096);
         int32_t* pn = nsh + (((size_t)K + 3) & ~(size_t)3);
-        int2* shpair = reinterpret_cast<int2*>(pn + (((size_t)2 * K + 3) & ~(size_t)3));
-        int32_t* plink = reinterpret_cast<int32_t*>(shpair + link_nnz);
+        int4* shrec = reinterpret_cast<int4*>(pn + (((size_t)2 * K + 3) & ~(size_t)3));
+        int32_t* plink = reinterpret_cast<int32_t*>(shrec + link_nnz);
         uint8_t* eflag = reinterpret_cast<uint8_t*>(plink + link_nnz);
         std::vector<int32_t> rp((size_t)K + 1), hns((size_t)K);
         // the index size first (its own short synchronisation): the link kernels below write row_ptr[K] entries of the link area
@@ -2915,7 +2930,7 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
         }
         hipLaunchKernelGGL(exact_neighbours_kernel, dim3((unsigned)(K + 255) / 256), dim3(256), 0, stream, K, row_ptr, pn);
         hipLaunchKernelGGL(exact_flag_kernel, dim3(2048), dim3(256), 0, stream, K, k, row_ptr, entry, idx, coef, pn, eflag, plink);
-        hipLaunchKernelGGL(exact_compact_kernel, dim3((unsigned)K), dim3(256), 0, stream, row_ptr, entry, plink, shpair, nsh);
+        hipLaunchKernelGGL(exact_compact_kernel, dim3((unsigned)K), dim3(256), 0, stream, k, row_ptr, entry, plink, coef, shrec, nsh);
         LYS_LAUNCH_CHECK();
         // the second read-back: with the lists' bounds, the shared-row counts become kernel ARGUMENTS of the 2 L launches below
         LYS_CHECK_HIP(hipMemcpyAsync(hns.data(), nsh, hns.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -2937,8 +2952,8 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
             const int pbeg = (p >= 0) ? rp[p] : 0, pend = (p >= 0) ? rp[p + 1] : 0;
             const unsigned ab = (unsigned)std::min<int64_t>(XK1_APPLY_BLOCKS, ((int64_t)(pend - pbeg) + 15) / 16);
             const int nsa = (a >= 0 && p >= 0) ? hns[a] : 0;
-            hipLaunchKernelGGL(exact_k1_kernel, dim3(16u + XL_SH + ab), dim3(256), 0, stream, a, (a >= 0) ? rp[a] : 0,
-                               (a >= 0) ? parts_of(a) : 0, nsa, p, pbeg, pend, R, ldr, n, k, entry, eflag, shpair, coef, D, ldd,
+            hipLaunchKernelGGL(exact_k1_kernel, dim3((unsigned)XK1_RED + XL_SH + ab), dim3(256), 0, stream, a, (a >= 0) ? rp[a] : 0,
+                               (a >= 0) ? parts_of(a) : 0, nsa, p, pbeg, pend, R, ldr, n, k, entry, eflag, shrec, coef, D, ldd,
                                Dnext, gpart, Csum, spart);
             if (a < 0) break;
             const int nx = (t + 1 < L) ? used[t + 1] : -1;

@@ -29,4 +29,7 @@ if e[5] > e[0]:
     print("eig steps (build with -DLYS_EXACT_STEP_STAMPS): " + " | ".join("%.2f" % ((x - e[0]) / 100) for x in e[5:8]))
 if e[14 - 8 + 8 - 8] >= 0 and t[16 + 14] > 0:
     print("eig : mean Lanczos steps %.3f over %d solves" % (t[16 + 13] / t[16 + 14], int(t[16 + 14])))
+if os.environ.get("K1_STAMPS"):
+    print("K1 roles (build with -DLYS_EXACT_K1_STAMPS), in-kernel us of the first workgroup of each: reduce %.2f | shared rows %.2f | apply %.2f"
+          % (e[5] / 100, e[6] / 100, e[7] / 100))
 print("gram: descriptors %.2f | rounds %.2f | end %.2f us | signals in wg0 %d" % ((q[1] - q[0]) / 100, (q[2] - q[0]) / 100, (q[3] - q[0]) / 100, int(q[4])))
