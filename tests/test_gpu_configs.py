@@ -605,6 +605,31 @@ def test_lc_ksvd_classifier_end_to_end(eng):
     assert scores[0][0] > 0.7, scores
 
 
+def test_clock_probe_reports_a_plausible_core_clock(eng):
+    """lys_debug_clock_probe (bench.py's `sclk_mhz`): shader-clock ticks over 100-MHz ticks on an idle GPU and beside an
+    encode -- a number between the chip's idle and boost clocks, and the 100-MHz side close to the requested spin."""
+    import ctypes
+    import torch
+    import bench
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros((2,), dtype=torch.int64, device="cuda")
+    _lib.check(lib.lys_debug_clock_probe(ctypes.c_void_p(buf.data_ptr()), 500,
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "probe")
+    torch.cuda.synchronize()
+    t = buf.cpu().tolist()
+    assert 50000 <= t[1] < 80000, t                      # 500 us of the 100-MHz clock (+ the last sleep)
+    assert 100.0 < 100.0 * t[0] / t[1] < 3000.0, t
+    rs = np.random.RandomState(0)
+    D0 = rs.randn(64, 256)
+    D0 /= np.linalg.norm(D0, axis=0)
+    Xs = eng.signals_to_device(rs.randn(64, 200000))
+    dd = eng.DeviceDictionary.from_host(D0)
+    mhz = bench.probe_sclk(lambda: [eng.bomp_encode(Xs, dd, 5) for _ in range(40)], 2000)
+    assert mhz is not None and 500.0 < mhz < 3000.0, mhz
+    assert lib.lys_debug_clock_probe(ctypes.c_void_p(0), 500, ctypes.c_void_p(0)) != 0
+
+
 # ------------------------------------------------------------------------------------------------ bench launch
 def test_bench_self_launch_two_ranks_gloo():
     """The bare `python bench.py --gpus 2` starts its two ranks itself (gloo lets them share this box's one GPU) and rank 0
