@@ -33,7 +33,7 @@ def one(rs, n, K, k, N, unused, noise):
     return aerr, zerr, same
 
 
-rs = np.random.RandomState(11)
+rs = np.random.RandomState(int(os.environ.get("SOAK_SEED", "11")))
 worst_a = worst_z = 0.0
 ok = True
 for (n, K, k, N) in [(64, 256, 6, 60000), (64, 1024, 10, 200000)]:
@@ -44,7 +44,7 @@ for (n, K, k, N) in [(64, 256, 6, 60000), (64, 1024, 10, 200000)]:
 nr = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 for t in range(nr):
     n = int(rs.randint(4, 65))
-    K = int(rs.randint(2, 200))
+    K = int(rs.randint(1, int(os.environ.get("SOAK_KMAX", "200"))))
     k = int(rs.randint(1, min(16, K) + 1))
     N = int(rs.randint(50, 30000))
     unused = tuple(sorted(set(int(a) for a in rs.choice(K, rs.randint(0, max(1, K // 4)), replace=False)))) if K > k + 2 else ()
