@@ -1688,8 +1688,8 @@ __device__ __forceinline__ double wave_sum_d(double x) {
 // threads only share the load of C (sum of the fp32 partials in fp64), then waves 1..3 retire.
 constexpr int E64_QS = 65;  // row stride of the Krylov basis (doubles): lanes reading different rows hit different banks
 
-__device__ int g_eig_mmin = 3;  // first Lanczos step the Ritz test runs at (LYS_EIG_MMIN)
-__device__ int g_eig_pre = 2;  // power steps before the Lanczos recurrence of the single-wave solver (LYS_EIG_PRE)
+__device__ int g_eig_mmin = 2;  // first Lanczos step the Ritz test runs at (LYS_EIG_MMIN)
+__device__ int g_eig_pre = 4;  // power steps before the Lanczos recurrence of the single-wave solver (LYS_EIG_PRE)
 constexpr int XK1_RED = 64;            // workgroups of K1's partial-sum role (64 matrix elements each)
 constexpr int XK1_APPLY_BLOCKS = 1024;  // most apply workgroups of a K1 launch (16 entries each per pass)
 constexpr int XL_SH = 4;  // workgroups (= fp32 partials) of the shared-row Gram part of the pipelined sweep below
@@ -2902,10 +2902,11 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
         const char* e = getenv("LYS_EIG_PRE");
         // default 2 (configs[1], same box: 0 / 1 / 2 / 3 pre-steps -> 4.7 / 4.0 / 3.0 / 3.0 Lanczos steps per solve, sweep
         // 24.0 / 24.8 / 22.6-23.3 / 23.8 ms; with the Ritz test from m = 2: 3 / 4 / 5 pre-steps -> 22.9 / 22.6 / 23.3 ms)
-        const int pre = (e && atoi(e) >= 0 && atoi(e) <= 8) ? atoi(e) : 2;
+        // (after the K1 rework, with the Ritz test from m = 2: 2 pre-steps / test from 3 -> 21.3 ms, 3 / 2 -> 21.3, 4 / 2 -> 20.8: default)
+        const int pre = (e && atoi(e) >= 0 && atoi(e) <= 8) ? atoi(e) : 4;
         LYS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eig_pre), &pre, sizeof(int)));
         const char* e2 = getenv("LYS_EIG_MMIN");
-        const int mmin = (e2 && atoi(e2) >= 2 && atoi(e2) <= 8) ? atoi(e2) : 3;
+        const int mmin = (e2 && atoi(e2) >= 2 && atoi(e2) <= 8) ? atoi(e2) : 2;
         LYS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eig_mmin), &mmin, sizeof(int)));
         pre_set[dev] = 1;
     }
