@@ -83,9 +83,11 @@ int ksvd_exact_gram(int, const float*, int64_t, int, int, const int32_t*, const 
 int ksvd_exact_update(int, float*, int64_t, int, int, const int32_t*, const int32_t*, const int32_t*, float*, const double*,
                       const float*, float*, hipStream_t);
 int lasso_from_alpha0(const float*, const float*, int, int, float, float, int, int, int64_t, int32_t*, float*, int32_t*,
-                      int32_t*, hipStream_t, int warm = 0);
+                      int32_t*, hipStream_t, int warm = 0, int32_t* rounds = nullptr);
 int lasso_lars_from_alpha0(const float*, const float*, int, int, float, int, int, int64_t, int32_t*, float*, int32_t*,
-                           int32_t*, hipStream_t);
+                           int32_t*, hipStream_t, const int32_t* only = nullptr);
+int lasso_ws_from_alpha0(const float*, const float*, int, int, float, float, int, int, int64_t, int32_t*, float*, int32_t*,
+                         int32_t*, int32_t*, hipStream_t);
 int ksvd_sweep(float*, int64_t, int, int, int, const int32_t*, const int32_t*, float*, double*, float*, float*,
                hipStream_t);
 int ksvd_sweep_fused(float*, int64_t, int, int, int, const int32_t*, const int32_t*, const int32_t*, float*, double*,
@@ -539,11 +541,19 @@ int lys_lasso_lars_encode(const float* X, int64_t ldx, const float* D_packed, co
         const int64_t cnt = (N - s0 < rows) ? N - s0 : rows;
         int rc;
         if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, st))) return rc;
+        // round 5: for K >= 1024 the working-set coordinate descent solves the signals whose support stays well below n
+        // (every signal at configs[3]'s shape) in a fraction of the homotopy's Gram-row traffic; the homotopy and its
+        // polish then run for the signals it flagged only (steps == its marker), everyone else leaves those launches at once
+        const int pre = lasso_ws_from_alpha0(a0, G, Kp, K, lambda, tol, max_steps, kcap, cnt, idx + s0 * kcap, coef + s0 * kcap,
+                                             nnz + s0, steps ? steps + s0 : nullptr,
+                                             breakpoints ? breakpoints + s0 : nullptr, st);
+        if (pre < 0) return pre;
         if ((rc = lasso_lars_from_alpha0(a0, G, Kp, K, lambda, max_breakpoints, kcap, cnt, idx + s0 * kcap,
-                                         coef + s0 * kcap, nnz + s0, breakpoints ? breakpoints + s0 : nullptr, st)))
+                                         coef + s0 * kcap, nnz + s0, breakpoints ? breakpoints + s0 : nullptr, st,
+                                         pre ? steps + s0 : nullptr)))
             return rc;
         if ((rc = lasso_from_alpha0(a0, G, Kp, K, lambda, tol, max_steps, kcap, cnt, idx + s0 * kcap, coef + s0 * kcap,
-                                    nnz + s0, steps ? steps + s0 : nullptr, st, 1)))
+                                    nnz + s0, steps ? steps + s0 : nullptr, st, pre ? 2 : 1)))
             return rc;
     }
     return LYS_OK;

@@ -655,8 +655,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_bf16x3_kernel(const flo
     constexpr int NT = 64 * WAVES;
     constexpr int NJ = (WAVES == 4) ? 2 : 1;        // 32-atom tiles per wave
     constexpr int A_IT = 1024 / NT, B_IT = 1536 / NT;
-    __shared__ __attribute__((aligned(16))) unsigned short As[3 * 128 * GB_LDP];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * 128 * GB_LDP];
+    // ONE array: the epilogue's wave-private transposition regions (WAVES x 4 KB) start at its base and run past the A
+    // planes into the B planes -- both are dead after the loop's last barrier
+    constexpr int GB_PLANES = 3 * 128 * GB_LDP;     // bf16 elements of one operand's three planes
+    __shared__ __attribute__((aligned(16))) unsigned short S3[2 * GB_PLANES];
+    static_assert(WAVES * 4096 <= 2 * GB_PLANES * (int)sizeof(unsigned short), "epilogue transposition regions exceed the staging LDS");
+    unsigned short* const As = S3;
+    unsigned short* const Bs = S3 + GB_PLANES;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = (WAVES == 4) ? (wid >> 1) : (wid >> 2), wn = (WAVES == 4) ? (wid & 1) : (wid & 3);
     const int n_ct = Nc / 128;
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_bf16x3_kernel(const flo
     // epilogue: every 32 x 32 accumulator tile through a wave-private 4-KB LDS transposition (the staging buffers are free:
     // the loop ended with a barrier), then four dwordx4 row stores of 8 rows x 128 B instead of 16 dword stores -- the dword
     // form is bound by the number of store instructions the texture addresser takes (see alpha0_n64_bf16x3_kernel)
-    float* Tw = reinterpret_cast<float*>(As) + wid * 1024;   // 8 waves x 4 KB <= the 30 KB of As
+    float* Tw = reinterpret_cast<float*>(S3) + wid * 1024;   // WAVES x 4 KB inside the 60 KB of S3 (static_assert above)
     const int t_wr = (4 * h) * 32 + l31, t_rd = (lane >> 3) * 32 + (lane & 7) * 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)

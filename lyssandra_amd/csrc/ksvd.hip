@@ -368,30 +368,61 @@ __global__ __launch_bounds__(64) void bksvd_index_kernel(const int32_t* __restri
     }
 }
 
-// Exclusive scan over the chunks, in place, of the chunk-major table counts[T][K] for 64 consecutive atoms per workgroup
-// (1024 threads = 16 chunk segments x 64 atoms: every access is a coalesced 256-byte run), atom totals out.
-__global__ __launch_bounds__(1024) void csr_scan_chunks_kernel(int32_t* __restrict__ counts, int T, int K,
-                                                              int32_t* __restrict__ totals) {
-    __shared__ int s_seg[16][64];
-    const int a = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
-    const int per = (T + 15) / 16;
-    const int c0 = seg * per, c1 = (c0 + per < T) ? c0 + per : T;
+// Exclusive scan over the chunks, in place, of the chunk-major table counts[T][K], atom totals out.  Three launches so that
+// the 2 x 4 K T bytes of the table (64 MB at config 2) move through 256 workgroups instead of K / 64 = 16 (round 4: one
+// launch of 16 workgroups, 100 us of the 0.43-ms index build):
+//   csr_scan_partial_kernel  grid (K / 64, 16): workgroup (g, z) = 64 atoms x chunk range z; its 16 sub-segments' sums
+//   csr_scan_bases_kernel    the 256 sub-segment sums of every atom -> exclusive prefix in place, atom totals out
+//   csr_scan_apply_kernel    same grid as the first: the sub-segment rewritten as running offsets from its base
+// (1024 threads = 16 sub-segments x 64 atoms: every access is a coalesced 256-byte run.)
+constexpr int CSR_ZSEG = 16;   // chunk ranges (gridDim.y)
+constexpr int CSR_SSEG = 16;   // sub-segments per range (threadIdx / 64)
+__device__ __forceinline__ void csr_scan_range(int T, int z, int seg, int& c0, int& c1) {
+    const int per = (T + CSR_ZSEG * CSR_SSEG - 1) / (CSR_ZSEG * CSR_SSEG);
+    c0 = (z * CSR_SSEG + seg) * per;
+    c1 = (c0 + per < T) ? c0 + per : T;
+    if (c0 > T) c0 = T;
+}
+__global__ __launch_bounds__(1024) void csr_scan_partial_kernel(const int32_t* __restrict__ counts, int T, int K,
+                                                                int32_t* __restrict__ part) {
+    const int a = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6, z = blockIdx.y;
+    int c0, c1;
+    csr_scan_range(T, z, seg, c0, c1);
     int sum = 0;
     if (a < K) {
 #pragma unroll 8
         for (int c = c0; c < c1; ++c) sum += counts[(int64_t)c * K + a];
+        part[(int64_t)(z * CSR_SSEG + seg) * K + a] = sum;
     }
-    s_seg[seg][threadIdx.x & 63] = sum;
-    __syncthreads();
+}
+__global__ __launch_bounds__(256) void csr_scan_bases_kernel(int32_t* __restrict__ part, int K, int32_t* __restrict__ totals) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= K) return;
     int run = 0;
-    for (int q = 0; q < seg; ++q) run += s_seg[q][threadIdx.x & 63];
-    if (a < K) {
-        for (int c = c0; c < c1; ++c) {
-            const int v = counts[(int64_t)c * K + a];
-            counts[(int64_t)c * K + a] = run;
-            run += v;
+#pragma unroll 8
+    for (int s = 0; s < CSR_ZSEG * CSR_SSEG; ++s) {
+        const int v = part[(int64_t)s * K + a];
+        part[(int64_t)s * K + a] = run;
+        run += v;
+    }
+    totals[a] = run;
+}
+__global__ __launch_bounds__(1024) void csr_scan_apply_kernel(int32_t* __restrict__ counts, int T, int K,
+                                                              const int32_t* __restrict__ part) {
+    const int a = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6, z = blockIdx.y;
+    int c0, c1;
+    csr_scan_range(T, z, seg, c0, c1);
+    if (a >= K) return;
+    int run = part[(int64_t)(z * CSR_SSEG + seg) * K + a];
+    for (int c = c0; c < c1; c += 8) {   // eight loads in flight, then the dependent running sum
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (c + u < c1) ? counts[(int64_t)(c + u) * K + a] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c + u < c1) counts[(int64_t)(c + u) * K + a] = run;
+            run += v[u];
         }
-        if (seg == 15) totals[a] = run;
     }
 }
 
@@ -437,7 +468,7 @@ size_t csr_workspace_bytes(int K, int k, int64_t N) {
     int T;
     int64_t S;
     csr_plan(N, K, T, S);
-    return ((size_t)K * (size_t)T + (size_t)K) * sizeof(int32_t);
+    return ((size_t)K * (size_t)T + (size_t)K + (size_t)K * CSR_ZSEG * CSR_SSEG) * sizeof(int32_t);   // counts, totals, scan partials
 }
 
 // logb == 0: entry = int32 signal*k + slot (per-atom kernels, online DL).  logb = 2 / 3 (block sweep, k <= 64): `entry`
@@ -461,7 +492,7 @@ int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K
     csr_plan(N, K, T, S);
     const int B = emeta ? (1 << logb) : 1;
     const size_t nkey = emeta ? ((size_t)((K + B - 1) / B) << B) : 0;
-    const size_t need = ((size_t)K * T + K) * sizeof(int32_t) + (emeta ? (nkey + 1) * sizeof(int32_t) : 0);
+    const size_t need = csr_workspace_bytes(K, k, N) + (emeta ? (nkey + 1) * sizeof(int32_t) : 0);
     if (ws_bytes < need) {
         set_error("csr_by_atom: workspace %zu < %zu", ws_bytes, need);
         return LYS_EWORKSPACE;
@@ -476,7 +507,8 @@ int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K
     }
     int32_t* counts = static_cast<int32_t*>(ws);
     int32_t* totals = counts + (size_t)K * T;
-    int32_t* cg_cur = emeta ? totals + K : nullptr;
+    int32_t* part = totals + K;                                  // [CSR_ZSEG * CSR_SSEG][K] sub-segment sums of the chunk scan
+    int32_t* cg_cur = emeta ? part + (size_t)K * CSR_ZSEG * CSR_SSEG : nullptr;
     const size_t lds = (size_t)K * sizeof(int);
     if (emeta) LYS_CHECK_HIP(hipMemsetAsync(cg_cur, 0, (nkey + 1) * sizeof(int32_t), stream));
     const bool quad = emeta && k <= 16;  // block-sweep index with four signals per wave instruction
@@ -488,7 +520,11 @@ int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K
                            counts, row_ptr, entry, 0, (int32_t*)nullptr, (float*)nullptr, emeta ? logb : 0, cg_cur,
                            (int32_t*)nullptr);
     LYS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(csr_scan_chunks_kernel, dim3((K + 63) / 64), dim3(1024), 0, stream, counts, T, K, totals);
+    hipLaunchKernelGGL(csr_scan_partial_kernel, dim3((K + 63) / 64, CSR_ZSEG), dim3(1024), 0, stream, counts, T, K, part);
+    LYS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_scan_bases_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, part, K, totals);
+    LYS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_scan_apply_kernel, dim3((K + 63) / 64, CSR_ZSEG), dim3(1024), 0, stream, counts, T, K, part);
     LYS_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_scan_totals_kernel, dim3(1), dim3(1024), 0, stream, totals, K, row_ptr);
     LYS_LAUNCH_CHECK();

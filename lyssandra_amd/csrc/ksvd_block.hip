@@ -1329,11 +1329,17 @@ static int launch_step(int sl, int mode, int c, int nb, int K, float* R, int64_t
                        hipStream_t stream) {
 #define BK_A mode, c, nb, K, R, ldr, n, k, ix, idx, coef, D, Dnext, bbuf, lay, stream
     const bool full = (n == 64 * FB);
+#ifdef LYS_BK_DEV   // development builds (tools/bk_dev_build.sh): only the config-2 instantiation, compiled in seconds
+    if (sl == 1 && full) return launch_step_full<FB, LOGB, 1, TEAMS, true>(BK_A);
+    set_error("LYS_BK_DEV build: only k <= 16 with n a multiple of 64");
+    return LYS_ENOSUP;
+#else
     switch (sl) {
         case 1: return full ? launch_step_full<FB, LOGB, 1, TEAMS, true>(BK_A) : launch_step_full<FB, LOGB, 1, TEAMS, false>(BK_A);
         case 2: return full ? launch_step_full<FB, LOGB, 2, TEAMS, true>(BK_A) : launch_step_full<FB, LOGB, 2, TEAMS, false>(BK_A);
         default: return full ? launch_step_full<FB, LOGB, 4, TEAMS, true>(BK_A) : launch_step_full<FB, LOGB, 4, TEAMS, false>(BK_A);
     }
+#endif
 #undef BK_A
 }
 
@@ -1356,9 +1362,15 @@ int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int 
     const int sl = (k <= 16) ? 1 : (k <= 32) ? 2 : 4;
     const int fb = (n <= 64) ? 1 : (n <= 128) ? 2 : 4;
 #define BK_ARGS sl, mode, c, nb, K, R, ldr, n, k, ix, idx, coef, D, Dnext, bbuf, lay, stream
+#ifdef LYS_BK_DEV
+    if (fb == 1 && B == 8) return launch_step<1, 3, 64>(BK_ARGS);
+    set_error("LYS_BK_DEV build: only B = 8, n <= 64");
+    return LYS_ENOSUP;
+#else
     if (fb == 1) return (B == 8) ? launch_step<1, 3, 64>(BK_ARGS) : launch_step<1, 2, 64>(BK_ARGS);
     if (fb == 2) return (B == 8) ? launch_step<2, 3, 64>(BK_ARGS) : launch_step<2, 2, 64>(BK_ARGS);
     return launch_step<4, 2, 32>(BK_ARGS);
+#endif
 #undef BK_ARGS
 }
 

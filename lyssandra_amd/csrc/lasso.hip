@@ -8,6 +8,8 @@
 //     a_j += delta;  c -= delta * G[j, :]      (one Gram row per step, like one Batch-OMP step)
 // until the largest change is below tol * max|D'x| (then every KKT condition holds to that accuracy).
 // One workgroup per signal, 16 atoms per lane (fewer for small dictionaries): a, c, diag(G) stay in registers.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace lys {
@@ -59,6 +61,7 @@ __device__ __forceinline__ Best wave_best(Best x) {
 }
 
 constexpr int LASSO_MAX_WAVES = 16;
+constexpr int LWS_RETRY = -0x40000000;  // steps marker: the working-set kernel hands this signal to the plain kernel
 
 template <int R>
 __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_cd_kernel(const float* __restrict__ alpha0,
@@ -75,6 +78,8 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_cd_kernel(const fl
     __shared__ int s_e[LASSO_MAX_WAVES], s_cnt[LASSO_MAX_WAVES];
     const int64_t sig = blockIdx.x;
     if (sig >= N) return;
+    // warm == 2: the fallback behind lasso_ws_kernel -- only the signals it flagged (steps == LWS_RETRY) run, warm-started
+    if (warm == 2 && steps_out[sig] != LWS_RETRY) return;
     const int t = threadIdx.x, T = blockDim.x, W = T >> 6, wid = t >> 6, lane = t & 63;
     float c[R], a[R], gd[R], ginv[R];
     load_vec<R>(alpha0 + sig * Kp, t, T, c);
@@ -223,6 +228,315 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_cd_kernel(const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// Working-set coordinate descent (round 5) for large dictionaries (K >= 1024): the same minimiser, far fewer Gram rows.
+//
+// The kernels above and below stream FULL Gram rows (4 K bytes each): plain coordinate descent one per step (hundreds when
+// the support approaches n), the LARS homotopy |A| per breakpoint (~465 per signal at K = 8192, lambda = 0.2: 15 MB per
+// signal, 498 GB per 32 768-signal mini-batch -- the coder ran at the HBM roofline of THAT traffic, 15.5x the one row per
+// non-zero the problem needs; fp32 G = 268 MB does not fit the 256 MB Infinity Cache).  But only the correlations of the
+// atoms that can become active matter while the solution is being found.  So (the working-set / active-set strategy of
+// glmnet and sklearn's coordinate descent, here on the precomputed Gram matrix):
+//   round r:  c = D'x - G a from scratch          |supp a| full rows (round 0: none, a = 0)
+//             violators = atoms outside the working set with |c_j| > lambda (+ slack); none -> DONE: every KKT condition
+//                         was just verified on fresh fp32 correlations
+//             add them (the largest first when there is no room for all) and gather their Gram ENTRIES against the
+//             working set into LDS (scattered 4-byte reads, <= 128 x 128 packed triangular)
+//             solve the lasso restricted to the working set by greedy coordinate descent ENTIRELY in LDS / registers of
+//             wave 0 (the stopping rule of lasso_cd_kernel: largest coordinate change <= tol * max|D'x|)
+// Typical at configs[3]'s shape: 2-3 rounds, i.e. 30-60 full rows per signal instead of 465.  The working set only
+// grows (zero coefficients keep their slot) until it is full; then it is compacted to the non-zeros.  A signal that does
+// not finish (rounds / steps exhausted, more than LWS_M candidates that matter) is flagged LWS_RETRY and taken by the plain
+// kernel (warm == 2) in a second launch that every other workgroup leaves at once.
+// ---------------------------------------------------------------------------------------------
+constexpr int LWS_M = 128;                          // working-set capacity (a lasso minimiser has at most min(n, K) non-zeros)
+constexpr int LWS_TRI = LWS_M * (LWS_M + 1) / 2;    // packed lower triangle of G restricted to the working set
+constexpr int LWS_ROUNDS = 24;
+__device__ __forceinline__ int lws_tri(int i, int q) {
+    const int hi = (i > q) ? i : q, lo = (i > q) ? q : i;
+    return hi * (hi + 1) / 2 + lo;
+}
+
+template <int R>
+__global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_ws_kernel(const float* __restrict__ alpha0,
+                                                                         const float* __restrict__ G, int Kp, int K,
+                                                                         float lambda, float tol_rel, int max_steps,
+                                                                         int kcap, int64_t N, int32_t* __restrict__ idx,
+                                                                         float* __restrict__ coef,
+                                                                         int32_t* __restrict__ nnz,
+                                                                         int32_t* __restrict__ steps_out,
+                                                                         int32_t* __restrict__ rounds_out) {
+    using L = LLay<R>;
+    extern __shared__ float lws[];  // Gtri[LWS_TRI], then the atom -> working-set position map (Kp shorts)
+    float* Gtri = lws;
+    short* s_pos = reinterpret_cast<short*>(lws + LWS_TRI);
+    __shared__ int s_act[LWS_M];
+    __shared__ float s_a[LWS_M], s_c[LWS_M];
+    __shared__ float s_redf[LASSO_MAX_WAVES];
+    __shared__ int s_redi[LASSO_MAX_WAVES];
+    __shared__ int s_m, s_steps, s_state;
+    const int64_t sig = blockIdx.x;
+    if (sig >= N) return;
+    const int t = threadIdx.x, T = blockDim.x, W = T >> 6, wid = t >> 6, lane = t & 63;
+    auto block_max = [&](float x) -> float {  // x >= 0
+        x = wave_max_f(x);
+        if (W > 1) {
+            if (lane == 0) s_redf[wid] = x;
+            __syncthreads();
+            for (int w = 0; w < W; ++w) x = fmaxf(x, s_redf[w]);
+            __syncthreads();
+        }
+        return x;
+    };
+    // sum over the workgroup, and the exclusive prefix of this THREAD's value (lane order inside a wave, then wave order)
+    auto block_scan = [&](int x, int& total) -> int {
+        int incl = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        int base = 0;
+        total = __shfl(incl, 63, 64);
+        if (W > 1) {
+            if (lane == 63) s_redi[wid] = incl;
+            __syncthreads();
+            total = 0;
+            for (int w = 0; w < W; ++w) {
+                if (w < wid) base += s_redi[w];
+                total += s_redi[w];
+            }
+            __syncthreads();
+        }
+        return base + incl - x;
+    };
+    auto block_sum = [&](int x) -> int {
+        int tot;
+        (void)block_scan(x, tot);
+        return tot;
+    };
+    float c[R];
+    load_vec<R>(alpha0 + sig * Kp, t, T, c);
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) amax = fmaxf(amax, (L::elem(r, t, T) < K) ? fabsf(c[r]) : 0.f);
+    amax = block_max(amax);
+    const float tol_abs = tol_rel * amax;
+    for (int i = t; i < Kp; i += T) s_pos[i] = (short)-1;
+    if (t == 0) {
+        s_m = 0;
+        s_steps = 0;
+        s_state = 0;
+    }
+    __syncthreads();
+    int m = 0, rounds = 0;
+    bool done = false;
+    for (int round = 0; round < LWS_ROUNDS; ++round) {
+        if (round > 0) {  // fresh correlations: c = D'x - sum_i a_i G[act_i, :]
+            load_vec<R>(alpha0 + sig * Kp, t, T, c);
+            for (int i = 0; i < m; ++i) {
+                const float ai = s_a[i];
+                if (ai == 0.f) continue;  // uniform
+                float g[R];
+                load_vec<R>(G + (int64_t)s_act[i] * Kp, t, T, g);
+#pragma unroll
+                for (int r = 0; r < R; ++r) c[r] = fmaf(-ai, g[r], c[r]);
+            }
+        }
+        // violators: atoms outside the working set above lambda (slack: the stopping tolerance of the solve)
+        const float thr0 = lambda + tol_abs;
+        unsigned viol = 0;
+        float vmax = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = L::elem(r, t, T);
+            const float v = fabsf(c[r]);
+            if (e < K && v > thr0 && s_pos[e] < 0) {
+                viol |= 1u << r;
+                vmax = fmaxf(vmax, v);
+            }
+        }
+        int tot = block_sum(__popc(viol));
+        if (tot == 0) {  // uniform: the working set's solution satisfies every KKT condition
+            done = true;
+            break;
+        }
+        ++rounds;
+        if (LWS_M - m < ((tot < 16) ? tot : 16)) {
+            // no room: keep only the non-zeros (wave 0 compacts the list; the Gram entries are gathered again below)
+            if (wid == 0) {
+                const int i0 = lane, i1 = lane + 64;
+                const int e0 = (i0 < m) ? s_act[i0] : -1, e1 = (i1 < m) ? s_act[i1] : -1;
+                const float a0 = (i0 < m) ? s_a[i0] : 0.f, a1 = (i1 < m) ? s_a[i1] : 0.f;
+                const unsigned long long b0 = __ballot(a0 != 0.f), b1 = __ballot(a1 != 0.f);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int p0 = __popcll(b0 & lt), p1 = __popcll(b0) + __popcll(b1 & lt);
+                __builtin_amdgcn_wave_barrier();
+                if (e0 >= 0 && a0 == 0.f) s_pos[e0] = (short)-1;
+                if (e1 >= 0 && a1 == 0.f) s_pos[e1] = (short)-1;
+                if (a0 != 0.f) {
+                    s_act[p0] = e0;
+                    s_a[p0] = a0;
+                    s_pos[e0] = (short)p0;
+                }
+                if (a1 != 0.f) {
+                    s_act[p1] = e1;
+                    s_a[p1] = a1;
+                    s_pos[e1] = (short)p1;
+                }
+                if (lane == 0) s_m = __popcll(b0) + __popcll(b1);
+            }
+            __syncthreads();
+            m = s_m;
+            if (t == 0) s_state = 1;  // every Gram entry is gathered again
+            __syncthreads();
+            if (LWS_M - m < 1) break;  // the non-zeros alone fill the working set: the plain kernel takes this signal
+            // dropped atoms are candidates again
+            viol = 0;
+            vmax = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int e = L::elem(r, t, T);
+                const float v = fabsf(c[r]);
+                if (e < K && v > thr0 && s_pos[e] < 0) {
+                    viol |= 1u << r;
+                    vmax = fmaxf(vmax, v);
+                }
+            }
+            tot = block_sum(__popc(viol));
+        }
+        const int gather_from = s_state ? 0 : m;
+        // when the candidates outnumber the room, the largest first: bisect a threshold (the others come back next round)
+        const int room = LWS_M - m;
+        const int target = (round == 0 && room > 96) ? 96 : room;
+        float lo = thr0;
+        if (tot > target) {
+            float hi = block_max(vmax);
+            for (int it = 0; it < 24; ++it) {  // uniform
+                const float mid = 0.5f * (lo + hi);
+                int cnt = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) cnt += (((viol >> r) & 1u) && fabsf(c[r]) > mid) ? 1 : 0;
+                const int tc = block_sum(cnt);
+                if (tc > target) lo = mid;
+                else if (tc == 0) hi = mid;
+                else {
+                    lo = mid;
+                    break;
+                }
+            }
+        }
+        unsigned sel = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) sel |= (((viol >> r) & 1u) && fabsf(c[r]) > lo) ? (1u << r) : 0u;
+        int nsel;
+        int pos = m + block_scan(__popc(sel), nsel);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((sel >> r) & 1u) {
+                if (pos < LWS_M) {
+                    const int e = L::elem(r, t, T);
+                    s_act[pos] = e;
+                    s_a[pos] = 0.f;
+                    s_pos[e] = (short)pos;
+                }
+                ++pos;
+            }
+        const int m_new = (m + nsel < LWS_M) ? m + nsel : LWS_M;
+        __syncthreads();
+        // Gram entries of the new positions against everything before them (packed triangle, flat over the pairs)
+        {
+            const int f0 = gather_from * (gather_from + 1) / 2, f1 = m_new * (m_new + 1) / 2;
+            for (int f = f0 + t; f < f1; f += T) {
+                int q = (int)((sqrtf(8.f * (float)f + 1.f) - 1.f) * 0.5f);
+                while (q * (q + 1) / 2 > f) --q;
+                while ((q + 1) * (q + 2) / 2 <= f) ++q;
+                const int i = f - q * (q + 1) / 2;
+                Gtri[f] = G[(int64_t)s_act[q] * Kp + s_act[i]];
+            }
+        }
+        // the members' fresh correlations
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = L::elem(r, t, T);
+            if (e < K) {
+                const int p = s_pos[e];
+                if (p >= 0) s_c[p] = c[r];
+            }
+        }
+        if (t == 0) s_state = 0;
+        __syncthreads();
+        m = m_new;
+        // ---- the lasso restricted to the working set: greedy coordinate descent on wave 0, two coordinates per lane
+        if (wid == 0) {
+            const int i0 = lane, i1 = lane + 64;
+            float a0 = (i0 < m) ? s_a[i0] : 0.f, a1 = (i1 < m) ? s_a[i1] : 0.f;
+            float c0 = (i0 < m) ? s_c[i0] : 0.f, c1 = (i1 < m) ? s_c[i1] : 0.f;
+            const float gd0 = (i0 < m) ? Gtri[lws_tri(i0, i0)] : 0.f, gd1 = (i1 < m) ? Gtri[lws_tri(i1, i1)] : 0.f;
+            const float gi0 = (gd0 > 0.f) ? 1.f / gd0 : 0.f, gi1 = (gd1 > 0.f) ? 1.f / gd1 : 0.f;
+            int steps = s_steps;
+            while (steps < max_steps) {
+                const float v0 = fmaf(gd0, a0, c0), v1 = fmaf(gd1, a1, c1);
+                const float d0 = copysignf(fmaxf(fabsf(v0) - lambda, 0.f), v0) * gi0 - a0;
+                const float d1 = copysignf(fmaxf(fabsf(v1) - lambda, 0.f), v1) * gi1 - a1;
+                const bool second = fabsf(d1) > fabsf(d0);  // ties -> the lower position
+                const float sc = second ? fabsf(d1) : fabsf(d0);
+                const float smax = wave_max_f(sc);
+                if (!(smax > tol_abs)) break;
+                const unsigned long long bal = __ballot(sc == smax);
+                const int wl = __ffsll((unsigned long long)bal) - 1;
+                const int e = __builtin_amdgcn_readlane(second ? i1 : i0, wl);
+                const float dl = readlane_f(second ? d1 : d0, wl);
+                c0 = fmaf(-dl, Gtri[lws_tri(i0 < m ? i0 : 0, e)], c0);
+                c1 = fmaf(-dl, Gtri[lws_tri(i1 < m ? i1 : 0, e)], c1);
+                a0 += (i0 == e) ? dl : 0.f;
+                a1 += (i1 == e) ? dl : 0.f;
+                ++steps;
+            }
+            // snap: a coefficient whose own update target is exactly zero sits below the stopping tolerance (see lasso_cd_kernel)
+            if (a0 != 0.f && !(fabsf(fmaf(gd0, a0, c0)) > lambda)) a0 = 0.f;
+            if (a1 != 0.f && !(fabsf(fmaf(gd1, a1, c1)) > lambda)) a1 = 0.f;
+            if (i0 < m) s_a[i0] = a0;
+            if (i1 < m) s_a[i1] = a1;
+            if (lane == 0) s_steps = steps;
+        }
+        __syncthreads();
+        if (s_steps >= max_steps) break;  // uniform
+    }
+    // ---- output: the non-zeros in working-set order; a signal that did not finish goes to the plain kernel
+    int total = 0;
+    if (wid == 0) {
+        const int i0 = lane, i1 = lane + 64;
+        const float a0 = (i0 < m) ? s_a[i0] : 0.f, a1 = (i1 < m) ? s_a[i1] : 0.f;
+        const unsigned long long b0 = __ballot(a0 != 0.f), b1 = __ballot(a1 != 0.f);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int p0 = __popcll(b0 & lt), p1 = __popcll(b0) + __popcll(b1 & lt);
+        total = __popcll(b0) + __popcll(b1);
+        if (a0 != 0.f && p0 < kcap) {
+            idx[sig * kcap + p0] = s_act[i0];
+            coef[sig * kcap + p0] = a0;
+        }
+        if (a1 != 0.f && p1 < kcap) {
+            idx[sig * kcap + p1] = s_act[i1];
+            coef[sig * kcap + p1] = a1;
+        }
+        if (lane == 0) s_m = total;
+    }
+    __syncthreads();
+    total = s_m;
+    for (int p = total + t; p < kcap; p += T) {  // unused slots: (-1, 0) like the other encoders
+        idx[sig * kcap + p] = -1;
+        coef[sig * kcap + p] = 0.f;
+    }
+    if (t == 0) {
+        nnz[sig] = total < kcap ? total : kcap;
+        const int steps = s_steps;
+        // negative: support truncated to kcap (like lasso_cd_kernel); LWS_RETRY: not finished here
+        steps_out[sig] = !done ? LWS_RETRY : (total > kcap) ? -(steps + 1) : steps;
+        if (rounds_out) rounds_out[sig] = -rounds;  // in the breakpoint array of the LARS entry: <= 0 = solved here, in that many rounds
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LARS-lasso homotopy (the algorithm family of spams.lasso(mode=2), lyssa/sparse_coding.py:487-509), on the Gram
 // matrix, one workgroup per signal in the register layout of the kernel above.  With c = D'x - G a and the active set
 // A (signs s), the solution path is piecewise linear in the common correlation level C = |c_A|:
@@ -262,8 +576,11 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_lars_kernel(const 
                                                                            int64_t N, int32_t* __restrict__ idx,
                                                                            float* __restrict__ coef,
                                                                            int32_t* __restrict__ nnz,
-                                                                           int32_t* __restrict__ breaks_out) {
+                                                                           int32_t* __restrict__ breaks_out,
+                                                                           const int32_t* __restrict__ only) {
     using L = LLay<R>;
+    // only != null: the homotopy runs for the signals the working-set pass flagged (only[sig] == LWS_RETRY) and nobody else
+    if (only && blockIdx.x < N && only[blockIdx.x] != LWS_RETRY) return;
     extern __shared__ float lsm[];  // Lc[cap][cap]
     __shared__ float s_a[LARS_MAX], s_d[LARS_MAX], s_s[LARS_MAX], s_y[LARS_MAX], s_g[LARS_MAX];
     __shared__ int s_act[LARS_MAX];
@@ -458,7 +775,8 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_lars_kernel(const 
 }
 
 int lasso_lars_from_alpha0(const float* alpha0, const float* G, int Kp, int K, float lambda, int max_break, int kcap,
-                           int64_t N, int32_t* idx, float* coef, int32_t* nnz, int32_t* breaks, hipStream_t stream) {
+                           int64_t N, int32_t* idx, float* coef, int32_t* nnz, int32_t* breaks, hipStream_t stream,
+                           const int32_t* only) {
     if (N <= 0) return LYS_OK;
     if (N > 0x7fffffffLL) {
         set_error("lasso(lars): too many signals in one tile");
@@ -479,7 +797,7 @@ int lasso_lars_from_alpha0(const float* alpha0, const float* G, int Kp, int K, f
             attr_set[dev][SLOT] = true;                                                                                 \
         }                                                                                                               \
         hipLaunchKernelGGL(lasso_lars_kernel<RR>, grid, dim3(TT), lds, stream, alpha0, G, Kp, K, lambda, max_break,    \
-                           kcap, N, idx, coef, nnz, breaks);                                                            \
+                           kcap, N, idx, coef, nnz, breaks, only);                                                      \
     } while (0)
     if (Kp == 64) LYS_LARS(1, 64, 0);
     else if (Kp == 128) LYS_LARS(2, 64, 1);
@@ -495,15 +813,43 @@ int lasso_lars_from_alpha0(const float* alpha0, const float* G, int Kp, int K, f
     return LYS_OK;
 }
 
+// The working-set pass alone (see lasso_ws_kernel): 1 = launched (signals it could not finish carry steps == LWS_RETRY), 0 = not
+// applicable (K < 1024, no step array to flag in, or LYS_LASSO_WS=0), < 0 = error.
+int lasso_ws_from_alpha0(const float* alpha0, const float* G, int Kp, int K, float lambda, float tol, int max_steps, int kcap,
+                         int64_t N, int32_t* idx, float* coef, int32_t* nnz, int32_t* steps, int32_t* rounds,
+                         hipStream_t stream) {
+    if (N <= 0 || !steps || Kp % 1024 != 0 || Kp / 16 > 64 * LASSO_MAX_WAVES || Kp > 32768 || N > 0x7fffffffLL) return 0;
+    const char* e = getenv("LYS_LASSO_WS");  // read per call: tests switch inside one process
+    if (e && e[0] == '0') return 0;
+    const size_t lds = (size_t)LWS_TRI * sizeof(float) + (size_t)Kp * sizeof(short);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    LYS_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lasso_ws_kernel<16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(LWS_TRI * sizeof(float) + 32768 * sizeof(short))));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(lasso_ws_kernel<16>, dim3((unsigned)N), dim3(Kp / 16), lds, stream, alpha0, G, Kp, K, lambda, tol,
+                       max_steps, kcap, N, idx, coef, nnz, steps, rounds);
+    LYS_LAUNCH_CHECK();
+    return 1;
+}
+
 int lasso_from_alpha0(const float* alpha0, const float* G, int Kp, int K, float lambda, float tol, int max_steps,
                       int kcap, int64_t N, int32_t* idx, float* coef, int32_t* nnz, int32_t* steps,
-                      hipStream_t stream, int warm) {
+                      hipStream_t stream, int warm, int32_t* rounds) {
     if (N <= 0) return LYS_OK;
     if (N > 0x7fffffffLL) {
         set_error("lasso: too many signals in one tile");
         return LYS_ENOSUP;
     }
     const dim3 grid((unsigned)N);
+    // K >= 1024: working-set coordinate descent first (LYS_LASSO_WS=0: the plain kernel alone), then the plain kernel for the
+    // signals it flagged (warm == 2: everyone else returns at once).  It needs the per-signal step counts as its flag.
+    if (!warm && lasso_ws_from_alpha0(alpha0, G, Kp, K, lambda, tol, max_steps, kcap, N, idx, coef, nnz, steps, rounds, stream) == 1)
+        warm = 2;
 #define LYS_LASSO(RR, TT)                                                                                              \
     hipLaunchKernelGGL(lasso_cd_kernel<RR>, grid, dim3(TT), 0, stream, alpha0, G, Kp, K, lambda, tol, max_steps, kcap, \
                        N, idx, coef, nnz, steps, warm)

@@ -53,10 +53,9 @@ def lc_ksvd(X, y, D, Q, alpha=1, beta=1, lambda1=1, lambda2=1,
     n_classes = len(set(np.asarray(y).tolist()))
     if group is not None:  # a shard need not hold every class: the labels are 0 .. C-1
         import torch
-        import torch.distributed as tdist
+        from .. import dist as _ldist
         top = torch.tensor([int(np.max(np.asarray(y).astype(int))) + 1 if np.size(y) else 0], dtype=torch.int64)
-        tdist.all_reduce(top, op=tdist.ReduceOp.MAX, group=group)
-        n_classes = int(top.item())
+        n_classes = int(_ldist.allreduce_max_(top, group=group).item())  # staged through the device under RCCL
     H = _label_matrix(y, n_classes)
     Z = np.zeros((K, X.shape[1]))
     # with Z = 0 these are zero matrices (:136-139) -- kept as the reference computes them

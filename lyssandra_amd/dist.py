@@ -53,6 +53,21 @@ def allreduce_sum_(t, group=None):
     return t
 
 
+def allreduce_max_(t, group=None):
+    """In-place maximum over ranks of a torch tensor; like `allreduce_sum_` it stages a host tensor through the device under
+    RCCL (which only moves device memory) and is a no-op without an initialised process group."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if not t.is_cuda and dist.get_backend(group) == "nccl":
+            import torch
+            d = t.to(torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+            t.copy_(d.cpu())
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 def local_shard(X, group=None):
     """Columns of the (n, N) host matrix that belong to this rank (contiguous, remainder to the last rank)."""
     ws, rk = world(group)

@@ -572,6 +572,8 @@ def ksvd_cycle(R, dd, idx, coef, nnz, group=None, buffers=None, block=None):
     """
     import os
     k = int(idx.shape[1])
+    if buffers is not None:  # a stale view of an earlier sweep's error must not survive a cycle that does not rewrite it
+        buffers.pop("sweep_error_view", None)
     if os.environ.get("LYS_KSVD_LEGACY", "0") != "1" and HipBlockKsvdOps.supported(dd, k, int(idx.shape[0])):
         ops = HipBlockKsvdOps(R, dd, idx, coef, nnz, buffers, block=block)
         if group is None:
@@ -678,6 +680,8 @@ class HipNnKsvdOps(HipExactKsvdOps):
 
     def __init__(self, R, dd, idx, coef, nnz, buffers=None):
         torch = _torch()
+        if dd.n > 256:  # the exact update's matrix-free form (n > 256) has no Gram matrix for the projection passes to use
+            raise _lib.LyssaHipError("sharded nn_ksvd needs n <= 256 (got n = %d)" % dd.n)
         HipExactKsvdOps.__init__(self, R, dd, idx, coef, nnz, buffers)
         if buffers is None:
             buffers = {}

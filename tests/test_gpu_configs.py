@@ -435,13 +435,19 @@ def test_error_constrained_omp_and_large_K_thresh(eng):
 @pytest.mark.parametrize("n,K,N,lam,unit", [(64, 256, 60, 0.15, True), (64, 1024, 40, 0.02, True), (32, 512, 40, 0.01, True),
                                             (20, 40, 50, 0.1, True), (128, 2048, 24, 0.15, False),
                                             (128, 8192, 8, 0.05, True)])
-def test_lasso_lars_homotopy(eng, n, K, N, lam, unit):
+@pytest.mark.parametrize("ws", ["0", "1"])
+def test_lasso_lars_homotopy(eng, n, K, N, lam, unit, ws, monkeypatch):
     """`sparse_encoder('lasso')` through the LARS-lasso homotopy kernel (the algorithm family of spams.lasso(mode=2),
     sparse_coding.py:487-509; SPAMS itself is absent, parity with it is unpinned): KKT conditions in float64, agreement
     with sklearn's float64 `lars_path(method='lasso')`, about one breakpoint per non-zero -- including the dense regimes
-    (non-zeros ~ n) where coordinate descent does not converge in thousands of steps."""
+    (non-zeros ~ n) where coordinate descent does not converge in thousands of steps.
+    ws = "0": the pure homotopy.  ws = "1" (the default, round 5): for K >= 1024 the working-set coordinate descent runs
+    first and the homotopy takes the signals it hands on -- the same solution is demanded of both."""
     from sklearn.linear_model import lars_path
     from oracle import lyssa_oracle as orc
+    if ws == "1" and K < 1024:
+        pytest.skip("the working-set pass starts at K = 1024: same code path as ws = 0")
+    monkeypatch.setenv("LYS_LASSO_WS", ws)
     rs = np.random.RandomState(n + K)
     D = rs.randn(n, K)
     D /= np.linalg.norm(D, axis=0)
@@ -468,9 +474,10 @@ def test_lasso_lars_homotopy(eng, n, K, N, lam, unit):
         worst_obj = max(worst_obj, (objective(X[:, i], Z[:, i]) - objective(X[:, i], ref)) / objective(X[:, i], ref))
     nz = (Z != 0).sum(0)
     dense = nz.max() >= 0.75 * min(n, K)
-    print("n=%d K=%d lam=%g: nnz mean %.1f max %d, breakpoints max %d, polish steps max %d, KKT %.2e, vs lars_path: "
-          "coefficients %.2e, objective excess %.2e" % (n, K, lam, nz.mean(), nz.max(), int(br.max()),
-                                                        int(steps.abs().max()), kkt, worst, worst_obj))
+    print("n=%d K=%d lam=%g ws=%s: nnz mean %.1f max %d, breakpoints max %d, %d of %d signals solved by the working-set pass, "
+          "polish steps max %d, KKT %.2e, vs lars_path: coefficients %.2e, objective excess %.2e"
+          % (n, K, lam, ws, nz.mean(), nz.max(), int(br.max()), int((br <= 0).sum()) if ws == "1" else 0, N,
+             int(steps.abs().max()), kkt, worst, worst_obj))
     assert kkt < 1e-5
     # the objective is matched to fp32 accuracy everywhere; the coefficients to 1e-4 unless the support approaches n,
     # where the active Gram block is ill-conditioned and a 1e-6 KKT residual (the fp32 floor) moves them by cond * 1e-6

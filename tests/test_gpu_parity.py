@@ -297,6 +297,12 @@ def test_residual_error_and_csr(eng):
 
 
 # ------------------------------------------------------------------------------------------------ approx K-SVD
+# Full alternation on F5 with the engine's own fp32 encode: a tie signal may take another support than the reference's
+# float64 run, which moves the error of the iteration.  Bound = 10 x the largest value measured on MI355X (round 5, both
+# alpha0 kernels; see profiles/r05_gpu_tests.log) instead of a flat guess.
+FULL_ALT_TOL = 2e-4
+
+
 def _atom_err(D, Dref):
     return np.max(np.linalg.norm(D - Dref, axis=0) / np.maximum(np.linalg.norm(Dref, axis=0), 1e-30))
 
@@ -332,7 +338,9 @@ def test_approx_ksvd_golden(eng):
         Z = se.encode(X, D)
         D, Z, unused = approx_ksvd(X, D, Z, n_cycles=1, verbose=False)
         err = np.sum((X - D @ Z) ** 2)
-        assert abs(err - float(g["it%d_err" % it])) < 2e-4 * float(g["it%d_err" % it]), (it, err)
+        rel = abs(err - float(g["it%d_err" % it])) / float(g["it%d_err" % it])
+        print("full alternation, iteration %d: relative error difference %.3g" % (it, rel))
+        assert rel < FULL_ALT_TOL, (it, err, rel)
     # (c) n_cycles = 2
     D = g["D0"].astype(np.float64).copy()
     Z = np.zeros((K, X.shape[1]))
@@ -1557,8 +1565,6 @@ def test_bomp_template_sweep(eng, n, K, k, alpha0_mode):
     Xs = torch.randn((N, n), device="cuda", generator=gen)
     dd = eng.DeviceDictionary(n, K)
     dd.set(Dt)
-    if alpha0_mode == 0 and n > 64:
-        pytest.skip("n > 64 has one alpha0 kernel (gemm_nt_f32_kernel): covered by the other parameter")
     idx, coef, nnz = _host_triplet(eng.bomp_encode(Xs, dd, k))
     D = dd.D[:K, :n].t().contiguous().double().cpu().numpy()
     X = Xs.t().contiguous().double().cpu().numpy()
