@@ -130,6 +130,88 @@ def self_launch(n_ranks):
     return subprocess.call(cmd, env=env)
 
 
+def single_process_main(args):
+    """`bench.py --single-process --gpus N`: the same metric from ONE process that owns all N devices through the plain-C
+    context (the reference fans one call out over workers and gathers, lyssa/utils/__init__.py:92-146): the context
+    replicates the dictionary, shards every step's stream of synthetic patches contiguously over its devices, the devices
+    generate and encode their shards concurrently.  A step = N x patches-per-gpu patches; timed on the host clock around K
+    synchronous calls.  Prints ONE JSON line with the contract's fields; `roofline` from the library's own HIP events."""
+    import numpy as np
+    import torch
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    n, K, k, S = N_FEATURES, N_ATOMS, K_NNZ, args.signals
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit("--single-process --gpus %d needs %d HIP devices, %d visible" % (args.gpus, args.gpus, n_dev))
+    ids = (ctypes.c_int * args.gpus)(*range(args.gpus))
+    ctx = ctypes.c_void_p()
+    _lib.check(lib.lys_ctx_create_multi(args.gpus, ids, ctypes.byref(ctx)), "lys_ctx_create_multi")
+    try:
+        # the dictionary of the torch.distributed form: the first K signals of the dictionary stream, normalised
+        dev = torch.device("cuda", 0)
+        Dt = torch.empty((K, n), dtype=torch.float32, device=dev)
+        _lib.check(lib.lys_synth_signals(SEED_DICTIONARY, 0, K, n, ctypes.c_void_p(Dt.data_ptr()), n,
+                                         ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "lys_synth_signals")
+        Dt = Dt / (Dt.norm(dim=1, keepdim=True) + float(np.finfo(np.float64).eps))
+        Dh = np.ascontiguousarray(Dt.cpu().numpy(), dtype=np.float32)
+        _lib.check(lib.lys_ctx_set_dictionary(ctx, Dh.ctypes.data_as(ctypes.c_void_p), n, K), "lys_ctx_set_dictionary")
+        total = S * args.gpus
+        stats = (ctypes.c_double * 4)()
+        for _ in range(args.warmup):
+            _lib.check(lib.lys_ctx_bomp_encode_synthetic(ctx, SEED_SIGNALS, 0, total, k, stats), "lys_ctx_bomp_encode_synthetic")
+        for d in range(args.gpus):
+            torch.cuda.synchronize(d)
+        enc_ms = 0.0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _lib.check(lib.lys_ctx_bomp_encode_synthetic(ctx, SEED_SIGNALS, 0, total, k, stats), "lys_ctx_bomp_encode_synthetic")
+            enc_ms += stats[2]
+        for d in range(args.gpus):
+            torch.cuda.synchronize(d)
+        elapsed = time.perf_counter() - t0
+        mean_nnz = stats[1]
+    finally:
+        lib.lys_ctx_destroy(ctx)
+    f_gemm, f_omp = flops_per_signal(n, K, k)
+    value = float(total) * args.steps / elapsed
+    step_tf = (f_gemm + f_omp) * (value / args.gpus) / 1e12
+    kern_rate = float(S) * args.steps / (enc_ms * 1e-3)   # per device, encode kernels only (slowest device's events)
+    devices = [{"device_index": d, "device_uuid": device_uuid(torch.device("cuda", d)),
+                "device_name": torch.cuda.get_device_name(d)} for d in range(args.gpus)]
+    result = {
+        "metric": "patches/sec Batch-OMP (1024 atoms, k=10, 64-dim)",
+        "value": value, "unit": "patches/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (alpha0: every fp32 operand split into 3 bf16 planes, 6 products on the bf16 matrix cores, fp32 accumulate "
+                 "= fp32 accuracy; greedy stage: fp32 VALU)",
+        "data": "synthetic (Philox4x32-10 Gaussian patches generated on every device by the library inside the step; random "
+                "unit-norm dictionary)",
+        "config": {"workload": "Batch-OMP encode step of configs[1]: n=64, K=1024 atoms, k=10, %d Gaussian patches per GPU per "
+                               "step, device-resident sparse output; the step INCLUDES generating the patches on the device "
+                               "(%.2f of %.2f ms per step are generation + call overhead, the rest the encode kernels of the "
+                               "slowest device)" % (S, elapsed / args.steps * 1e3 - enc_ms / args.steps, elapsed / args.steps * 1e3),
+                   "signals_per_gpu": S, "n_features": n, "n_atoms": K, "n_nonzero_coefs": k,
+                   "sharding": "ONE process, lys_ctx_create_multi over %d device(s): contiguous shards of every step's stream, "
+                               "dictionary replicated, no data-path collective" % args.gpus},
+        "process_group": {"world_size": 1, "backend": "single process: lys_ctx_create_multi (RCCL communicator via "
+                                                      "ncclCommInitAll for the learning calls; the encode step has no collective)",
+                          "devices": devices, "distinct_devices": len(set(d["device_uuid"] for d in devices)),
+                          "mean_selected_atoms": mean_nnz},
+        "roofline": {"bound": "valu", "kernel": "alpha0 GEMM + w2::bomp_wave2_kernel per tile (library events around both)",
+                     "achieved": (f_gemm + f_omp) * kern_rate / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (f_gemm + f_omp) * kern_rate / 1e12 / PEAK_FP32_TFLOPS,
+                     "note": "whole encode (2nK + Kk(k+1) + k^3 FLOP per patch) over the encode-kernel time of the slowest "
+                             "device; the per-kernel split, traffic and the CPU baseline are in the default (one rank per GPU) line",
+                     "traffic": None,
+                     "whole_step": {"achieved": step_tf, "frac": step_tf / PEAK_FP32_TFLOPS}},
+        "cpu_baseline": None,
+    }
+    check_fractions(result)
+    print(json.dumps(result), flush=True)
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +224,14 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8000)
     ap.add_argument("--cpu-pool-workers", type=int, default=-1,
                     help="processes for the all-cores CPU baseline (-1 = min(host cpus, 64), 0 = skip)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives --gpus devices through the library-owned multi-device context "
+                         "(lys_ctx_create_multi + lys_ctx_bomp_encode_synthetic: SURVEY 8(e)'s process model) instead of one "
+                         "torch.distributed rank per GPU")
     args = ap.parse_args()
+
+    if args.single_process:
+        return single_process_main(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # a bare `python bench.py --gpus N`: start the N ranks ourselves, like the reference's parallel path spawns its
@@ -657,6 +746,27 @@ def config1_host(synth, N=10000, reps=7):
             _lib.check(lib.lys_ctx_timings(ctx, ms4), "lys_ctx_timings")
             stages.append(list(ms4))
         stages = sorted(stages[1:], key=lambda m: m[3])[len(stages[1:]) // 2]
+        # the host path at N = 10^6 (256 MB of patches in, 84 MB of codes out): page-locked for the call (round 5) against the
+        # staged pageable copies; `wall_ms` is the whole call on the host clock, registration included
+        big = {}
+        Nb = 1000000
+        Xb = np.ascontiguousarray(np.random.RandomState(7).randn(Nb, n).astype(np.float32))
+        bi, bc, bn = np.empty((Nb, k), np.int32), np.empty((Nb, k), np.float32), np.empty((Nb,), np.int32)
+        for label, pin in (("page_locked_for_the_call", "1"), ("pageable_staged", "0")):
+            os.environ["LYS_CTX_PIN"] = pin
+            runs = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                _lib.check(lib.lys_ctx_bomp_encode(ctx, P(Xb), Nb, k, P(bi), P(bc), P(bn)), "lys_ctx_bomp_encode")
+                wall = (time.perf_counter() - t0) * 1e3
+                ms4 = (ctypes.c_double * 4)()
+                _lib.check(lib.lys_ctx_timings(ctx, ms4), "lys_ctx_timings")
+                runs.append((wall, list(ms4)))
+            wall, m4 = sorted(runs[1:], key=lambda r: r[0])[0]
+            big[label] = {"wall_ms": wall, "host_to_device_ms": m4[0], "kernels_ms": m4[1], "device_to_host_ms": m4[2],
+                          "host_to_device_gbs": 4.0 * n * Nb / (m4[0] * 1e-3) / 1e9 if m4[0] > 0 else None,
+                          "patches_per_s_wall": Nb / (wall * 1e-3)}
+        os.environ.pop("LYS_CTX_PIN", None)
     finally:
         lib.lys_ctx_destroy(ctx)
     return {"workload": "configs[0]: Batch-OMP encode of %d random 64-dim patches, 256-atom random dictionary, k=5, through the "
@@ -671,6 +781,7 @@ def config1_host(synth, N=10000, reps=7):
                                      "sum": stages[3]},
                               "patches_per_s": N / (stages[3] * 1e-3),
                               "note": "lys_ctx_bomp_encode: host fp32 [N][n] in, host triplet out; stages from lys_ctx_timings"},
+            "c_abi_context_1M_patches": big,
             "unit": "patches/s (PCIe-inclusive; never `value`)"}
 
 

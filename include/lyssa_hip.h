@@ -479,9 +479,15 @@ int lys_synth_signals(uint64_t seed, int64_t first, int64_t N, int n, float* X, 
  *                            sparse_coding.py:603) -> upload, pack, G = D'D                    (sparse_coding.py:629)
  *   lys_ctx_bomp_encode      X_sig_major_host [N][n] fp32 (signal i = row i, the transpose of the reference's X),
  *                            results into host arrays idx/coef [N][k], nnz [N]                 (sparse_coding.py:302-367,630-635)
- *   lys_ctx_bomp_encode_synthetic   signals first..first+N-1 of lys_synth_signals generated on the device and encoded;
- *                            stats4 = {N, mean nnz, encode ms, patches/s with inputs resident}
- *   lys_ctx_timings          ms4 = {host->device (or generation), encode kernels, device->host, sum} of the last call
+ *   lys_ctx_bomp_encode_synthetic   signals first..first+N-1 of lys_synth_signals generated on the device and encoded; a
+ *                            multi-device context shards the range over ALL its devices (contiguous, the last takes the rest:
+ *                            gen_even_batches, utils/__init__.py:166-180), which run concurrently;
+ *                            stats4 = {N, mean nnz, encode ms of the slowest device, patches/s over all devices, inputs resident}
+ *   lys_ctx_timings          ms4 = {host->device (or generation), encode kernels, device->host, sum} of the last call, on the
+ *                            device that took longest
+ * lys_ctx_bomp_encode page-locks the caller's four arrays for the call (hipHostRegister; LYS_CTX_PIN=0 or arrays below 1 MB:
+ * staged pageable copies), so that the copies are asynchronous DMA and the devices of a multi-device context are fed
+ * concurrently.
  */
 typedef struct lys_ctx lys_ctx;
 int lys_ctx_create(int device, lys_ctx** out);

@@ -199,6 +199,22 @@ using namespace lys;
         if (rc_) return rc_;     \
     } while (0)
 
+// page-lock a caller's host range for the lifetime of the object (no-op when the range cannot be registered)
+struct HostPin {
+    void* p = nullptr;
+    HostPin(const void* ptr, size_t bytes) {
+        const char* e = getenv("LYS_CTX_PIN");  // read per call: bench.py measures both forms in one process
+        if ((e && e[0] == '0') || !ptr || bytes < (1u << 20)) return;  // small ranges: the staged copy is cheaper than the registration
+        if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
+        else (void)hipGetLastError();
+    }
+    ~HostPin() {
+        if (p) (void)hipHostUnregister(p);
+    }
+    HostPin(const HostPin&) = delete;
+    HostPin& operator=(const HostPin&) = delete;
+};
+
 template <class T>
 static void dfree(T*& p) {
     if (p) (void)hipFree(p);
@@ -505,6 +521,12 @@ int lys_ctx_bomp_encode(lys_ctx* c, const float* X_sig_major_host, int64_t N, in
     c->ms[0] = c->ms[1] = c->ms[2] = c->ms[3] = 0.0;
     if (N == 0) return LYS_OK;
     CTX_RC(ctx_ensure_gram(c));
+    // The caller's arrays are ordinary pageable memory (numpy).  A hipMemcpyAsync from / to pageable memory is staged by the
+    // runtime and BLOCKS the host thread, so device i + 1 was not fed before device i's copy was staged (round-4 review).  For
+    // the duration of the call the four arrays are page-locked (hipHostRegister: the copies become real DMA, asynchronous,
+    // one queue per device); memory that cannot be registered (read-only maps, ...) falls back to the staged copies.
+    HostPin pin_x(X_sig_major_host, (size_t)N * c->n * sizeof(float)), pin_i(idx_host, (size_t)N * k * sizeof(int32_t)),
+        pin_c(coef_host, (size_t)N * k * sizeof(float)), pin_n(nnz_host, (size_t)N * sizeof(int32_t));
     // every device encodes its contiguous shard, tile by tile; the devices run concurrently (one stream each)
     int64_t first[LYS_CTX_MAX_DEV], count[LYS_CTX_MAX_DEV], tile[LYS_CTX_MAX_DEV], rounds = 0;
     for (int i = 0; i < c->nd; ++i) {
@@ -538,18 +560,26 @@ int lys_ctx_bomp_encode(lys_ctx* c, const float* X_sig_major_host, int64_t N, in
             CTX_HIP(hipEventRecord(d->ev[3], d->stream));
         }
         CTX_RC(ctx_sync_all(c));
-        if (t * tile[0] < count[0]) {
-            lys_dev* d = &c->dev[0];
+        // the split of this round on the device that took longest (the devices run concurrently)
+        float ra = 0.f, rb = 0.f, re = 0.f;
+        for (int i = 0; i < c->nd; ++i) {
+            if (t * tile[i] >= count[i]) continue;
+            lys_dev* d = &c->dev[i];
             float a = 0.f, b = 0.f, e = 0.f;
             CTX_HIP(hipSetDevice(d->device));
             CTX_HIP(hipEventElapsedTime(&a, d->ev[0], d->ev[1]));
             CTX_HIP(hipEventElapsedTime(&b, d->ev[1], d->ev[2]));
             CTX_HIP(hipEventElapsedTime(&e, d->ev[2], d->ev[3]));
-            c->ms[0] += a;
-            c->ms[1] += b;
-            c->ms[2] += e;
-            c->ms[3] += a + b + e;
+            if (a + b + e > ra + rb + re) {
+                ra = a;
+                rb = b;
+                re = e;
+            }
         }
+        c->ms[0] += ra;
+        c->ms[1] += rb;
+        c->ms[2] += re;
+        c->ms[3] += ra + rb + re;
     }
     return LYS_OK;
 }
@@ -559,51 +589,86 @@ int lys_ctx_bomp_encode_synthetic(lys_ctx* c, uint64_t seed, int64_t first, int6
         set_error("ctx_bomp_encode_synthetic: bad arguments");
         return LYS_EINVAL;
     }
-    lys_dev* d = &c->dev[0];  // measurement aid: device 0 only
-    CTX_HIP(hipSetDevice(d->device));
     c->ms[0] = c->ms[1] = c->ms[2] = c->ms[3] = 0.0;
     stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0.0;
     if (N == 0) return LYS_OK;
     CTX_RC(ctx_ensure_gram(c));
-    const int64_t tile = ctx_tile(c, N);
-    int rc = dev_reserve(c, d, tile, k);
-    if (rc) return rc;
-    int32_t* hn = static_cast<int32_t*>(malloc((size_t)tile * sizeof(int32_t)));
-    if (!hn) {
-        set_error("ctx_bomp_encode_synthetic: out of host memory");
-        return LYS_EINVAL;
-    }
-    double nnz_sum = 0.0;
-    for (int64_t s0 = 0; s0 < N && !rc; s0 += tile) {
-        const int64_t cnt = (N - s0 < tile) ? N - s0 : tile;
-        hipError_t e = hipEventRecord(d->ev[0], d->stream);
-        rc = synth_signals(seed, first + s0, cnt, c->n, d->X, c->n, d->stream);
-        if (e == hipSuccess) e = hipEventRecord(d->ev[1], d->stream);
-        if (!rc)
-            rc = lys_bomp_encode(d->X, c->n, d->D, d->G, c->n, c->K, k, cnt, d->idx, d->coef, d->nnz, d->ws, d->ws_bytes,
-                                 d->stream);
-        if (e == hipSuccess) e = hipEventRecord(d->ev[2], d->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(hn, d->nnz, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-        float a = 0.f, b = 0.f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&a, d->ev[0], d->ev[1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&b, d->ev[1], d->ev[2]);
-        if (e != hipSuccess) {
-            set_error("ctx_bomp_encode_synthetic: %s", hipGetErrorString(e));
+    // Round 5: every device of the context takes its contiguous shard of the stream [first, first + N) (the reference's
+    // gen_even_batches split, lyssa/utils/__init__.py:166-180), generates it on the device and encodes it, all devices
+    // concurrently on their own streams.  (Rounds 2-4: device 0 only, so the single-process form of SURVEY 8(e) could not be
+    // measured.)  The rate counts the devices' concurrent work: N over the time of the device that took longest.
+    int64_t sfirst[LYS_CTX_MAX_DEV], count[LYS_CTX_MAX_DEV], tile[LYS_CTX_MAX_DEV], rounds = 0;
+    int32_t* hn[LYS_CTX_MAX_DEV] = {};
+    double gen_ms[LYS_CTX_MAX_DEV] = {}, enc_ms[LYS_CTX_MAX_DEV] = {};
+    int rc = LYS_OK;
+    for (int i = 0; i < c->nd && !rc; ++i) {
+        shard_of(N, c->nd, i, &sfirst[i], &count[i]);
+        tile[i] = ctx_tile(c, count[i]);
+        if (count[i] <= 0) continue;
+        if (hipSetDevice(c->dev[i].device) != hipSuccess) {
+            set_error("ctx_bomp_encode_synthetic: hipSetDevice(%d)", c->dev[i].device);
             rc = LYS_EHIP;
             break;
         }
-        c->ms[0] += a;
-        c->ms[1] += b;
-        c->ms[3] += a + b;
-        for (int64_t i = 0; i < cnt; ++i) nnz_sum += hn[i];
+        rc = dev_reserve(c, &c->dev[i], tile[i], k);
+        if (!rc && hipHostMalloc(reinterpret_cast<void**>(&hn[i]), (size_t)tile[i] * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+            set_error("ctx_bomp_encode_synthetic: out of pinned host memory");
+            rc = LYS_EHIP;
+        }
+        const int64_t r = (count[i] + tile[i] - 1) / tile[i];
+        rounds = r > rounds ? r : rounds;
     }
-    free(hn);
+    double nnz_sum = 0.0;
+    for (int64_t t = 0; t < rounds && !rc; ++t) {
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < c->nd && !rc && e == hipSuccess; ++i) {
+            lys_dev* d = &c->dev[i];
+            const int64_t s0 = t * tile[i];
+            if (s0 >= count[i]) continue;
+            const int64_t cnt = (count[i] - s0 < tile[i]) ? count[i] - s0 : tile[i];
+            e = hipSetDevice(d->device);
+            if (e == hipSuccess) e = hipEventRecord(d->ev[0], d->stream);
+            if (e == hipSuccess) rc = synth_signals(seed, first + sfirst[i] + s0, cnt, c->n, d->X, c->n, d->stream);
+            if (e == hipSuccess) e = hipEventRecord(d->ev[1], d->stream);
+            if (!rc && e == hipSuccess)
+                rc = lys_bomp_encode(d->X, c->n, d->D, d->G, c->n, c->K, k, cnt, d->idx, d->coef, d->nnz, d->ws, d->ws_bytes,
+                                     d->stream);
+            if (e == hipSuccess) e = hipEventRecord(d->ev[2], d->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(hn[i], d->nnz, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream);
+        }
+        for (int i = 0; i < c->nd && !rc && e == hipSuccess; ++i) {
+            lys_dev* d = &c->dev[i];
+            const int64_t s0 = t * tile[i];
+            if (s0 >= count[i]) continue;
+            const int64_t cnt = (count[i] - s0 < tile[i]) ? count[i] - s0 : tile[i];
+            e = hipSetDevice(d->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+            float a = 0.f, b = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&a, d->ev[0], d->ev[1]);
+            if (e == hipSuccess) e = hipEventElapsedTime(&b, d->ev[1], d->ev[2]);
+            gen_ms[i] += a;
+            enc_ms[i] += b;
+            if (e == hipSuccess)
+                for (int64_t q = 0; q < cnt; ++q) nnz_sum += hn[i][q];
+        }
+        if (e != hipSuccess && !rc) {
+            set_error("ctx_bomp_encode_synthetic: %s", hipGetErrorString(e));
+            rc = LYS_EHIP;
+        }
+    }
+    for (int i = 0; i < c->nd; ++i)
+        if (hn[i]) (void)hipHostFree(hn[i]);
     if (rc) return rc;
+    int slow = 0;
+    for (int i = 1; i < c->nd; ++i)
+        if (enc_ms[i] > enc_ms[slow]) slow = i;
+    c->ms[0] = gen_ms[slow];
+    c->ms[1] = enc_ms[slow];
+    c->ms[3] = gen_ms[slow] + enc_ms[slow];
     stats4[0] = (double)N;
     stats4[1] = nnz_sum / (double)N;              // mean number of selected atoms
-    stats4[2] = c->ms[1];                         // encode kernels, ms
-    stats4[3] = (double)N / (c->ms[1] * 1e-3);    // patches per second, inputs resident
+    stats4[2] = c->ms[1];                         // encode kernels of the slowest device, ms
+    stats4[3] = (double)N / (c->ms[1] * 1e-3);    // patches per second over all devices, inputs resident
     return LYS_OK;
 }
 

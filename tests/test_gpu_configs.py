@@ -659,3 +659,70 @@ def test_bench_self_launch_two_ranks_gloo():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
     assert "exchange" in line["ksvd_iteration"]["ms"], line["ksvd_iteration"]
     assert "exchange" in line["odl_batch"]["ms"], line["odl_batch"]
+    # what a reader needs to verify that the ranks ran (round 5): world size, backend, one entry per rank with its device
+    pg = line["process_group"]
+    assert pg["world_size"] == 2 and pg["backend"] == "gloo" and len(pg["ranks"]) == 2
+    assert sorted(r_["rank"] for r_ in pg["ranks"]) == [0, 1]
+    assert all(r_["device_uuid"] and r_["patches_per_s"] > 0 and r_["pid"] > 0 for r_ in pg["ranks"])
+    assert len(set(r_["pid"] for r_ in pg["ranks"])) == 2
+    assert abs(sum(r_["patches_per_s"] for r_ in pg["ranks"]) / line["value"] - 1.0) < 0.5   # slowest-rank clock vs own clocks
+
+
+def test_bench_single_process_context(monkeypatch):
+    """`bench.py --single-process`: ONE process drives the devices through lys_ctx_create_multi + lys_ctx_bomp_encode_synthetic
+    (SURVEY 8(e)'s process model; the reference fans one call out and gathers, lyssa/utils/__init__.py:92-146).  On this
+    one-GPU box the context is created with its RCCL communicator anyway (LYS_CTX_FORCE_RCCL=1), so the same code path as on
+    an 8-GPU node runs; the line carries the contract's fields and the device list."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LYS_CTX_FORCE_RCCL="1")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--single-process", "--gpus", "1", "--steps", "3",
+                        "--warmup", "1", "--patches-per-gpu", str(1 << 18)], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["unit"] == "patches/s" and line["scaling"] == "weak"
+    assert line["value"] > 5e7                                        # > 50 M patches/s through the plain-C context
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 / (1 << 18) - 1.0) < 1e-6
+    pg = line["process_group"]
+    assert pg["world_size"] == 1 and len(pg["devices"]) == 1 and pg["devices"][0]["device_uuid"]
+    assert 9.0 < pg["mean_selected_atoms"] <= 10.0                    # k = 10 atoms per patch (a few noise-floor stops)
+    assert 0.0 < line["roofline"]["frac"] <= 1.0
+
+
+def test_ctx_synthetic_multi_device_shards(eng):
+    """lys_ctx_bomp_encode_synthetic on a (forced-RCCL, one-device) multi context: same statistics as the single-device
+    context for the same stream -- the sharding of round 5 changes who encodes a patch, not what is encoded."""
+    import ctypes
+    import os
+    from lyssandra_amd import _lib
+    lib = _lib.load()
+    n, K, k, N = 64, 256, 5, 100000
+    rs = np.random.RandomState(3)
+    D = rs.randn(K, n).astype(np.float32)
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    res = []
+    for multi in (False, True):
+        ctx = ctypes.c_void_p()
+        if multi:
+            os.environ["LYS_CTX_FORCE_RCCL"] = "1"
+            ids = (ctypes.c_int * 1)(0)
+            _lib.check(lib.lys_ctx_create_multi(1, ids, ctypes.byref(ctx)), "lys_ctx_create_multi")
+            os.environ.pop("LYS_CTX_FORCE_RCCL")
+        else:
+            _lib.check(lib.lys_ctx_create(0, ctypes.byref(ctx)), "lys_ctx_create")
+        try:
+            _lib.check(lib.lys_ctx_set_dictionary(ctx, D.ctypes.data_as(ctypes.c_void_p), n, K), "set_dictionary")
+            st = (ctypes.c_double * 4)()
+            _lib.check(lib.lys_ctx_bomp_encode_synthetic(ctx, 11, 1000, N, k, st), "synthetic")
+            res.append(list(st))
+        finally:
+            lib.lys_ctx_destroy(ctx)
+    assert res[0][0] == res[1][0] == N and res[0][1] == res[1][1] and res[0][3] > 0 and res[1][3] > 0
