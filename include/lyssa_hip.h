@@ -359,13 +359,6 @@ int lys_bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, 
  * applied by lys_bksvd_finish: call it once after X(nb), before D_packed <- D_next (a no-op for the eager schedule).
  */
 int lys_bksvd_is_lazy(int k, int K);
-/* FUSED launches (single GPU, lazy schedule; opt-in with LYS_BKSVD_FUSED=1 -- measured equal to the separate launches, see
- * ksvd_block.hip): lys_bksvd_step(2, c), c in [1, nb-1], is
- * Z(c) = Y(c) followed IN THE SAME LAUNCH by X(c+1) -- workgroup 0 runs the narrow step of block c once a device-side
- * counter (behind the slabs, inside the statistics buffer) says every workgroup's Y(c) statistics are in; nobody else
- * waits.  A cycle is then  X(0), X(1), Z(1), ..., Z(nb-1), lys_bksvd_finish : one kernel boundary per block instead of
- * two.  Callers that all-reduce the slab between Y(c) and X(c+1) (several GPUs) keep modes 0 / 1. */
-int lys_bksvd_is_fused(int k, int K);
 int lys_bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
                      const float* D_packed, const float* D_next, int B, void* stream);
 /* one whole cycle on one GPU: index (workspace: lys_bksvd_index_workspace_bytes) + all launches + D_packed <- D_next */

@@ -111,7 +111,6 @@ int64_t sym_packed_count(int, int);
 int sym_pack(const float*, int, int, float*, hipStream_t);
 int sym_unpack(const float*, int, int, float*, hipStream_t);
 int bksvd_lazy(int, int);
-int bksvd_fused(int, int);
 int bksvd_sweep(float*, int64_t, int, int, int, int64_t, const int32_t*, float*, const int32_t*, int, int32_t*, void*,
                 int32_t*, int32_t*, void*, size_t, double*, float*, float*, hipStream_t);
 int odl_increments(const float*, int64_t, int, int, int, const int32_t*, const float*, const int32_t*, const int32_t*,
@@ -134,10 +133,7 @@ int densify_f64(const int32_t*, const float*, const int32_t*, int, int, int64_t,
 // measured against 1 GiB tiles: +1.2 % patches/s -- fewer launch ramps / tails; MI355X has 288 GB).
 int64_t tile_signals(int Kp) {
     int64_t bytes = 4ll << 30;
-    const char* e = getenv("LYS_TILE_MB");
-    if (e && atoi(e) > 0) {
-        bytes = (int64_t)atoi(e) << 20;
-    } else {
+    {
         // never more than a sixteenth of the device memory per tile (18 GB on a 288 GB MI355X: no effect there; on a
         // smaller or busier device the 4 GiB default would otherwise pin a large share of it per stream)
         // cached per device id (the multi-device context calls this with each of its devices current in turn)
@@ -174,17 +170,12 @@ static bool alpha0_bf16x3_enabled() {
 
 static int alpha0_any(const float* X, int64_t ldx, const float* D, int ldd, float* a0, int Kp, int64_t cnt, int n,
                       hipStream_t stream, void* split_scratch = nullptr, bool presplit = false) {
-    static int use_fast = -1;
-    if (use_fast < 0) {
-        const char* e = getenv("LYS_ALPHA0_FAST");
-        use_fast = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (use_fast && alpha0_fast_path(n, Kp)) {
+    if (alpha0_fast_path(n, Kp)) {
         if (split_scratch && alpha0_bf16x3_enabled())
             return alpha0_n64_bf16x3(X, ldx, D, ldd, a0, Kp, cnt, n, split_scratch, stream, presplit);
         return alpha0_n64(X, ldx, D, ldd, a0, Kp, cnt, n, stream);
     }
-    if (use_fast && n > 64 && split_scratch && alpha0_bf16x3_enabled() && alpha0_split_path(n, Kp)) {
+    if (n > 64 && split_scratch && alpha0_bf16x3_enabled() && alpha0_split_path(n, Kp)) {
         // k-looped bf16x3 GEMM (round 4): the dictionary's planes in split_scratch ([3][Kp][ldp])
         if (!presplit) {
             const int rc = alpha0_bf16x3_split(D, ldd, Kp, n, split_scratch, stream);
@@ -221,45 +212,9 @@ static int prof_mark(hipStream_t stream) {
     return LYS_OK;
 }
 
-// ---- two-stream tile pipeline: the alpha0 GEMM of tile t+1 (MFMA pipe, LDS) runs next to the greedy kernel of
-// tile t (VALU, latency-bound); the two kernels co-reside on a CU (2 x 192 + 128 VGPRs per SIMD lane).
-struct Pipe {
-    bool made = false;
-    hipStream_t s_gemm = nullptr, s_omp = nullptr;
-    hipEvent_t ev_in = nullptr, ev_gemm[2] = {nullptr, nullptr}, ev_omp[2] = {nullptr, nullptr};
-};
-static Pipe g_pipe[64];
-
-static int pipe_get(Pipe** out) {
-    int dev = 0;
-    LYS_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) {
-        set_error("device index %d out of range", dev);
-        return LYS_EINVAL;
-    }
-    Pipe& p = g_pipe[dev];
-    if (!p.made) {
-        LYS_CHECK_HIP(hipStreamCreateWithFlags(&p.s_gemm, hipStreamNonBlocking));
-        LYS_CHECK_HIP(hipStreamCreateWithFlags(&p.s_omp, hipStreamNonBlocking));
-        LYS_CHECK_HIP(hipEventCreateWithFlags(&p.ev_in, hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i) {
-            LYS_CHECK_HIP(hipEventCreateWithFlags(&p.ev_gemm[i], hipEventDisableTiming));
-            LYS_CHECK_HIP(hipEventCreateWithFlags(&p.ev_omp[i], hipEventDisableTiming));
-        }
-        p.made = true;
-    }
-    *out = &p;
-    return LYS_OK;
-}
-
-static bool pipeline_enabled() {
-    static int cached = -1;
-    if (cached < 0) {
-        const char* e = getenv("LYS_PIPELINE");
-        cached = (e && e[0] == '1') ? 1 : 0;  // off by default: measured slower (both kernels contend in L2)
-    }
-    return cached == 1;
-}
+// (Rounds 2-4 carried a two-stream tile pipeline here -- the alpha0 GEMM of tile t+1 beside the greedy kernel of tile t,
+// LYS_PIPELINE=1 -- measured slower every time (both kernels contend in L2; profiles/r04_experiments.txt) and removed in
+// round 5 together with its ping-pong workspace.)
 
 }  // namespace lys
 
@@ -303,7 +258,7 @@ int lys_gram(const float* D_packed, int n, int K, float* G, void* stream) {
 size_t lys_bomp_workspace_bytes(int n, int K, int k, int64_t N) {
     const int Kp = padded_atoms(K);
     const int64_t t = tile_signals(Kp);
-    int64_t rows = (N <= t) ? ((N < 1) ? 1 : N) : (pipeline_enabled() ? 2 * t : t);  // one tile (two if ping-pong)
+    int64_t rows = (N <= t) ? ((N < 1) ? 1 : N) : t;  // one tile
     size_t bytes = (size_t)rows * (size_t)Kp * sizeof(float);
     if (!bomp_has_wave_kernel(Kp, k)) bytes += bomp_generic_scratch_bytes(Kp, k);
     if (alpha0_fast_path(n, Kp) || (n > 64 && alpha0_split_path(n, Kp)))
@@ -397,21 +352,11 @@ static int encode_tiles(int mode, const float* X, int64_t ldx, const float* D_pa
         }
         return LYS_OK;
     }
-    const bool piped = pipeline_enabled() && rows >= 2 * 512;
-    int64_t tile = piped ? rows / 2 : rows;
+    int64_t tile = rows;
     if (tile > pref) tile = pref;
     tile = (tile / 512) * 512;
     if (tile < 512) tile = (rows < 512) ? rows : 512;
-    Pipe* pp = nullptr;
-    hipStream_t sg = user, so = user;
-    if (piped) {
-        if ((rc = pipe_get(&pp))) return rc;
-        sg = pp->s_gemm;
-        so = pp->s_omp;
-        LYS_CHECK_HIP(hipEventRecord(pp->ev_in, user));
-        LYS_CHECK_HIP(hipStreamWaitEvent(sg, pp->ev_in, 0));
-        LYS_CHECK_HIP(hipStreamWaitEvent(so, pp->ev_in, 0));
-    }
+    const hipStream_t sg = user, so = user;  // both kernels of a tile on the caller's stream
     bool presplit = false;
     if (split && alpha0_bf16x3_enabled()) {  // one split of the dictionary for all tiles of this call
         if ((rc = alpha0_bf16x3_split(D_packed, ldd, Kp, n, split, sg))) return rc;
@@ -420,17 +365,11 @@ static int encode_tiles(int mode, const float* X, int64_t ldx, const float* D_pa
     int64_t t = 0;
     for (int64_t s0 = 0; s0 < N; s0 += tile, ++t) {
         const int64_t cnt = (N - s0 < tile) ? N - s0 : tile;
-        const int b = piped ? (int)(t & 1) : 0;
-        float* a0 = alpha0 + (size_t)b * (size_t)tile * Kp;
+        float* a0 = alpha0;
         const bool prof = g_prof.on && g_prof.used + StageProfile::PER_TILE <= StageProfile::CAP;
-        if (piped && t >= 2) LYS_CHECK_HIP(hipStreamWaitEvent(sg, pp->ev_omp[b], 0));  // buffer b is free again
         if (prof && (rc = prof_mark(sg))) return rc;
         if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, sg, split, presplit))) return rc;
         if (prof && (rc = prof_mark(sg))) return rc;
-        if (piped) {
-            LYS_CHECK_HIP(hipEventRecord(pp->ev_gemm[b], sg));
-            LYS_CHECK_HIP(hipStreamWaitEvent(so, pp->ev_gemm[b], 0));
-        }
         if (prof && (rc = prof_mark(so))) return rc;
         if ((rc = (mode == 2) ? thresh_from_alpha0(a0, K, Kp, k, cnt, idx + s0 * k, coef + s0 * k, nnz + s0, so)
                               : bomp_from_alpha0(a0, G, Kp, k, cnt, idx + s0 * k, coef + s0 * k, nnz + s0, gen, so, mode == 0)))
@@ -439,11 +378,6 @@ static int encode_tiles(int mode, const float* X, int64_t ldx, const float* D_pa
             if ((rc = prof_mark(so))) return rc;
             g_prof.signals += cnt;
         }
-        if (piped) LYS_CHECK_HIP(hipEventRecord(pp->ev_omp[b], so));
-    }
-    if (piped) {
-        // the greedy stream is in-order: its last event covers every tile (and every GEMM they waited for)
-        LYS_CHECK_HIP(hipStreamWaitEvent(user, pp->ev_omp[(t - 1) & 1], 0));
     }
     return LYS_OK;
 }
@@ -714,7 +648,6 @@ int lys_bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, cons
 }
 
 int lys_bksvd_is_lazy(int k, int K) { return bksvd_lazy(k, K); }
-int lys_bksvd_is_fused(int k, int K) { return bksvd_fused(k, K); }
 
 int lys_bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
                     const int32_t* nnz, int B, int32_t* row_ptr, void* entry_records, int32_t* cg_ptr, int32_t* cg_entry,

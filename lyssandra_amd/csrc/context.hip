@@ -888,19 +888,7 @@ int lys_ctx_ksvd_sweep(lys_ctx* c, int* n_unused_host) {
         }
         CTX_HIP(hipMemsetAsync(d->stats, 0, d->stats_bytes, d->stream));
     }
-    // one device, no collective between the half steps: the fused launches (one per block, lys_bksvd_step mode 2)
-    const bool fused = c->nd == 1 && !c->use_rccl && lys_bksvd_is_fused(k, c->K);
-    if (fused) {
-        lys_dev* d = &c->dev[0];
-        CTX_HIP(hipSetDevice(d->device));
-        for (int cb = 0; cb <= (nb > 1 ? 1 : nb); ++cb)
-            CTX_RC(lys_bksvd_step(0, cb, B, d->R, c->ldd, c->n, c->K, k, d->row_ptr, d->erec, d->cg_ptr, d->cg_entry, d->r_idx,
-                                  d->r_coef, d->D, d->Dnext, d->stats, d->stream));
-        for (int cb = 1; cb < nb; ++cb)
-            CTX_RC(lys_bksvd_step(2, cb, B, d->R, c->ldd, c->n, c->K, k, d->row_ptr, d->erec, d->cg_ptr, d->cg_entry, d->r_idx,
-                                  d->r_coef, d->D, d->Dnext, d->stats, d->stream));
-    }
-    for (int cb = 0; !fused && cb <= nb; ++cb) {
+    for (int cb = 0; cb <= nb; ++cb) {
         for (int i = 0; i < c->nd; ++i) {
             lys_dev* d = &c->dev[i];
             CTX_HIP(hipSetDevice(d->device));

@@ -807,17 +807,10 @@ int gemm_nt_bf16x3(const float* A, int64_t lda, const void* Bsp, int n, float* C
         set_error("gemm_nt_bf16x3: Nc = %d, %lld blocks", Nc, (long long)blocks);
         return LYS_ENOSUP;
     }
-    static int waves = 0;
-    if (!waves) {
-        const char* e = getenv("LYS_GEMM_WAVES");
-        waves = (e && atoi(e) == 4) ? 4 : 8;
-    }
-    if (waves == 4)
-        hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, stream, A, lda,
-                           static_cast<const unsigned*>(Bsp), bf16x3_ldp(n), C, ldc, M, Nc, n);
-    else
-        hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<true, 8>), dim3((unsigned)blocks), dim3(512), 0, stream, A, lda,
-                           static_cast<const unsigned*>(Bsp), bf16x3_ldp(n), C, ldc, M, Nc, n);
+    // 8 waves per workgroup (wave tile 32 x 64; the 4-wave form with 64 x 64 wave tiles measured 1.75 against 1.63 ms at
+    // configs[2] in round 4 and is no longer instantiated)
+    hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<true, 8>), dim3((unsigned)blocks), dim3(512), 0, stream, A, lda,
+                       static_cast<const unsigned*>(Bsp), bf16x3_ldp(n), C, ldc, M, Nc, n);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -858,8 +851,6 @@ int alpha0_n64_bf16x3(const float* X, int64_t ldx, const float* D, int ldd, floa
         const int lds0 = 2 * 3 * 64 * B3_LD * (int)sizeof(unsigned short);   // two atom-tile buffers (>= the one-off fp32 staging)
         const int lds1 = lds0 + 4 * 1024 * (int)sizeof(float);               // + the four waves' transposition regions
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_bf16x3_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds0));
             LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_bf16x3_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
 
@@ -868,11 +859,8 @@ int alpha0_n64_bf16x3(const float* X, int64_t ldx, const float* D, int ldd, floa
         unsigned* Dsp = static_cast<unsigned*>(scratch);
         if (!presplit)
             hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((Kp * 32 + 255) / 256)), dim3(256), 0, stream, D, ldd, Kp, n, Dsp);
-        const char* xe = getenv("LYS_A0_XPOSE");   // =0: the dword-store epilogue of rounds 2-3 (read per call: A/B inside one job)
-        if (xe && xe[0] == '0')
-            hipLaunchKernelGGL(alpha0_n64_bf16x3_kernel<false>, dim3((unsigned)whole), dim3(256), lds0, stream, X, ldx, Dsp, C, Kp, n);
-        else
-            hipLaunchKernelGGL(alpha0_n64_bf16x3_kernel<true>, dim3((unsigned)whole), dim3(256), lds1, stream, X, ldx, Dsp, C, Kp, n);
+        // (the dword-store epilogue of rounds 2-3, XPOSE = false, lost its A/B in round 4 and is no longer instantiated)
+        hipLaunchKernelGGL(alpha0_n64_bf16x3_kernel<true>, dim3((unsigned)whole), dim3(256), lds1, stream, X, ldx, Dsp, C, Kp, n);
         LYS_LAUNCH_CHECK();
     }
     if (tail) return alpha0_n64(X + whole * 128 * ldx, ldx, D, ldd, C + whole * 128 * Kp, Kp, tail, n, stream);
@@ -884,30 +872,18 @@ bool alpha0_fast_path(int n, int Kp) { return n <= 64 && (Kp % 128) == 0; }
 int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, int Kp, int64_t N, int n,
                hipStream_t stream) {
     if (N <= 0) return LYS_OK;
-    // LYS_ALPHA0_BN = 64 | 128 atoms per workgroup tile.  Measured: 128 (2 workgroups/CU) 80.7 TFLOP/s, 64 (3/CU)
-    // 77.7 -- occupancy is not the limiter, the 1 GiB/tile of alpha0 stores is (about 2.6 TB/s).
-    static int nj = -1, xpose = 2;
-    if (nj < 0) {
-        const char* e = getenv("LYS_ALPHA0_BN");
-        nj = (e && atoi(e) == 64) ? 1 : 2;
-        const char* x = getenv("LYS_ALPHA0_XPOSE");
-        xpose = x ? atoi(x) : 2;   // LYS_ALPHA0_XPOSE = 0 direct | 1 LDS transpose | 2 pipelined stores (default)
-    }
-    const size_t lds = (size_t)(128 + 64 * nj) * A0_LD * sizeof(float);
+    // 128 atoms per workgroup tile (2 workgroups per CU: 80.7 TFLOP/s against 77.7 with 64 atoms and 3 per CU -- occupancy is
+    // not the limiter, the alpha0 stores are) with software-pipelined stores; the other tile / epilogue forms of rounds 1-3
+    // (LYS_ALPHA0_BN, LYS_ALPHA0_XPOSE) lost their A/Bs and are no longer instantiated
+    const size_t lds = (size_t)(128 + 64 * 2) * A0_LD * sizeof(float);
     static bool attr_set[64] = {false};
     int dev = 0;
     LYS_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<2, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * A0_LD * (int)sizeof(float)));
         LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<2, 2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * A0_LD * (int)sizeof(float)));
         LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<2, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * A0_LD * (int)sizeof(float)));
-        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<1, 0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 192 * A0_LD * (int)sizeof(float)));
-        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha0_n64_kernel<1, 2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 192 * A0_LD * (int)sizeof(float)));
         attr_set[dev] = true;
     }
     const int64_t blocks = (N + 127) / 128;
@@ -915,28 +891,13 @@ int alpha0_n64(const float* X, int64_t ldx, const float* D, int ldd, float* C, i
         set_error("alpha0: grid too large");
         return LYS_ENOSUP;
     }
-    if (nj == 2 && xpose == 2) {
-        const int64_t whole = N / 128, tail = N - whole * 128;
-        if (whole)
-            hipLaunchKernelGGL((alpha0_n64_kernel<2, 2>), dim3((unsigned)whole), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp,
-                               whole * 128, n);
-        if (tail)
-            hipLaunchKernelGGL((alpha0_n64_kernel<2, 0>), dim3(1), dim3(256), lds, stream, X + whole * 128 * ldx, ldx, D, ldd,
-                               C + whole * 128 * Kp, Kp, tail, n);
-    } else if (nj == 1 && xpose == 2) {
-        const int64_t whole = N / 128, tail = N - whole * 128;
-        if (whole)
-            hipLaunchKernelGGL((alpha0_n64_kernel<1, 2>), dim3((unsigned)whole), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp,
-                               whole * 128, n);
-        if (tail)
-            hipLaunchKernelGGL((alpha0_n64_kernel<1, 0>), dim3(1), dim3(256), lds, stream, X + whole * 128 * ldx, ldx, D, ldd,
-                               C + whole * 128 * Kp, Kp, tail, n);
-    } else if (nj == 2 && xpose == 1)
-        hipLaunchKernelGGL((alpha0_n64_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
-    else if (nj == 2)
-        hipLaunchKernelGGL((alpha0_n64_kernel<2, 0>), dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
-    else
-        hipLaunchKernelGGL((alpha0_n64_kernel<1, 0>), dim3((unsigned)blocks), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp, N, n);
+    const int64_t whole = N / 128, tail = N - whole * 128;
+    if (whole)
+        hipLaunchKernelGGL((alpha0_n64_kernel<2, 2>), dim3((unsigned)whole), dim3(256), lds, stream, X, ldx, D, ldd, C, Kp,
+                           whole * 128, n);
+    if (tail)
+        hipLaunchKernelGGL((alpha0_n64_kernel<2, 0>), dim3(1), dim3(256), lds, stream, X + whole * 128 * ldx, ldx, D, ldd,
+                           C + whole * 128 * Kp, Kp, tail, n);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }

@@ -925,12 +925,7 @@ int ksvd_fused_step(int atom, int K, float* R, int64_t ldr, int n, int k, const 
     }
     const int ldd = padded_features(n);
     const int fb = (n <= 64) ? 1 : (n <= 128) ? 2 : (n <= 256) ? 4 : 0;
-    static int pf = -1;  // workgroups that warm L2 for the next atom (LYS_KSVD_PREFETCH_BLOCKS, default 256: 13.1 -> 12.0 ms/sweep at config 2)
-    if (pf < 0) {
-        const char* e = getenv("LYS_KSVD_PREFETCH_BLOCKS");
-        pf = e ? atoi(e) : 256;
-        if (pf < 0) pf = 0;
-    }
+    constexpr int pf = 256;  // workgroups that warm L2 for the next atom (measured: 13.1 -> 12.0 ms per sweep at config 2)
     switch (fb) {
         case 1: hipLaunchKernelGGL((ksvd_fused_kernel<1, 64>), dim3(KSVD_BLOCKS + pf), dim3(1024), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
         case 2: hipLaunchKernelGGL((ksvd_fused_kernel<2, 64>), dim3(KSVD_BLOCKS + pf), dim3(1024), 0, stream, atom, K, hb, hn, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, ldd, Dnext); break;
@@ -1724,8 +1719,8 @@ __device__ __forceinline__ double wave_sum_d(double x) {
 // threads only share the load of C (sum of the fp32 partials in fp64), then waves 1..3 retire.
 constexpr int E64_QS = 65;  // row stride of the Krylov basis (doubles): lanes reading different rows hit different banks
 
-__device__ int g_eig_mmin = 2;  // first Lanczos step the Ritz test runs at (LYS_EIG_MMIN)
-__device__ int g_eig_pre = 4;  // power steps before the Lanczos recurrence of the single-wave solver (LYS_EIG_PRE)
+constexpr int g_eig_mmin = 2;  // first Lanczos step the Ritz test runs at
+constexpr int g_eig_pre = 4;   // power steps before the Lanczos recurrence of the single-wave solver
 constexpr int XK1_RED = 64;            // workgroups of K1's partial-sum role (64 matrix elements each)
 constexpr int XK1_APPLY_BLOCKS = 1024;  // most apply workgroups of a K1 launch (16 entries each per pass)
 constexpr int XL_SH = 4;  // workgroups (= fp32 partials) of the shared-row Gram part of the pipelined sweep below
@@ -2918,35 +2913,18 @@ int ksvd_exact_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* 
     const int nb = (n + 63) / 64;
     const unsigned gx = (unsigned)std::max<int64_t>(1, (max_support + GRAM_SPB - 1) / GRAM_SPB);
     // n <= 64: MFMA Gram kernel with per-workgroup partial sums (no memset, no atomics); slices of <= 320 signals
-    static int slice = 0;  // signals per Gram workgroup (LYS_EXACT_SLICE; measured at configs[1] with the 16-deep reduce kernel: 96 / 128 / 160 / 192 / 256 -> 37.9 / 36.6 / 37.6 / 37.8 / 39.4 ms per sweep)
-    if (!slice) {
-        const char* e = getenv("LYS_EXACT_SLICE");
-        slice = (e && atoi(e) >= 64) ? atoi(e) : 128;
-    }
+    constexpr int slice = 128;  // signals per Gram workgroup (measured at configs[1] with the 16-deep reduce kernel: 96 / 128 / 160 / 192 / 256 -> 37.9 / 36.6 / 37.6 / 37.8 / 39.4 ms per sweep)
     int parts = (int)std::min<int64_t>(G64_MAX_PARTS, std::max<int64_t>(1, (max_support + slice - 1) / slice));
     if ((max_support + parts - 1) / parts + 63 > G64_ROWS) parts = 0;  // an atom used by > 45k signals: atomics path
     if (n > 64) parts = 0;
     // idx given (the codes' atom indices), n <= 64, k <= 16, plain exact update: the pipelined sweep (exact_k1_kernel /
     // exact_k2_kernel: two dependent launches per atom instead of four)
-    static int pipe_env = -1;
-    if (pipe_env < 0) {
-        const char* e = getenv("LYS_EXACT_PIPELINED");
-        pipe_env = (e && e[0] == '0') ? 0 : 1;
-    }
-    static int pre_set[64] = {};
-    if (dev >= 0 && dev < 64 && !pre_set[dev]) {
-        const char* e = getenv("LYS_EIG_PRE");
-        // default 2 (configs[1], same box: 0 / 1 / 2 / 3 pre-steps -> 4.7 / 4.0 / 3.0 / 3.0 Lanczos steps per solve, sweep
-        // 24.0 / 24.8 / 22.6-23.3 / 23.8 ms; with the Ritz test from m = 2: 3 / 4 / 5 pre-steps -> 22.9 / 22.6 / 23.3 ms)
-        // (after the K1 rework, with the Ritz test from m = 2: 2 pre-steps / test from 3 -> 21.3 ms, 3 / 2 -> 21.3, 4 / 2 -> 20.8: default)
-        const int pre = (e && atoi(e) >= 0 && atoi(e) <= 8) ? atoi(e) : 4;
-        LYS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eig_pre), &pre, sizeof(int)));
-        const char* e2 = getenv("LYS_EIG_MMIN");
-        const int mmin = (e2 && atoi(e2) >= 2 && atoi(e2) <= 8) ? atoi(e2) : 2;
-        LYS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eig_mmin), &mmin, sizeof(int)));
-        pre_set[dev] = 1;
-    }
-    if (pipe_env && idx && link && parts > 0 && k <= 16 && nn_cycles < 0) {
+    // (The single-wave solver runs EIG_PRE = 4 power steps before the Lanczos recurrence and tests the Ritz pair from step
+    // EIG_MMIN = 2 on -- configs[1], same box: 0 / 1 / 2 / 3 pre-steps -> 4.7 / 4.0 / 3.0 / 3.0 Lanczos steps per solve, sweep
+    // 24.0 / 24.8 / 22.6-23.3 / 23.8 ms; after the K1 rework 2 / test from 3 -> 21.3 ms, 3 / 2 -> 21.3, 4 / 2 -> 20.8.  Rounds 3-4
+    // read both from the environment; they are constants of the kernel now.  The four-launch form below stays for the callers
+    // the pipelined sweep does not cover: nn_ksvd, the sharded update, k > 16, n > 64.)
+    if (idx && link && parts > 0 && k <= 16 && nn_cycles < 0) {
         double* Csum = work + (size_t)G64_MAX_PARTS * 4096 / 2;
         float* gpart = reinterpret_cast<float*>(work);
         // link area: [shared partials XL_SH x 64 x 64 floats | nsh K ints | prev / next used atom 2K ints | shrec nnz int4 |
@@ -3201,52 +3179,13 @@ int nn_ksvd_phase(int phase, int atom, float* R, int64_t ldr, int n, int k, cons
     }
 }
 
-// The 2K+2 dependent launches of one cycle are captured once into a hipGraph and replayed while the buffer
-// pointers stay the same (the drop-in learners allocate R/codes/index once per fit): a replayed boundary costs
-// about 1.5 us against 3-4 us of host time per eager launch.
-struct SweepGraphKey {
-    void *R, *row_ptr, *entry, *coef, *sbuf, *D, *Dnext;
-    int64_t ldr;
-    int n, K, k;
-    bool operator==(const SweepGraphKey& o) const {
-        return R == o.R && row_ptr == o.row_ptr && entry == o.entry && coef == o.coef && sbuf == o.sbuf && D == o.D &&
-               Dnext == o.Dnext && ldr == o.ldr && n == o.n && K == o.K && k == o.k;
-    }
-};
-struct SweepGraphCache {
-    bool valid = false;
-    SweepGraphKey key;
-    hipGraphExec_t exec = nullptr;
-    // the caller's stream may be the legacy NULL stream (PyTorch's default), which cannot be captured: the sweep
-    // is captured and replayed on a private stream, ordered against the caller's stream with two events
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-};
-static SweepGraphCache g_sweep_cache[64];
 
 int ksvd_sweep_fused(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry,
                      const int32_t* idx, float* coef, double* sbuf, float* D, float* Dnext, hipStream_t stream) {
     LYS_CHECK_HIP(hipMemsetAsync(sbuf, 0, (size_t)K * (n + 1) * sizeof(double), stream));
-    // optional (LYS_KSVD_BOUNDS_BY_VALUE=1): one small D2H copy per cycle gives every launch its segment bounds by
-    // value.  Measured: no gain (11.59 vs 11.55 ms/sweep) -- the row_ptr load is not on the critical path -- so off.
-    static int byval = -1;
-    if (byval < 0) {
-        const char* e = getenv("LYS_KSVD_BOUNDS_BY_VALUE");
-        byval = (e && e[0] == '1') ? 1 : 0;
-    }
-    static thread_local int32_t* host_rp = nullptr;
-    static thread_local int host_cap = 0;
+    // (handing every launch its segment bounds by value -- one small D2H copy per cycle -- was measured: 11.59 against 11.55 ms
+    // per sweep, the row_ptr load is not on the critical path; removed in round 5)
     const int32_t* rp_host = nullptr;
-    if (byval) {
-        if (host_cap < K + 1) {
-            if (host_rp) (void)hipHostFree(host_rp);
-            LYS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&host_rp), (size_t)(K + 1) * sizeof(int32_t), 0));
-            host_cap = K + 1;
-        }
-        LYS_CHECK_HIP(hipMemcpyAsync(host_rp, row_ptr, (size_t)(K + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        LYS_CHECK_HIP(hipStreamSynchronize(stream));
-        rp_host = host_rp;
-    }
     for (int a = 0; a <= K; ++a) {
         const int rc = ksvd_fused_step(a, K, R, ldr, n, k, row_ptr, entry, idx, coef, sbuf, D, Dnext, stream, rp_host);
         if (rc) return rc;
@@ -3268,49 +3207,9 @@ static int ksvd_sweep_eager(float* R, int64_t ldr, int n, int K, int k, const in
 
 int ksvd_sweep(float* R, int64_t ldr, int n, int K, int k, const int32_t* row_ptr, const int32_t* entry, float* coef,
                double* sbuf, float* D, float* Dnext, hipStream_t stream) {
-    static int use_graph = -1;
-    if (use_graph < 0) {
-        const char* e = getenv("LYS_KSVD_GRAPH");
-        use_graph = (e && e[0] == '1') ? 1 : 0;  // opt-in: measured 17.8 ms/sweep replayed vs 16.4 ms eager at config 2
-                                                 // (the atom kernels' own latency chains dominate, not launches)
-    }
-    int dev = 0;
-    if (!use_graph || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
-        return ksvd_sweep_eager(R, ldr, n, K, k, row_ptr, entry, coef, sbuf, D, Dnext, stream);
-    SweepGraphCache& c = g_sweep_cache[dev];
-    if (!c.stream) {
-        LYS_CHECK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-        LYS_CHECK_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
-        LYS_CHECK_HIP(hipEventCreateWithFlags(&c.ev_out, hipEventDisableTiming));
-    }
-    const SweepGraphKey key{R, (void*)row_ptr, (void*)entry, coef, sbuf, D, Dnext, ldr, n, K, k};
-    if (!(c.valid && c.key == key)) {
-        if (c.exec) {
-            (void)hipGraphExecDestroy(c.exec);
-            c.exec = nullptr;
-        }
-        c.valid = false;
-        hipGraph_t graph = nullptr;
-        LYS_CHECK_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal));
-        const int rc = ksvd_sweep_eager(R, ldr, n, K, k, row_ptr, entry, coef, sbuf, D, Dnext, c.stream);
-        const hipError_t e2 = hipStreamEndCapture(c.stream, &graph);
-        if (rc) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return rc;
-        }
-        LYS_CHECK_HIP(e2);
-        const hipError_t e3 = hipGraphInstantiate(&c.exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        LYS_CHECK_HIP(e3);
-        c.key = key;
-        c.valid = true;
-    }
-    LYS_CHECK_HIP(hipEventRecord(c.ev_in, stream));
-    LYS_CHECK_HIP(hipStreamWaitEvent(c.stream, c.ev_in, 0));
-    LYS_CHECK_HIP(hipGraphLaunch(c.exec, c.stream));
-    LYS_CHECK_HIP(hipEventRecord(c.ev_out, c.stream));
-    LYS_CHECK_HIP(hipStreamWaitEvent(stream, c.ev_out, 0));
-    return LYS_OK;
+    // (replaying the 2 K launches as one hipGraph measured 17.8 against 16.4 ms eager at config 2 -- the atom kernels' own
+    // latency chains dominate, not the launches -- and was removed in round 5)
+    return ksvd_sweep_eager(R, ldr, n, K, k, row_ptr, entry, coef, sbuf, D, Dnext, stream);
 }
 
 

@@ -62,15 +62,7 @@ BkLayout bk_layout(int n, int B) {
     return l;
 }
 
-int bksvd_default_block(int n) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("LYS_KSVD_BLOCK");
-        forced = e ? atoi(e) : 0;
-    }
-    if (forced == 4 || (forced == 8 && n <= 128)) return forced;
-    return (n <= 128) ? 8 : 4;
-}
+int bksvd_default_block(int n) { return (n <= 128) ? 8 : 4; }  // callers may pass 4 explicitly (engine.ksvd_cycle(block=4))
 
 // ---------------------------------------------------------------------------------------------
 // device helpers: a "team" is one 16-lane DPP row; lane q owns features 64*b + 4*q .. +3 (b < FB) of a signal and the
@@ -1075,13 +1067,11 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
 #undef BK_WSTAMP
 }
 
-// The launch: mode 0 = X(c), 1 = Y(c) (see the header), 2 = the FUSED launch Z(c) = [Y(c)] -> [narrow step of block c ||
-// X(c+1)] of the single-GPU lazy schedule: one launch and one kernel boundary per block instead of two.  Only workgroup 0
-// (the narrow step) waits inside the kernel -- for a device-scope counter that every other workgroup bumps when its Y(c)
-// statistics are in; those workgroups never wait for anything, so the launch makes progress whatever the residency (no
-// co-residency requirement, no deadlock).  The two phases are two inlined copies of bksvd_phase: a first version that ran
-// them as iterations of one loop over mutable phase state spilled 123 VGPRs (240 B of scratch per lane, 26 MB of scratch
-// traffic per launch) and made every schedule slower.
+// The launch: mode 0 = X(c), 1 = Y(c) (see the header).  (Rounds 3-4 also carried a FUSED launch Z(c) = Y(c) -> [narrow step of
+// block c || X(c+1)] with device-side arrival counters, opt-in: measured 26.2 us against X 17.4 + Y 8.6 in round 3 and 4.37-4.40
+// against 4.25-4.31 ms per sweep in round 5 -- the narrow workgroup sees the last arrival 1.8 us late and both phases run
+// slower than as launches of their own.  Removed in round 5; the two phases as two inlined copies of bksvd_phase was the
+// lesson kept: as iterations of one loop over mutable phase state the kernel spilled 123 VGPRs.)
 template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
 __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c, int nb, int K, float* __restrict__ R,
                                                                 int64_t ldr, int n, int k,
@@ -1092,39 +1082,13 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                                                                 const int32_t* __restrict__ idx,
                                                                 float* __restrict__ coef, const float* __restrict__ D,
                                                                 float* __restrict__ Dnext, int ldd,
-                                                                double* __restrict__ bbuf, BkLayout lay, int lazy_rt,
-                                                                int* __restrict__ done) {
+                                                                double* __restrict__ bbuf, BkLayout lay, int lazy_rt) {
     constexpr int NTH = 16 * TEAMS;
     extern __shared__ double sm[];  // narrow step / group phase
     // The narrow step is workgroup 0: with ~100 KB of dynamic LDS only one workgroup fits a CU, a launch of 257 on 256 CUs
     // leaves one waiting, and the serial narrow step -- the launch's critical path -- must not be the one that waits.
     int nwg = (int)gridDim.x, bx = (int)blockIdx.x;
 #define BK_PHASE_ARGS nwg, bx, sm, nb, K, R, ldr, n, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, ldd, bbuf, lay, lazy_rt
-    if (mode == 2) {
-        --nwg;
-        --bx;
-        if (bx < 0) {
-            // 16 counters per block (workgroup bx bumps counter bx % 16): no 255-deep queue of device-scope adds on one address
-                        if (threadIdx.x < 16) {
-                const int want = (nwg - (int)threadIdx.x + 15) / 16;
-                while (__hip_atomic_load(done + c * 16 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
-                    __builtin_amdgcn_s_sleep(2);
-            }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of the slab may come from a stale line of this L2
-            bk_narrow_body<LOGB, FB, NTH>(c, K, n, D, Dnext, ldd, bbuf, lay, sm);
-            return;
-        }
-        bksvd_phase<FB, LOGB, SL, TEAMS, FULL>(1, c, BK_PHASE_ARGS);  // Y(c)
-        // Y(c) of this workgroup is in: its statistics were device-scope atomics (performed at the coherence point, not
-        // parked in this XCD's L2), so "every wave has its acknowledgements" + barrier + ONE relaxed device-scope add
-        // publishes them (a release fence at agent scope would write back the whole L2: 100 us when every wave does it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(done + c * 16 + (bx & 15), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c + 1 < nb) bksvd_phase<FB, LOGB, SL, TEAMS, FULL>(0, c + 1, BK_PHASE_ARGS);  // X(c+1) without its narrow step
-        return;
-    }
     if (mode == 0 && c >= 1) {
         --nwg;
         --bx;
@@ -1287,21 +1251,12 @@ int bksvd_lazy(int k, int K) {
     return (!(e && e[0] == '0') && k <= 16 && K <= 8192) ? 1 : 0;
 }
 
-// Fused launches (one per block) for the single-GPU sweep of the lazy schedule: OPT-IN (LYS_BKSVD_FUSED=1).  Measured in
-// round 3 (tools/profile_ksvd.sh, same box): Z(c) 26.2 us against X 17.4 + Y 8.6 -- the kernel boundary it saves (~3.5 us) is
-// spent inside the kernel instead: the narrow workgroup sees the last arrival 1.8 us late (an uncached device-scope load is a
-// fabric round trip) and both phases run ~1 us slower than as launches of their own.  4.13 against 4.19 ms per sweep.
-int bksvd_fused(int k, int K) {
-    const char* e = getenv("LYS_BKSVD_FUSED");
-    return ((e && e[0] == '1') && bksvd_lazy(k, K)) ? 1 : 0;
-}
-
 template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
 static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ldr, int n, int k, const BkIndex& ix,
                             const int32_t* idx, float* coef, const float* D, float* Dnext, double* bbuf,
                             const BkLayout& lay, hipStream_t stream) {
     // only X(c >= 1) runs the narrow step and needs its LDS (up to ~100 KB of the 160 KB of a gfx950 workgroup)
-    const bool narrow = (mode == 0 && c >= 1) || mode == 2;
+    const bool narrow = (mode == 0 && c >= 1);
     const size_t lds = (mode == 1) ? 0 : std::max(narrow ? narrow_lds_bytes(n, 1 << LOGB) : 0, group_lds_bytes(n, 1 << LOGB));
     static bool attr_set[64] = {};
     int dev = 0;
@@ -1317,8 +1272,7 @@ static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ld
     const int grid = (mode == 0 && c >= nb) ? 1 : BK_WBLOCKS;
     hipLaunchKernelGGL((bksvd_step_kernel<FB, LOGB, SL, TEAMS, FULL>), dim3(grid), dim3(16 * TEAMS), lds, stream, mode,
                        c, nb, K, R, ldr, n, k, ix.row_ptr, ix.erec, ix.cg_ptr, ix.cg_entry, idx, coef, D, Dnext,
-                       padded_features(n), bbuf, lay, bksvd_lazy(k, K),
-                       reinterpret_cast<int*>(bbuf + (size_t)((K + (1 << LOGB) - 1) >> LOGB) * (size_t)lay.stride));
+                       padded_features(n), bbuf, lay, bksvd_lazy(k, K));
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -1353,7 +1307,7 @@ int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int 
         return LYS_ENOSUP;
     }
     const int nb = (K + B - 1) / B;
-    if ((mode != 0 && mode != 1 && mode != 2) || c < (mode ? 1 : 0) || c > nb || (mode == 2 && (c >= nb || !bksvd_lazy(k, K)))) {
+    if ((mode != 0 && mode != 1) || c < (mode ? 1 : 0) || c > nb) {
         set_error("bksvd_step: mode %d, block %d of %d", mode, c, nb);
         return LYS_EINVAL;
     }
@@ -1414,7 +1368,8 @@ int bk_debug_timestamps(unsigned long long* out64) {
     return LYS_OK;
 }
 
-// the slabs of all blocks, then 16 ints per block (+ spare): the arrival counters of the fused launches
+// the slabs of all blocks, then (nb + 2) * 8 spare doubles (the arrival counters of the fused launches of rounds 3-4; kept so
+// that the buffer layout callers sized stays the same), then 8: [||R||^2 of the final pass, its valid flag, spare]
 size_t bksvd_stats_doubles(int n, int K, int B) {
     const BkLayout lay = bk_layout(n, B);
     const size_t nb = (size_t)((K + B - 1) / B);
@@ -1444,93 +1399,18 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
     if (rc) return rc;
     LYS_CHECK_HIP(hipMemsetAsync(bbuf, 0, bksvd_stats_doubles(n, K, B) * sizeof(double), stream));
     const int nb = (K + B - 1) / B;
-    auto steps = [&](hipStream_t st) __attribute__((always_inline)) -> int {
-        if (bksvd_fused(k, K)) {
-            // X(0), X(1) = [narrow(0) || walk(1)], then ONE launch per block: Z(c) = Y(c) -> [narrow(c) || X(c+1)]
-            for (int c = 0; c <= (nb > 1 ? 1 : nb); ++c) {
-                const int r = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, st);
-                if (r) return r;
-            }
-            for (int c = 1; c < nb; ++c) {
-                const int r = bksvd_step(2, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, st);
-                if (r) return r;
-            }
-            return bksvd_finish(R, ldr, n, K, k, N, idx, coef, D, Dnext, B, st, bbuf + bksvd_error_offset_doubles(n, K, B));
-        }
-        for (int c = 0; c <= nb; ++c) {
-            int r = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, st);
-            if (r) return r;
-            if (c >= 1) {
-                r = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, st);
-                if (r) return r;
-            }
-        }
-        return bksvd_finish(R, ldr, n, K, k, N, idx, coef, D, Dnext, B, st, bbuf + bksvd_error_offset_doubles(n, K, B));
-    };
-    // LYS_BKSVD_GRAPH=1: the 2 K/B + 1 dependent launches replayed as one hipGraph while the buffers stay the same (the
-    // learners allocate them once per fit).  The first sweep on a device always runs eagerly (function attributes).
-    static int use_graph = -1;
-    if (use_graph < 0) {
-        const char* e = getenv("LYS_BKSVD_GRAPH");
-        use_graph = (e && e[0] == '1') ? 1 : 0;
-    }
-    struct Key {
-        void *R, *row_ptr, *erec, *cg_ptr, *cg_entry, *idx, *coef, *D, *Dnext, *bbuf;
-        int64_t ldr, N;      // N fixes bksvd_finish's grid and argument
-        int n, K, k, B;
-        int lazy, fused;     // the schedule is baked into the captured kernel arguments and launch order
-    };
-    struct Cache {
-        bool warmed = false, valid = false;
-        Key key;
-        hipGraphExec_t exec = nullptr;
-        hipStream_t stream = nullptr;
-        hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    };
-    static Cache cache[64];
-    int dev = 0;
-    if (use_graph && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && cache[dev].warmed) {
-        Cache& c = cache[dev];
-        if (!c.stream) {
-            LYS_CHECK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-            LYS_CHECK_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
-            LYS_CHECK_HIP(hipEventCreateWithFlags(&c.ev_out, hipEventDisableTiming));
-        }
-        Key key;
-        memset(&key, 0, sizeof(Key));      // padding bytes take part in the memcmp below
-        key.R = R; key.row_ptr = row_ptr; key.erec = erec; key.cg_ptr = cg_ptr; key.cg_entry = cg_entry;
-        key.idx = (void*)idx; key.coef = coef; key.D = D; key.Dnext = Dnext; key.bbuf = bbuf;
-        key.ldr = ldr; key.N = N; key.n = n; key.K = K; key.k = k; key.B = B;
-        key.lazy = bksvd_lazy(k, K) ? 1 : 0; key.fused = bksvd_fused(k, K) ? 1 : 0;
-        if (!(c.valid && memcmp(&c.key, &key, sizeof(Key)) == 0)) {
-            if (c.exec) (void)hipGraphExecDestroy(c.exec);
-            c.exec = nullptr;
-            c.valid = false;
-            hipGraph_t graph = nullptr;
-            LYS_CHECK_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal));
-            rc = steps(c.stream);
-            const hipError_t e2 = hipStreamEndCapture(c.stream, &graph);
-            if (rc) {
-                if (graph) (void)hipGraphDestroy(graph);
-                return rc;
-            }
-            LYS_CHECK_HIP(e2);
-            const hipError_t e3 = hipGraphInstantiate(&c.exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            LYS_CHECK_HIP(e3);
-            memcpy(&c.key, &key, sizeof(Key));
-            c.valid = true;
-        }
-        LYS_CHECK_HIP(hipEventRecord(c.ev_in, stream));
-        LYS_CHECK_HIP(hipStreamWaitEvent(c.stream, c.ev_in, 0));
-        LYS_CHECK_HIP(hipGraphLaunch(c.exec, c.stream));
-        LYS_CHECK_HIP(hipEventRecord(c.ev_out, c.stream));
-        LYS_CHECK_HIP(hipStreamWaitEvent(stream, c.ev_out, 0));
-    } else {
-        rc = steps(stream);
+    // 2 K/B + 1 dependent launches.  (Replaying them as one hipGraph, LYS_BKSVD_GRAPH=1 in rounds 2-4, measured 5.40 against
+    // 5.23 ms eager: the launches are back to back already -- rocprofv3 shows no gaps between them; removed in round 5.)
+    for (int c = 0; c <= nb; ++c) {
+        rc = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
         if (rc) return rc;
-        if (dev >= 0 && dev < 64) cache[dev].warmed = true;
+        if (c >= 1) {
+            rc = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
+            if (rc) return rc;
+        }
     }
+    rc = bksvd_finish(R, ldr, n, K, k, N, idx, coef, D, Dnext, B, stream, bbuf + bksvd_error_offset_doubles(n, K, B));
+    if (rc) return rc;
     LYS_CHECK_HIP(hipMemcpyAsync(D, Dnext, (size_t)K * padded_features(n) * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return LYS_OK;
 }

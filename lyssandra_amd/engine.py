@@ -436,8 +436,7 @@ class HipKsvdOps(object):
 
     def sweep_single_gpu(self):
         """All atoms of one cycle in one C call (no per-atom Python / collective), fused K+1-launch form."""
-        import os
-        if os.environ.get("LYS_KSVD_FUSED", "1") != "0" and self.has_fused:
+        if self.has_fused:
             _lib.check(self.lib.lys_ksvd_sweep_fused(_ptr(self.R), _ld(self.R), self.dd.n, self.dd.K, self.k,
                                                      _ptr(self.row_ptr), _ptr(self.entry), _ptr(self.idx),
                                                      _ptr(self.coef), _ptr(self.sbuf), _ptr(self.dd.D),

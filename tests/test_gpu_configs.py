@@ -70,7 +70,7 @@ def test_approx_ksvd_sweep_config2_size(eng, N, cycles):
 def test_approx_ksvd_sweep_dense_coupling_many_signals(eng, n, K, k, N, monkeypatch):
     """Small dictionaries with many signals: most signals use SEVERAL atoms of a block of 8 (1.2e5 coupled signals per block
     at K = 64), more than one round of the group phase holds (a round is 255 workgroups x 128 entries; the entries past it
-    were dropped before round 3: atoms off by 1e-2, residual no longer X - DZ).  All three schedules, against the float64 C
+    were dropped before round 3: atoms off by 1e-2, residual no longer X - DZ).  Both schedules, against the float64 C
     restatement (lyssa/dict_learning/ksvd.py:98-126)."""
     import torch
     from oracle import c_oracle
@@ -80,10 +80,9 @@ def test_approx_ksvd_sweep_dense_coupling_many_signals(eng, n, K, k, N, monkeypa
     Xs = torch.randn((N, n), device="cuda", generator=gen)
     X = Xs.t().contiguous().double().cpu().numpy()
     ref = None
-    # the three schedules: fused launches (opt-in), lazy with separate X / Y launches (default), eager (round 2)
-    for lazy, fused in (("1", "1"), ("1", "0"), ("0", "0")):
+    # the two schedules: lazy apply (default), eager (round 2; what k > 16 runs)
+    for lazy in ("1", "0"):
         monkeypatch.setenv("LYS_BKSVD_LAZY", lazy)
-        monkeypatch.setenv("LYS_BKSVD_FUSED", fused)
         dd = eng.DeviceDictionary(n, K)
         dd.set(Dt)
         idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
@@ -98,7 +97,7 @@ def test_approx_ksvd_sweep_dense_coupling_many_signals(eng, n, K, k, N, monkeypa
         drift = (R[:, :n] - R2[:, :n]).abs().max().item()
         ae = _atom_err(dd.to_host(), Do)
         ce = np.max(np.abs(coef.double().cpu().numpy() - co)) / np.abs(co).max()
-        print("lazy=%s fused=%s n=%d K=%d N=%d: atom err %.3g, code err %.3g, drift %.3g" % (lazy, fused, n, K, N, ae, ce, drift))
+        print("lazy=%s n=%d K=%d N=%d: atom err %.3g, code err %.3g, drift %.3g" % (lazy, n, K, N, ae, ce, drift))
         assert unused == uo
         assert drift < 2e-5 * Xs.abs().max().item(), drift
         assert ae < 1e-5 and ce < 1e-5 and abs(err_dev - err_o) / err_o < 1e-5
@@ -432,10 +431,13 @@ def test_error_constrained_omp_and_large_K_thresh(eng):
     assert np.max(np.abs(Zb - Zo)[:, ok]) < 1e-5 * np.abs(Zo).max()
 
 
-@pytest.mark.parametrize("n,K,N,lam,unit", [(64, 256, 60, 0.15, True), (64, 1024, 40, 0.02, True), (32, 512, 40, 0.01, True),
-                                            (20, 40, 50, 0.1, True), (128, 2048, 24, 0.15, False),
-                                            (128, 8192, 8, 0.05, True)])
-@pytest.mark.parametrize("ws", ["0", "1"])
+_LARS_CASES = [(64, 256, 60, 0.15, True), (64, 1024, 40, 0.02, True), (32, 512, 40, 0.01, True), (20, 40, 50, 0.1, True),
+               (128, 2048, 24, 0.15, False), (128, 8192, 8, 0.05, True)]
+
+
+# every case with the pure homotopy (ws = "0"); K >= 1024 also with the working-set pass in front (below K = 1024 the pass
+# does not exist: same code path)
+@pytest.mark.parametrize("n,K,N,lam,unit,ws", [c + ("0",) for c in _LARS_CASES] + [c + ("1",) for c in _LARS_CASES if c[1] >= 1024])
 def test_lasso_lars_homotopy(eng, n, K, N, lam, unit, ws, monkeypatch):
     """`sparse_encoder('lasso')` through the LARS-lasso homotopy kernel (the algorithm family of spams.lasso(mode=2),
     sparse_coding.py:487-509; SPAMS itself is absent, parity with it is unpinned): KKT conditions in float64, agreement
@@ -445,8 +447,6 @@ def test_lasso_lars_homotopy(eng, n, K, N, lam, unit, ws, monkeypatch):
     first and the homotopy takes the signals it hands on -- the same solution is demanded of both."""
     from sklearn.linear_model import lars_path
     from oracle import lyssa_oracle as orc
-    if ws == "1" and K < 1024:
-        pytest.skip("the working-set pass starts at K = 1024: same code path as ws = 0")
     monkeypatch.setenv("LYS_LASSO_WS", ws)
     rs = np.random.RandomState(n + K)
     D = rs.randn(n, K)

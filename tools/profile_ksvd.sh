@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_w
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc -- $CMD > /dev/null 2> $OUT/pmc_sq.err
 cd $ROOT
 {
-  echo "# command: $CMD  (3 alternations; the sweep = ${STEPS:-257} launches of bksvd_step_kernel per alternation + the index build + the final pass; STEPS=129 with LYS_BKSVD_FUSED=1)"
+  echo "# command: $CMD  (3 alternations; the sweep = ${STEPS:-257} launches of bksvd_step_kernel per alternation + the index build + the final pass)"
   tail -3 $OUT/trace_cmd.out
   python $ROOT/tools/summarize_profile.py $OUT
   echo

@@ -1,6 +1,5 @@
 """From a rocprofv3 kernel-trace (rocpd .db) of tools/ksvd_bench.py: durations of the block-sweep launches of the last
-sweep.  usage: step_durations.py <trace dir> <launches per sweep>: 257 = separate X(c) / Y(c) launches (split reported),
-130 = the fused schedule X(0), X(1), Z(1) .. Z(nb-1) at K = 1024, B = 8."""
+sweep.  usage: step_durations.py <trace dir> <launches per sweep>: 257 = X(0), then X(c), Y(c) for c = 1 .. 128 at K = 1024, B = 8."""
 import glob, sqlite3, sys
 import numpy as np
 f = sorted(glob.glob(sys.argv[1] + "/**/*.db", recursive=True))[0]
@@ -11,15 +10,11 @@ per = int(sys.argv[2]) if len(sys.argv) > 2 else 257
 last = step[-per:]
 d = np.array([e - s for s, e in last]) / 1e3
 gaps = np.array([last[i + 1][0] - last[i][1] for i in range(len(last) - 1)]) / 1e3
-fused = per < 200
-if fused:   # X(0), X(1), Z(1), ..., Z(nb-1)
-    X, Y = d[:2], d[2:]
-else:       # X(0), X(1), Y(1), X(2), Y(2), ...
-    X = np.concatenate([[d[0]], d[1::2]])
-    Y = d[2::2]
+X = np.concatenate([[d[0]], d[1::2]])   # X(0), X(1), Y(1), X(2), Y(2), ...
+Y = d[2::2]
 print("last sweep: %d launches, total kernel %.1f us, span %.1f us, gaps mean %.2f us (sum %.1f)" %
       (len(d), d.sum(), (last[-1][1] - last[0][0]) / 1e3, gaps.mean(), gaps.sum()))
 print("X: mean %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us" % (X.mean(), *np.percentile(X, [10, 50, 90]), X.max()))
-print(("Z" if fused else "Y") + ": mean %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us" % (Y.mean(), *np.percentile(Y, [10, 50, 90]), Y.max()))
+print("Y" + ": mean %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us" % (Y.mean(), *np.percentile(Y, [10, 50, 90]), Y.max()))
 print("X first 12:", np.round(X[:12], 1).tolist())
-print(("Z" if fused else "Y") + " first 12:", np.round(Y[:12], 1).tolist())
+print("Y first 12:", np.round(Y[:12], 1).tolist())

@@ -47,7 +47,8 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         for name, r in rows.items():
             for key, field in (("bomp_wave2_kernel", "bomp_wave_kernel"), ("bomp_wave_kernel", "bomp_wave_kernel"),
                                ("alpha0_n64", "alpha0_n64_kernel"), ("bksvd_step_kernel", "bksvd_step_kernel"),
-                               ("bomp_block_kernel", "bomp_block_kernel"), ("lasso_lars_kernel", "lasso_lars_kernel")):
+                               ("bomp_block_kernel", "bomp_block_kernel"), ("lasso_lars_kernel", "lasso_lars_kernel"),
+                               ("lasso_ws_kernel", "lasso_coder")):
                 if key in name:
                     pmc.setdefault(field, {}).update({c: v for c, v in r.items() if c not in ("n", "dur")})
                     break
