@@ -256,15 +256,15 @@ __device__ __forceinline__ int lws_tri(int i, int q) {
     return hi * (hi + 1) / 2 + lo;
 }
 
-template <int R>
-__global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_ws_kernel(const float* __restrict__ alpha0,
+template <int R, int MAXT>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT == 256 ? 3 : 4))) void lasso_ws_kernel(const float* __restrict__ alpha0,
                                                                          const float* __restrict__ G, int Kp, int K,
                                                                          float lambda, float tol_rel, int max_steps,
                                                                          int kcap, int64_t N, int32_t* __restrict__ idx,
                                                                          float* __restrict__ coef,
                                                                          int32_t* __restrict__ nnz,
                                                                          int32_t* __restrict__ steps_out,
-                                                                         int32_t* __restrict__ rounds_out) {
+                                                                         int32_t* __restrict__ rounds_out, int first_cap) {
     using L = LLay<R>;
     extern __shared__ float lws[];  // Gtri[LWS_TRI], then the atom -> working-set position map (Kp shorts)
     float* Gtri = lws;
@@ -407,23 +407,27 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_ws_kernel(const fl
         const int gather_from = s_state ? 0 : m;
         // when the candidates outnumber the room, the largest first: bisect a threshold (the others come back next round)
         const int room = LWS_M - m;
-        const int target = (round == 0 && room > 96) ? 96 : room;
+        const int target = (round == 0 && room > first_cap) ? first_cap : room;
         float lo = thr0;
         if (tot > target) {
-            float hi = block_max(vmax);
-            for (int it = 0; it < 24; ++it) {  // uniform
+            // the LOWEST threshold that leaves at most `target` candidates (ten halvings of [lambda, max|c|]).  (A first version
+            // stopped at the first threshold with 1 .. target candidates -- the midpoint, ~16 atoms of ~190 -- so that every
+            // signal needed a second round to collect the rest.)
+            float hi = block_max(vmax), best = -1.f;
+            for (int it = 0; it < 10; ++it) {  // uniform
                 const float mid = 0.5f * (lo + hi);
                 int cnt = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) cnt += (((viol >> r) & 1u) && fabsf(c[r]) > mid) ? 1 : 0;
                 const int tc = block_sum(cnt);
                 if (tc > target) lo = mid;
-                else if (tc == 0) hi = mid;
                 else {
-                    lo = mid;
-                    break;
+                    best = mid;
+                    hi = mid;
+                    if (tc == target) break;
                 }
             }
+            if (best >= 0.f) lo = best;  // else: ties above every threshold tried -- the capacity check below drops the surplus
         }
         unsigned sel = 0;
 #pragma unroll
@@ -473,6 +477,7 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_ws_kernel(const fl
             float c0 = (i0 < m) ? s_c[i0] : 0.f, c1 = (i1 < m) ? s_c[i1] : 0.f;
             const float gd0 = (i0 < m) ? Gtri[lws_tri(i0, i0)] : 0.f, gd1 = (i1 < m) ? Gtri[lws_tri(i1, i1)] : 0.f;
             const float gi0 = (gd0 > 0.f) ? 1.f / gd0 : 0.f, gi1 = (gd1 > 0.f) ? 1.f / gd1 : 0.f;
+            const int rb0 = i0 * (i0 + 1) / 2, rb1 = i1 * (i1 + 1) / 2;  // row bases of this lane's two coordinates
             int steps = s_steps;
             while (steps < max_steps) {
                 const float v0 = fmaf(gd0, a0, c0), v1 = fmaf(gd1, a1, c1);
@@ -486,8 +491,10 @@ __global__ __launch_bounds__(64 * LASSO_MAX_WAVES) void lasso_ws_kernel(const fl
                 const int wl = __ffsll((unsigned long long)bal) - 1;
                 const int e = __builtin_amdgcn_readlane(second ? i1 : i0, wl);
                 const float dl = readlane_f(second ? d1 : d0, wl);
-                c0 = fmaf(-dl, Gtri[lws_tri(i0 < m ? i0 : 0, e)], c0);
-                c1 = fmaf(-dl, Gtri[lws_tri(i1 < m ? i1 : 0, e)], c1);
+                // G[i][e] of the packed triangle: row max(i, e), column min(i, e); positions >= m read a valid slot, their c is unused
+                const int rbe = e * (e + 1) / 2;  // uniform
+                c0 = fmaf(-dl, Gtri[(i0 >= e) ? ((i0 < m) ? rb0 + e : rbe) : rbe + i0], c0);
+                c1 = fmaf(-dl, Gtri[(i1 >= e) ? ((i1 < m) ? rb1 + e : rbe) : rbe + i1], c1);
                 a0 += (i0 == e) ? dl : 0.f;
                 a1 += (i1 == e) ? dl : 0.f;
                 ++steps;
@@ -826,13 +833,22 @@ int lasso_ws_from_alpha0(const float* alpha0, const float* G, int Kp, int K, flo
     int dev = 0;
     LYS_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lasso_ws_kernel<16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)(LWS_TRI * sizeof(float) + 32768 * sizeof(short))));
+        const int max_lds = (int)(LWS_TRI * sizeof(float) + 32768 * sizeof(short));
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lasso_ws_kernel<16, 64 * LASSO_MAX_WAVES>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        LYS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lasso_ws_kernel<32, 256>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(lasso_ws_kernel<16>, dim3((unsigned)N), dim3(Kp / 16), lds, stream, alpha0, G, Kp, K, lambda, tol,
-                       max_steps, kcap, N, idx, coef, nnz, steps, rounds);
+    // 32 atoms per lane where the dictionary allows (K <= 8192 in steps of 2048; K = 8192: 256 threads = 4 waves per signal): during the on-chip solve one
+    // wave works and the others wait, and three workgroups of 4 waves fit a CU (51 KB of LDS each) where two of 8 waves did --
+    // more Gram rows in flight per CU and fewer idle waves.  First working set: at most 112 of the 128 slots (see the kernel).
+    if (Kp % 2048 == 0 && Kp <= 8192)
+        hipLaunchKernelGGL((lasso_ws_kernel<32, 256>), dim3((unsigned)N), dim3(Kp / 32), lds, stream, alpha0, G, Kp, K, lambda, tol,
+                           max_steps, kcap, N, idx, coef, nnz, steps, rounds, 112);
+    else
+        hipLaunchKernelGGL((lasso_ws_kernel<16, 64 * LASSO_MAX_WAVES>), dim3((unsigned)N), dim3(Kp / 16), lds, stream, alpha0, G, Kp, K, lambda, tol,
+                           max_steps, kcap, N, idx, coef, nnz, steps, rounds, 112);
     LYS_LAUNCH_CHECK();
     return 1;
 }

@@ -36,7 +36,7 @@ def big(n=128, K=8192, B=32768, lam=0.2):
     dd.set(D / D.norm(dim=0, keepdim=True))
     dd.gram()
     res = {}
-    for name, solver, env in (("working-set cd", "cd", "1"), ("lars + polish", "lars", "1"), ("plain cd", "cd", "0")):
+    for name, solver, env in (("working-set cd", "cd", "1"), ("lars + polish", "lars", "0"), ("plain cd", "cd", "0")):
         if name == "plain cd" and B > 4096:
             Xrun = Xs[:4096]
         else:
