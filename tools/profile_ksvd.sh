@@ -19,7 +19,7 @@ cd $ROOT
   tail -3 $OUT/trace_cmd.out
   python $ROOT/tools/summarize_profile.py $OUT
   echo
-  echo "== per-launch durations of the last sweep (fused: Z(c) = Y(c) -> [narrow step of block c || X(c+1)]; unfused: X(c), Y(c)) =="
+  echo "== per-launch durations of the last sweep: X(0), then X(c), Y(c) for c = 1 .. nb =="
   python $ROOT/tools/step_durations.py $OUT/trace ${STEPS:-257}
 } > $ROOT/gpurun_out/prof_ksvd_${TAG}_summary.txt 2>&1
 find $OUT -name "*.db" -delete
