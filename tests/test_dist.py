@@ -448,6 +448,10 @@ def _worker(rank, world, port, out):  # noqa: C901
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         ld.allreduce_sum_(t)
         assert t.item() == world * (world + 1) / 2
+        # ---- maximum over ranks (lc_ksvd(group=): the number of classes when a shard does not hold every label)
+        tm = torch.tensor([3 + 2 * rank], dtype=torch.int64)
+        ld.allreduce_max_(tm)
+        assert tm.item() == 3 + 2 * (world - 1)
         out[rank] = 1
     finally:
         dist.destroy_process_group()
