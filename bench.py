@@ -321,8 +321,14 @@ def main():
              "device_uuid": device_uuid(dev), "device_name": torch.cuda.get_device_name(dev), "patches_per_s": own_rate,
              "pid": os.getpid()}
     if distributed:
-        idents = [None] * world
-        dist.all_gather_object(idents, ident)
+        # fixed-size byte tensors on this rank's device through the backend's own all_gather (RCCL moves device memory only; no
+        # object collectives, no pickling)
+        raw = json.dumps(ident).encode()[:1024]
+        mine = torch.zeros((1024,), dtype=torch.uint8, device=dev)
+        mine[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        idents = [json.loads(bytes(pt.cpu().tolist()).rstrip(b"\x00").decode()) for pt in parts]
         group_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": idents,
                       "distinct_devices": len(set((i["device_uuid"], i["device_index"]) for i in idents))}
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
