@@ -446,12 +446,26 @@ int lys_covariance(const float* X, int64_t ldx, int n, int64_t N, double* C_dev,
     return covariance(X, ldx, n, N, C_dev, STREAM(stream));
 }
 
+// room at the END of a lasso workspace for the dictionary's three bf16 planes (alpha0 on the bf16 matrix cores, round 5: the
+// l1 coders ran their alpha0 GEMM on the fp32 cores until then -- 0.74 ms of the 8.6-ms configs[3] mini-batch)
+static size_t lasso_split_bytes(int n, int Kp) {
+    return (alpha0_fast_path(n, Kp) || (n > 64 && alpha0_split_path(n, Kp))) ? alpha0_bf16x3_scratch_bytes(Kp, n) + 16 : 0;
+}
+
 size_t lys_lasso_workspace_bytes(int n, int K, int64_t N) {
-    (void)n;
     const int Kp = padded_atoms(K);
     const int64_t t = tile_signals(Kp);
     const int64_t rows = (N <= t) ? ((N < 1) ? 1 : N) : t;
-    return (size_t)rows * (size_t)Kp * sizeof(float);
+    return (size_t)rows * (size_t)Kp * sizeof(float) + lasso_split_bytes(n, Kp);
+}
+
+// carve the split scratch off the end of a lasso workspace (null: an older-sized workspace keeps the fp32 kernel)
+static void* lasso_split_scratch(void* workspace, size_t* workspace_bytes, int n, int Kp) {
+    const size_t sp = lasso_split_bytes(n, Kp);
+    if (!sp || *workspace_bytes < sp + (size_t)Kp * sizeof(float)) return nullptr;
+    *workspace_bytes -= sp;
+    const uintptr_t at = (reinterpret_cast<uintptr_t>(workspace) + *workspace_bytes + 15) & ~(uintptr_t)15;
+    return reinterpret_cast<void*>(at);
 }
 
 // LARS homotopy followed by the coordinate-descent polish (warm start): same problem, same outputs as lys_lasso_encode
@@ -465,6 +479,7 @@ int lys_lasso_lars_encode(const float* X, int64_t ldx, const float* D_packed, co
                 kcap, (double)lambda);
     if (N == 0) return LYS_OK;
     const int Kp = padded_atoms(K), ldd = padded_features(n);
+    void* split = lasso_split_scratch(workspace, &workspace_bytes, n, Kp);
     int64_t rows = (int64_t)(workspace_bytes / ((size_t)Kp * sizeof(float)));
     LYS_REQUIRE(rows >= 1, "lasso_lars_encode: workspace too small (%zu bytes)", workspace_bytes);
     const int64_t pref = tile_signals(Kp);
@@ -474,7 +489,7 @@ int lys_lasso_lars_encode(const float* X, int64_t ldx, const float* D_packed, co
     for (int64_t s0 = 0; s0 < N; s0 += rows) {
         const int64_t cnt = (N - s0 < rows) ? N - s0 : rows;
         int rc;
-        if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, st))) return rc;
+        if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, st, split, s0 > 0))) return rc;
         // round 5: for K >= 1024 the working-set coordinate descent solves the signals whose support stays well below n
         // (every signal at configs[3]'s shape) in a fraction of the homotopy's Gram-row traffic; the homotopy and its
         // polish then run for the signals it flagged only (steps == its marker), everyone else leaves those launches at once
@@ -501,6 +516,7 @@ int lys_lasso_encode(const float* X, int64_t ldx, const float* D_packed, const f
                 "lasso_encode: bad arguments n=%d K=%d kcap=%d lambda=%g", n, K, kcap, (double)lambda);
     if (N == 0) return LYS_OK;
     const int Kp = padded_atoms(K), ldd = padded_features(n);
+    void* split = lasso_split_scratch(workspace, &workspace_bytes, n, Kp);
     int64_t rows = (int64_t)(workspace_bytes / ((size_t)Kp * sizeof(float)));
     LYS_REQUIRE(rows >= 1, "lasso_encode: workspace too small (%zu bytes)", workspace_bytes);
     const int64_t pref = tile_signals(Kp);
@@ -510,7 +526,7 @@ int lys_lasso_encode(const float* X, int64_t ldx, const float* D_packed, const f
     for (int64_t s0 = 0; s0 < N; s0 += rows) {
         const int64_t cnt = (N - s0 < rows) ? N - s0 : rows;
         int rc;
-        if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, st))) return rc;
+        if ((rc = alpha0_any(X + s0 * ldx, ldx, D_packed, ldd, a0, Kp, cnt, n, st, split, s0 > 0))) return rc;
         if ((rc = lasso_from_alpha0(a0, G, Kp, K, lambda, tol, max_steps, kcap, cnt, idx + s0 * kcap, coef + s0 * kcap,
                                     nnz + s0, steps ? steps + s0 : nullptr, st)))
             return rc;
