@@ -1153,6 +1153,27 @@ def test_sweep_error_equals_approx_error(eng, n, K, k, N):
         assert e_sweep is not None and abs(e_sweep - e_ref) <= 2e-6 * e_ref, (cyc, e_sweep, e_ref)
         assert abs(float((R.double() ** 2).sum().item()) - e_sweep) <= 1e-6 * e_ref
         assert eng.sweep_error(buffers) is None        # consumed
+    # n_cycles > 1 on ONE maintained residual (ksvd.py:105: the cycles of approx_ksvd share R; round-4 advice): the value the
+    # patience rule of ksvd_dict_learn reads after the LAST cycle comes from a residual that three sweeps have updated in
+    # place -- its drift against a fresh X - D Z must stay far below what the rule resolves (error_curr > 0.9 * error_prev)
+    R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+    for cyc in range(3):
+        eng.ksvd_cycle(R, dd, idx, coef, nnz, buffers=buffers)
+        if cyc < 2:
+            assert buffers.get("sweep_error_view") is not None   # left by this cycle ...
+    e_sweep = eng.sweep_error(buffers)
+    e_ref = eng.approx_error(Xs, dd, idx, coef, nnz)
+    assert e_sweep is not None and abs(e_sweep - e_ref) <= 1e-5 * e_ref, (e_sweep, e_ref)
+    # ... and a cycle that does not rewrite it must not leave the previous sweep's value behind (round-4 advice): the view is
+    # dropped at the start of every ksvd_cycle, whatever path the cycle takes
+    buffers["sweep_error_view"] = torch.zeros(2, dtype=torch.float64, device="cuda")
+    os.environ["LYS_KSVD_LEGACY"] = "1"
+    try:
+        R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
+        eng.ksvd_cycle(R, dd, idx, coef, nnz, buffers=buffers)
+        assert eng.sweep_error(buffers) is None
+    finally:
+        del os.environ["LYS_KSVD_LEGACY"]
     os.environ["LYS_BKSVD_LAZY"] = "0"
     try:
         R, _ = eng.residual(Xs, dd, idx, coef, nnz, want_R=True, want_err=False)
