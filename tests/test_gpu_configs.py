@@ -657,6 +657,7 @@ def test_bench_self_launch_two_ranks_gloo():
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
+    assert line["fraction_check"] == "ok", line["fraction_check"]          # no roofline fraction above 1 anywhere in the line
     assert "exchange" in line["ksvd_iteration"]["ms"], line["ksvd_iteration"]
     assert "exchange" in line["odl_batch"]["ms"], line["odl_batch"]
     # what a reader needs to verify that the ranks ran (round 5): world size, backend, one entry per rank with its device
@@ -694,7 +695,7 @@ def test_bench_single_process_context(monkeypatch):
     pg = line["process_group"]
     assert pg["world_size"] == 1 and len(pg["devices"]) == 1 and pg["devices"][0]["device_uuid"]
     assert 9.0 < pg["mean_selected_atoms"] <= 10.0                    # k = 10 atoms per patch (a few noise-floor stops)
-    assert 0.0 < line["roofline"]["frac"] <= 1.0
+    assert 0.0 < line["roofline"]["frac"] <= 1.0 and line["fraction_check"] == "ok"
 
 
 def test_ctx_synthetic_multi_device_shards(eng):
