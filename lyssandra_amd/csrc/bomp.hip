@@ -546,8 +546,12 @@ struct BlkState {
 #endif
 };
 
-// Element r (wave-uniform, run-time) of a register vector: the VGPR index mode for R >= 8; LLVM serves a dynamic index into
-// a 4-element vector from scratch, so a select chain there.
+// Element r (wave-uniform, run-time) of a register vector.  R = 16: the VGPR index mode.  R = 8: LLVM expands the dynamic index
+// into compares and selects (8 v_cndmask per read); R = 4: a dynamic index would go through scratch, so a select chain.
+// Round 5 packed the vectors into 16-wide ones so that every read is one indexed v_mov (as bomp_wave2.h does, where it made
+// the K = 512 kernel 1.5x faster): HERE it measured slower -- 13.97 against 12.85 ms per 131072 signals at K = 4096, k = 20,
+// 10.27 against 9.55 ms at K = 2048 -- every read pays its own s_set_gpr_idx_on / off pair (201 pairs in the k = 20 kernel;
+// the compiler does not merge them), and a mode switch costs more than the eight selects it replaces.  Not adopted.
 template <int R, class V>
 __device__ __forceinline__ float blk_elem(const V& v, int r) {
     if constexpr (R == 4) {

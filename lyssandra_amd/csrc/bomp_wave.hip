@@ -6,6 +6,9 @@
 namespace lys {
 
 // (vectors in LDS, unstored tail vectors, waves per SIMD the register budget is bounded for) per (R, KMAX).
+// Round 5 (register vectors packed into 16-wide ones, bomp_wave2.h `State`): K = 512, k = 10 2.43 -> 1.61-1.68 ms per 2^20
+// signals, K = 512, k = 5 0.91 (first kernel) -> 0.72 ms (now served here), K = 256 0.61 -> 0.59 (k = 5) and 1.33 -> 1.19-1.22 ms
+// (k = 10); several signals per wave one after the other (2 / 4 / 8, next row prefetched): no change -- not launch bound.
 // K = 1024, k = 10: 2 vectors in LDS + the last one never stored -> 162 VGPRs, 3 waves per SIMD, 35 KB LDS per 4-wave
 // workgroup (measured, tools/omp_ab2.py: 3 in LDS 2 % slower -- every LDS vector costs 4 ds_read_b128 of latency per step;
 // 1 in LDS spills).
@@ -43,7 +46,7 @@ int bomp_wave2_launch(int Kp, const float* alpha0, const float* G, int64_t N, in
     switch (Kp) {
         case 256: return k <= 5 ? launch_w2<4, 5>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
                                 : launch_w2<4, 10>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
-        case 512: return k <= 5 ? 1  // the first kernel is 10 % faster at (K = 512, k <= 5): tools/gen_ab.py
+        case 512: return k <= 5 ? launch_w2<8, 5>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
                                 : launch_w2<8, 10>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
         case 1024: return k <= 5 ? launch_w2<16, 5>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag)
                                  : launch_w2<16, 10>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);

@@ -45,11 +45,26 @@ struct State {
     static constexpr int NS = KMAX - 1 - NV;  // stored vectors p_0 .. p_{NS-1}
     static constexpr int NREG = NS - NLDS;    // of them in VGPRs
     static_assert(NS >= NLDS && NS >= 0, "more LDS vectors than stored vectors");
-    typedef float pvec_t __attribute__((ext_vector_type(R)));
     // per-wave LDS scalar area: L[j][i] at j*KMAX+i, t_j at SC_T+j, 1/rho_j at SC_I+j (floats)
     static constexpr int SC_T = KMAX * KMAX, SC_I = SC_T + KMAX, SC_FLOATS = SC_I + KMAX;
-    pvec_t a;                      // current correlations (a true vector: element rr readable through the index mode)
-    pvec_t p[NREG > 0 ? NREG : 1];
+    // The register-resident vectors -- logical vector 0 = the current correlations a, 1 + i = p_{NLDS+i} -- are PACKED into
+    // 16-wide register vectors, 16 / R of them each (round 5).  Why: element `rown` of every vector is read with a run-time
+    // (wave-uniform) index in every step, and LLVM serves a dynamic index into a vector of <= 8 floats with a chain of
+    // compares and selects (8 v_cndmask + 8 s_cmp per read; the K = 512 kernel spent 961 of its 1169 VALU instructions
+    // outside the FMAs, more than the K = 1024 kernel in total), into a 16-wide one with the VGPR index mode (one v_mov).
+    static constexpr int PACK = 16 / R;
+    static constexpr int NLOG = 1 + (NREG > 0 ? NREG : 0);
+    static constexpr int N16 = (NLOG + PACK - 1) / PACK;
+    typedef float v16_t __attribute__((ext_vector_type(16)));
+    v16_t vec[N16];
+    __device__ __forceinline__ float get(int j, int r) const { return vec[j / PACK][(j % PACK) * R + r]; }
+    __device__ __forceinline__ void set(int j, int r, float x) { vec[j / PACK][(j % PACK) * R + r] = x; }
+    // element r (run-time, wave-uniform) of logical vector j.  R = 4: the caller makes r opaque -- knowing r < 4 the compiler
+    // served the vectors from scratch (384 B per lane at k = 10) instead of the index mode; against the three-select chain
+    // the index mode measured 0.61 -> 0.59 ms (K = 256, k = 5) and 1.33 -> 1.19 ms (k = 10) per 2^20 signals.
+    __device__ __forceinline__ float dyn(int j, int r) const {
+        return vec[j / PACK][(j % PACK) * R + r];
+    }
     int dxv;                       // lane j = Dx[j]
     unsigned m0;                   // bits of NOISE_REL * max|alpha0|
     unsigned laneoff;              // LDS byte address of this lane's dwordx4 slot of (vector 0, chunk 0)
@@ -119,7 +134,7 @@ __device__ __forceinline__ float elem_dyn(const V& v, int r) {
 // Atom order is (chunk c, lane, element e), so "lowest chunk, then lowest lane, then lowest element" is exactly
 // np.argmax's first maximum, also when several lanes tie (duplicate atoms, zero signals): no separate slow path.
 template <int R, bool STAMP = false, class AV>
-__device__ __forceinline__ bool wave_argmax(const AV& a, int& kk, float& akk, int& Lown, int& rown, unsigned& mbits_out,
+__device__ __forceinline__ bool wave_argmax(const AV& a, int& kk, int& Lown, int& rown, unsigned& mbits_out,
                                             unsigned long long* tmid = nullptr) {
     constexpr int NG = R / 4;
     float m4[NG];
@@ -157,8 +172,10 @@ __device__ __forceinline__ bool wave_argmax(const AV& a, int& kk, float& akk, in
         csel = ne ? c : csel;
     }
     const int Lo = __builtin_ctzll(T);
-    // the owner's group, read with a run-time (wave-uniform) register index
     int q = 3;
+    // the owner's group, read with a run-time (wave-uniform) register index.  (Round 5 tried the lane-local form -- every lane
+    // selects ITS OWN first group holding its maximum with the E masks, 9 v_cndmask beside the DPP reduction, no indexed read
+    // and one index-mode region per step instead of two: K = 1024, k = 10 2.93 against 2.93 ms; not kept.)
     float x[3];
 #pragma unroll
     for (int e = 0; e < 3; ++e) x[e] = a[csel * 4 + e];
@@ -168,8 +185,7 @@ __device__ __forceinline__ bool wave_argmax(const AV& a, int& kk, float& akk, in
         const bool hit = ((fe >> Lo) & 1ull) != 0ull;  // wave-uniform
         q = hit ? e : q;
     }
-    // one more indexed read for the signed value (a select chain over x[] costs three VALU instructions: -1.5 %)
-    akk = readlane_f(elem_dyn<R>(a, csel * 4 + q), Lo);
+    // (the signed value a[kk] is read by the caller, in the same index-mode region as the elements of the stored vectors)
     Lown = Lo;
     rown = csel * 4 + q;
     kk = csel * 256 + Lo * 4 + q;
@@ -205,6 +221,28 @@ __device__ __forceinline__ f32x4 lds_chunk(unsigned addr, int i, int c) {
     return *reinterpret_cast<lds_f32x4*>(addr + (unsigned)((i * C + c) * 1024));
 }
 
+// All of x[0..N-1] are produced before anything behind this point runs (keeps a step's indexed reads adjacent, see `steps`).
+template <int N>
+__device__ __forceinline__ void reads_done(float (&x)[N]) {
+    static_assert(N >= 1 && N <= 10, "one operand per value");
+    if constexpr (N == 1) asm volatile("" : "+v"(x[0]));
+    if constexpr (N == 2) asm volatile("" : "+v"(x[0]), "+v"(x[1]));
+    if constexpr (N == 3) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+    if constexpr (N == 4) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    if constexpr (N == 5) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]));
+    if constexpr (N == 6) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+    if constexpr (N == 7)
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
+    if constexpr (N == 8)
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    if constexpr (N == 9)
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                     "+v"(x[8]));
+    if constexpr (N == 10)
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                     "+v"(x[8]), "+v"(x[9]));
+}
+
 // Steps J..KMAX-1 as a compile-time recursion (see bomp.hip: loops with early exits around convergent cross-lane
 // operations are not unrolled, which would push the state to scratch).
 template <int R, int KMAX, int NLDS, int NV, int J, bool FAST, bool STAMP = false>
@@ -219,10 +257,10 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
     if constexpr (J < KMAX) {
         if (!FAST && J >= k) return;
         int kk, Lown, rown;
-        float akk;
         unsigned mbits;
         unsigned long long tmid = 0;
-        if (!wave_argmax<R, STAMP>(s.a, kk, akk, Lown, rown, mbits, &tmid)) return;
+        if (!wave_argmax<R, STAMP>(s.vec[0], kk, Lown, rown, mbits, &tmid)) return;
+        if constexpr (R == 4) asm("" : "+s"(rown));  // see State::dyn
         if constexpr (STAMP) {
             s.cyc[0] += (unsigned)(tmid - s.tlast);
             s.tlast = tmid;
@@ -269,8 +307,13 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
         if constexpr (VIRT_BEFORE) gsv = G[(int64_t)s.kkv * L::Kp + kk];  // scalar load through the constant cache
         const float gkk = unit_diag ? 1.f : grow[kk];
 
-        // ---- w_i = p_i[kk]  (== L^-1 G[Dx,kk], sparse_coding.py:331,341); the row of L goes to the LDS scalar area
+        // ---- a[kk], and w_i = p_i[kk]  (== L^-1 G[Dx,kk], sparse_coding.py:331,341); the row of L goes to the LDS scalar area.
+        // Element `rown` of a and of every register-resident vector is read in ONE index-mode region: all reads first, one
+        // barrier, then the v_readlanes (round 5).  A v_readlane between two indexed reads closes the region (its source
+        // would be indexed too), and an s_set_gpr_idx_on / off pair costs the chain ~50 cycles (tools/probes/idx_mode_probe.hip:
+        // 84 against 32 ticks per dependent read): the K = 1024 kernel had 2 + up to 4 regions per step.
         float w[KMAX];
+        float akk;
         {
             const float* lf = reinterpret_cast<const float*>(lds);
             const int eo = ((rown >> 2) * 64 + Lown) * 4 + (rown & 3);
@@ -279,10 +322,17 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
                 w[i] = lf[i * C * 256 + eo];  // every lane reads the same word: a broadcast, the value stays in a VGPR
                 sc[J * KMAX + i] = w[i];
             }
+            constexpr int NX = 1 + (NRJ > NLDS ? NRJ - NLDS : 0);  // a, then the register vectors of this step
+            float xv[NX];
+            xv[0] = s.dyn(0, rown);
+#pragma unroll
+            for (int i = NLDS; i < NRJ; ++i) xv[1 + i - NLDS] = s.dyn(1 + i - NLDS, rown);  // lane Lown holds what we want
+            reads_done<NX>(xv);
+            akk = readlane_f(xv[0], Lown);
             float tmp[KMAX];
 #pragma unroll
             for (int i = NLDS; i < NRJ; ++i) {
-                tmp[i] = elem_dyn<R>(s.p[i - NLDS], rown);  // VGPR index mode; lane Lown holds the element we want
+                tmp[i] = xv[1 + i - NLDS];
                 w[i] = readlane_f(tmp[i], Lown);
             }
             if constexpr (NRJ > NLDS) {
@@ -325,8 +375,8 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
                     f32x4 acc = g[c];
 #pragma unroll
                     for (int i = NLDS; i < NRJ; ++i) {
-                        const f32x4 pv = f32x4{s.p[i - NLDS][4 * c], s.p[i - NLDS][4 * c + 1], s.p[i - NLDS][4 * c + 2],
-                                               s.p[i - NLDS][4 * c + 3]};
+                        const f32x4 pv = f32x4{s.get(1 + i - NLDS, 4 * c), s.get(1 + i - NLDS, 4 * c + 1),
+                                               s.get(1 + i - NLDS, 4 * c + 2), s.get(1 + i - NLDS, 4 * c + 3)};
                         fma4(acc, -w[i], pv);
                     }
 #pragma unroll
@@ -336,18 +386,18 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
                         if constexpr (J < NLDS) {
                             lds[(J * C + c) * 64 + lane] = acc;
                         } else {
-                            s.p[J - NLDS][4 * c] = acc.x;
-                            s.p[J - NLDS][4 * c + 1] = acc.y;
-                            s.p[J - NLDS][4 * c + 2] = acc.z;
-                            s.p[J - NLDS][4 * c + 3] = acc.w;
+                            s.set(1 + J - NLDS, 4 * c, acc.x);
+                            s.set(1 + J - NLDS, 4 * c + 1, acc.y);
+                            s.set(1 + J - NLDS, 4 * c + 2, acc.z);
+                            s.set(1 + J - NLDS, 4 * c + 3, acc.w);
                         }
                     }
-                    f32x4 av = {s.a[4 * c], s.a[4 * c + 1], s.a[4 * c + 2], s.a[4 * c + 3]};
+                    f32x4 av = {s.get(0, 4 * c), s.get(0, 4 * c + 1), s.get(0, 4 * c + 2), s.get(0, 4 * c + 3)};
                     fma4(av, -tt, acc);
-                    s.a[4 * c] = av.x;
-                    s.a[4 * c + 1] = av.y;
-                    s.a[4 * c + 2] = av.z;
-                    s.a[4 * c + 3] = av.w;
+                    s.set(0, 4 * c, av.x);
+                    s.set(0, 4 * c + 1, av.y);
+                    s.set(0, 4 * c + 2, av.z);
+                    s.set(0, 4 * c + 3, av.w);
                     if constexpr (NLJ > 0) {
                         if (c + 2 < C) {
                             // chunk c+2 of the LDS vectors reuses chunk c's buffer: issue once chunk c is done
@@ -368,12 +418,12 @@ __device__ __forceinline__ void steps(State<R, KMAX, NLDS, NV>& s, const float* 
         }
         // keep the update above the exit: without this the optimiser sinks the whole vector update (and the Gram-row
         // load with it) below the branch, i.e. behind the extraction chain
-        asm volatile("" : "+v"(s.a));
+        asm volatile("" : "+v"(s.vec[0]));
         __builtin_amdgcn_s_setprio(3);
         if constexpr (STAMP) {
-            float a0 = s.a[0];
+            float a0 = s.vec[0][0];
             W2_STAMP_V(3, a0);
-            s.a[0] = a0;
+            s.vec[0][0] = a0;
         }
         if (stop) return;
         s.nsel = J + 1;
@@ -401,9 +451,9 @@ __device__ __forceinline__ void run_signal(State<R, KMAX, NLDS, NV>& s, const fl
     if constexpr (STAMP) {
         s.cyc[0] = s.cyc[1] = s.cyc[2] = s.cyc[3] = 0;
         tstart = __builtin_amdgcn_s_memtime();
-        float a0 = s.a[0];
+        float a0 = s.vec[0][0];
         s.tlast = stamp_v(a0);  // alpha0 row has landed
-        s.a[0] = a0;
+        s.vec[0][0] = a0;
     }
     steps<R, KMAX, NLDS, NV, 0, FAST, STAMP>(s, G, k, lane, lds_wave, sc, unit_diag);
     const int nsel = s.nsel;
@@ -453,7 +503,10 @@ __device__ __forceinline__ void run_signal(State<R, KMAX, NLDS, NV>& s, const fl
 // Gram-row loads into vmcnt(0), and the loop costs 4 spilled VGPRs; the ~950 cycles a fresh wave waits for its row
 // (5 % of its life) stay.  Touching the row of a workgroup 384 / 768 / 1536 places ahead with one strided load per signal
 // -- an L2 / Infinity-Cache prefetch -- was 8 % slower as well; the persistent loop with the next row loaded into the
-// dead correlation registers behind the back-substitution (ordinary loads, no LDS-DMA): 8 spilled VGPRs, 20 % slower.)
+// dead correlation registers behind the back-substitution (ordinary loads, no LDS-DMA): 8 spilled VGPRs, 20 % slower.
+// Round 5, K <= 512: 2 / 4 / 8 signals per wave one after the other with the next row requested ahead: within 1 % of one
+// signal per wave at K = 256 and 2 % slower at K = 512 -- these kernels are bound by VALU + SALU issue (K = 256, k = 5: 233
+// VALU + 311 SALU instructions per signal, both pipes ~80 % busy at 8 waves per SIMD), not by wave launches.)
 template <int R, int KMAX, int WPS, int NLDS, int NV, bool FAST, int BW = 4, bool STAMP = false>
 __global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* __restrict__ alpha0,
                                                                   const float* __restrict__ G, int64_t N, int k,
@@ -474,10 +527,10 @@ __global__ __launch_bounds__(64 * BW, WPS) void bomp_wave2_kernel(const float* _
     load_row4<R, true>(alpha0 + sig * L::Kp, lane, a4);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        s.a[4 * c] = a4[c].x;
-        s.a[4 * c + 1] = a4[c].y;
-        s.a[4 * c + 2] = a4[c].z;
-        s.a[4 * c + 3] = a4[c].w;
+        s.set(0, 4 * c, a4[c].x);
+        s.set(0, 4 * c + 1, a4[c].y);
+        s.set(0, 4 * c + 2, a4[c].z);
+        s.set(0, 4 * c + 3, a4[c].w);
     }
     run_signal<R, KMAX, NLDS, NV, FAST, STAMP>(s, G, sig, k, lane, s_p + wid * (NLDS * C * 64), s_sc + wid * S::SC_FLOATS,
                                                idx_out, coef_out, nnz_out, unit_diag);
