@@ -17,7 +17,6 @@ int bomp_x_variant(const float* alpha0, const float* G, int64_t N, int k, int32_
     switch (variant) {
         case 100: W2_LAUNCH(3, 2, 0); break;
         case 101: W2_LAUNCH(3, 2, 1); break;
-        case 104: W2_LAUNCH(3, 1, 1); break;
         case 106: W2_LAUNCH(3, 3, 1); break;
         case 107: W2_LAUNCH(3, 3, 0); break;
         case 150: hipLaunchKernelGGL((w2::bomp_wave2_kernel<16, 10, 3, 2, 0, true, 4, true>), grid, block, lds_bytes, stream, alpha0, G, N, k, idx, coef, nnz, 1); break;

@@ -11,7 +11,7 @@ from lyssandra_amd import _lib, engine
 lib = _lib.load()
 n, K, k = 64, 1024, 10
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-variants = [int(v) for v in sys.argv[2:]] or [100, 101, 104]
+variants = [int(v) for v in sys.argv[2:]] or [100, 101, 106]
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
 Dt = torch.randn((n, K), device=dev, generator=g)
