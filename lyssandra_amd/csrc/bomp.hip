@@ -954,8 +954,8 @@ template <int R>
 static int dispatch_k(const float* alpha0, const float* G, int64_t N, int k, int32_t* idx, float* coef, int32_t* nnz,
                       hipStream_t stream, int unit_diag) {
     // (R >= 4, k <= 10) is served by the second-generation kernel (bomp_wave.hip) before this dispatch is reached
-    // (R = 8, k <= 5) stays here as well: measured 0.90 ms against 1.00 ms per 2^20 signals for the second-generation kernel
-    if constexpr (R < 4 || R == 8) {
+    // (round 5: also R = 8, k <= 5 -- 0.72 against 0.91 ms per 2^20 signals since its vectors are read through the index mode)
+    if constexpr (R < 4) {
         if (k <= 5) return launch_wave<R, 5>(alpha0, G, N, k, idx, coef, nnz, stream, unit_diag);
     }
     if constexpr (R < 4) {
