@@ -321,9 +321,10 @@ int lys_ksvd_commit(int n, int K, const int32_t* row_ptr, const float* D_next, f
  *   row_ptr [K+1] / entry_records [N*k records of 16 bytes, 16-byte aligned]: lys_bksvd_index of the current codes = the
  *   by-atom index (a block's entries are one contiguous range) with one record {int32 signal, int32 slot | flags, fp32
  *   coefficient, 0} per entry (flag bit 8: the signal uses another atom of the same block, 9: of the previous block,
- *   10: of the next block, 11: leader entry), so that the common case moves only the residual row; cg_ptr [ceil(K/B) * 2^B + 1] / cg_entry [N*k/2 + 1]: the leaders of
+ *   10: of the next block, 11: leader entry), so that the common case moves only the residual row; cg_ptr [ceil(K/B) * 2^B + 1] / cg_entry [N*k + 1]: the leaders of
  *   the signals that use several atoms of one block (and none of the previous), sorted by (block << B) | in-block atom
- *   mask, for the tuple moments; workspace: lys_bksvd_index_workspace_bytes.  stats fp64
+ *   mask, for the tuple moments -- and, under single-bit masks, the entries whose pending block holds several atoms of
+ *   the signal (lazy schedule: X(c)'s group phase loads their support); workspace: lys_bksvd_index_workspace_bytes.  stats fp64
  *   [lys_bksvd_stats_bytes], zeroed by the caller once per cycle (lys_bksvd_sweep builds the index and zeroes it).
  *   lys_bksvd_layout: out6 = {stride, offQ, offC, offGC, groups, B*(n+2)}; slab c holds per atom t of the block
  *   [sum x R (n), sum x^2, count] at t*(n+2): count == 0 after the reduction <=> unused atom (ksvd.py:112-115).

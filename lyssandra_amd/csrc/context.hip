@@ -831,7 +831,7 @@ static int dev_reserve_sweep(lys_ctx* c, lys_dev* d, int B) {
     CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->row_ptr), (size_t)(c->K + 1) * sizeof(int32_t)));
     CTX_HIP(hipMalloc(&d->erec, nk * 16));
     CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->cg_ptr), ((size_t)nb * ((size_t)1 << B) + 1) * sizeof(int32_t)));
-    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->cg_entry), (nk / 2 + 1) * sizeof(int32_t)));
+    CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->cg_entry), (nk + 1) * sizeof(int32_t)));
     d->stats_bytes = lys_bksvd_stats_bytes(c->n, c->K, B);
     CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->stats), d->stats_bytes));
     CTX_HIP(hipMalloc(reinterpret_cast<void**>(&d->Dnext), (size_t)c->Kp * c->ldd * sizeof(float)));

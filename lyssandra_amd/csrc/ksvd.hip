@@ -349,7 +349,12 @@ __global__ __launch_bounds__(64) void bksvd_index_kernel(const int32_t* __restri
             const bool leader = live && ((a & (bsz - 1)) == __ffs(msk) - 1);
             meta |= coupled ? 0x100 : 0;
             meta |= leader ? 0x800 : 0;
-            if (leader && coupled && !(meta & 0x200)) {
+            // the group phase of X(c) also takes the UNCOUPLED entries whose pending block holds several atoms of the signal
+            // (bit 31: they need the support, which that phase loads anyway; single-bit mask keys, empty before round 5b) --
+            // as queued slow-path entries of the entry walk they kept every walking workgroup for a barrier-separated drain
+            // of ~3 us after its last fast entry
+            const bool several = live && !coupled && (meta < 0);
+            if (((leader && coupled) || several) && !(meta & 0x200)) {
                 const int key = (blk << bsz) | (int)msk;
                 const int pos = atomicAdd(&cg_cur[key], 1);  // count pass: a counter; fill pass: the position
                 if (FILL) cg_entry[pos] = (int32_t)sig;

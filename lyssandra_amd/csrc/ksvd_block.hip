@@ -133,25 +133,30 @@ __device__ __forceinline__ int bk_row_bcast_dyn(int x, int L) {
 }
 
 constexpr int BK_WBLOCKS = 256;  // workgroups of a step launch
+#ifndef BK_GPT
+#define BK_GPT 1
+#endif
 
 // phase timestamps (100 MHz wall clock) of the last launches, read by lys_debug_timestamps: [0..7] narrow step,
 // [32..39] workgroup 0, [48..55] workgroup gridDim/2.  They stay in registers and are written once at the very end (a
 // store inside the kernel would be waited for by the next barrier and distort what it measures).
 __device__ unsigned long long g_bk_stamp[64];
+#ifdef LYS_BK_WGEND
+__device__ unsigned long long g_bk_wg[2 * 260];  // hack build: absolute start / end of every workgroup of the last launch
+#endif
 
 // groups staged in LDS by the narrow step; further non-empty groups (not seen in practice) are read in place
 __host__ __device__ constexpr int bk_maxg(int B) { return ((1 << B) - 1 - B) < 64 ? ((1 << B) - 1 - B) : 64; }
 
 // ---------------------------------------------------------------------------------------------
-// The B sequential atom updates of block c on the aggregated statistics (one workgroup of NTH threads, fp64).
-// Everything is staged in LDS first (the slab was written by atomics: every access to it is a fabric round trip),
-// then the atom loop runs on 4 waves = 16 sixteen-lane teams and costs at most ONE barrier per atom: the teams evaluate
-// the atom's non-empty groups (Horner over the prefix set with 16-lane DPP dot products) into stot[t], barrier, and
-// every team normalises redundantly and writes the same d_new into LDS (no second barrier: a team only reads back what
-// it wrote itself).
+// The B sequential atom updates of block c on the aggregated statistics (one workgroup of NTH threads).
+// Everything is staged in LDS first (the slab was written by atomics: every access to it is a fabric round trip); then
+// ONE wave runs the atoms (its four 16-lane rows are four teams that share a target's groups and meet through
+// v_permlane16/32_swap) while the other waves prepare the groups beside it: every Horner step that does not need the atom the
+// main wave is working on.  See the atom loop for the protocol and for what it replaced.
 // ---------------------------------------------------------------------------------------------
 template <int LOGB, int FB, int NTH>
-__device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D, float* __restrict__ Dnext, int ldd,
+__device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D, float* __restrict__ Dnext, int ldd,
                                const double* __restrict__ bbuf, const BkLayout lay, double* sm) {
     constexpr int B = 1 << LOGB;
     constexpr int G = (1 << B) - 1 - B;
@@ -160,20 +165,18 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     // The slab holds fp64 sums (atomics of ~10^4 fp32 products each); everything after staging runs in fp32: d_new is an
     // fp32 result, so fp32 rounding of the staged sums (6e-8) is the rounding d_new gets anyway, and fp32 buys fused DPP
     // adds, one ds_read_b128 per four features and half the LDS traffic on the serial chain of B atoms.
-    // sm (as floats): dold[B][NF], dnew[B][NF], base[B][NF], stot[B][NF], QC[MAXG][NF+B]
-    __shared__ short gslot[G > 0 ? G : 1];
-    __shared__ short glist[G > 0 ? G : 1];  // non-empty groups in ascending order (grouped by target)
+    // sm (as floats): dold[B][NF], dnew[B][NF], base[B][NF], QC[MAXG][NF+B]
+    __shared__ short glist[G > 0 ? G : 1];  // non-empty groups in ascending order (grouped by target); position < MAXG = staging slot
     __shared__ int gfirst[B + 1];           // first entry of glist per target
     __shared__ float s_cnt[B];
-    __shared__ int s_arrive_v;
-    int* s_arrive = &s_arrive_v;
+    __shared__ int gmid[B + 1];             // per target: first list entry whose prefix set holds atom t - 1 (they end the target's range)
+    __shared__ int s_ndone;                 // atoms 0 .. s_ndone - 1 are final (published by the main wave)
+    __shared__ int s_hdone[B];              // per target: staged groups the helper teams are done with
     float* fm = reinterpret_cast<float*>(sm);
     float* dold = fm;
     float* dnew = dold + (size_t)B * NF;
     float* base = dnew + (size_t)B * NF;
-    float* stot = base + (size_t)B * NF;
-    float* QC = stot + (size_t)B * NF;
-    float* tpart = QC + (size_t)MAXG * (NF + B);  // [2][16 teams][NF]: per-team sums of the groups beyond the staging capacity
+    float* QC = base + (size_t)B * NF;
     const double* bb = bbuf + (int64_t)c * lay.stride;
     const int tid = threadIdx.x, lane = tid & 63, team = tid >> 4, q = tid & 15;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -191,10 +194,10 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
         dold[i] = (float)d0;
         dnew[i] = (float)d0;
         base[i] = (float)sv;
-        stot[i] = 0.f;
     }
     if (tid < B) s_cnt[tid] = (float)bb[(int64_t)tid * (n + 2) + n + 1];
-    if (tid == 0) s_arrive_v = 0;
+    if (tid == 0) s_ndone = 0;
+    if (tid < B) s_hdone[tid] = 0;
     if (tid < 64) {  // wave 0: ordered compaction of the non-empty groups (all count loads first, then ballots)
         constexpr int NW = (G + 63) / 64;
         bool ne[NW];
@@ -210,7 +213,6 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
             const int g = 64 * w + lane;
             bal[w] = __ballot(ne[w]);
             const int pos = basep + __popcll(bal[w] & ((1ull << lane) - 1ull));
-            if (g < G) gslot[g] = ne[w] ? (short)((pos < MAXG) ? pos : -2) : (short)-1;
             if (ne[w]) glist[pos] = (short)g;
             basep += __popcll(bal[w]);
         }
@@ -224,6 +226,18 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
                 cntb += __popcll(bal[w] & msk);
             }
             gfirst[lane] = cntb;
+        }
+        if (lane > B && lane <= 2 * B) {  // gmid[t], t = lane - B - 1: #non-empty groups below g0(t) + 2^(t-1) - 1 (prefix sets ascend inside a target)
+            const int t = lane - B - 1;
+            const int gstart = ((1 << t) - 1 - t) + ((t > 0) ? ((1 << (t - 1)) - 1) : 0);
+            int cntb = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int hi = gstart - 64 * w;
+                const unsigned long long msk = (hi >= 64) ? ~0ull : (hi <= 0) ? 0ull : ((1ull << hi) - 1ull);
+                cntb += __popcll(bal[w] & msk);
+            }
+            gmid[t] = cntb;
         }
     }
     __syncthreads();
@@ -253,41 +267,186 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
     }
     __syncthreads();
     BK_NSTAMP(2);
-    // the atom loop runs on 4 waves (one per SIMD, 16 teams): with more waves the redundant per-team normalisation
-    // below, not the group evaluation, is most of an atom's time.  The other waves were only needed to stage the slab.
-    // Those waves skip the loop and wait at the workgroup barrier behind it; inside the loop the four active waves
-    // synchronise among themselves through an LDS arrival counter (a __syncthreads() that not every thread of the workgroup
-    // reaches is undefined in the HIP model; letting the 12 idle waves take part in the in-loop barriers instead made the
-    // sweep 4x slower).
-    constexpr int NT = 16;  // teams in the atom loop (measured round 3: 4 teams = one wave, no rendezvous: 11.5 us for 8 atoms; 8 teams: 9.5; 16: 8)
-    const bool active = tid < 16 * NT;
-    int arrivals = 0;  // in-loop rendezvous taken so far (uniform over the active waves)
-    int par = 0;       // tpart buffer of the next atom with overflow groups: a team that is ahead writes the OTHER buffer
-    for (int t = 0; active && t < B; ++t) {
-        const int a = c * B + t;
-        if (a >= K) break;
-        if (s_cnt[t] == 0.f) continue;  // unused atom keeps its column (ksvd.py:112-115): dnew[t] == dold[t]; uniform
-        // groups with target t: team j evaluates list entries gfirst[t] + j, + NT, ..
-        const int lbeg = gfirst[t], lend = gfirst[t + 1];
-        // groups beyond the staging capacity (list index >= MAXG) are summed per team, in list order, into the team's own
-        // LDS row (a register accumulator here cost 20 bytes of scratch per lane), and the 16 rows in team order below
-        const bool overflow = lend > MAXG && lend > lbeg;  // uniform
-        float* tp = tpart + (size_t)par * 16 * NF;
-        if (overflow) {
-            par ^= 1;
+    // ---- the atom loop (round 5b): ONE main wave on the chain, the other waves as helpers beside it.
+    // In-kernel core-clock stamps of the 16-team loop this replaces: 2500-2700 cycles per atom = 1250 evaluating the target's
+    // groups (the four teams of a wave run the Horner steps of their groups in lock-step: up to three dependent steps of ~350
+    // cycles), 430-650 in the LDS rendezvous of its four waves, 650 summing ~14 staged slots in list order in every team, 170
+    // normalising.  Only ONE Horner step per group can depend on the atom that was just computed -- the step of atom t - 1 in
+    // a group that targets t -- and the groups that hold atom t - 1 END the target's list range (prefix sets ascend).  So:
+    //   helpers (waves 1.., 4 teams each, list entries h, h + #teams, ..): every Horner step of a staged group EXCEPT the one of
+    //       atom t - 1, as soon as the step's atom is published (s_ndone), result back into the group's slot, then s_hdone[t] += 1;
+    //   main wave (4 teams = its 16-lane rows): waits for s_hdone[t] (normally long there), team j takes list entries lbeg + j,
+    //       + 4, ..: loads the slot, applies the step of atom t - 1 where the entry is past gmid[t] (d_new[t-1] is a register
+    //       vector), sums; the four teams' sums meet through v_permlane16_swap / v_permlane32_swap (gfx950: rows (0,1),(2,3), then
+    //       halves -- every lane ends with the same bits), normalisation, d_new[t] and s_ndone published.
+    // No rendezvous and no slot write-back on the chain.  Groups beyond the staging capacity (small dictionaries with many signals)
+    // are evaluated by the main wave from the slab.  The summation order is fixed by the list (team = position mod 4, ascending
+    // inside a team, teams as ((0+1)+(2+3))): deterministic given the slab, which the multi-GPU protocol needs.
+    constexpr int NHT = (NTH - 64) / 16;  // helper teams
+    static_assert(NHT >= 1, "the narrow step needs at least two waves");
+    // u = P_l (u + cl d_l^old), the new atom given in registers
+    auto project = [&](float4 (&u)[FB], float cl, const float4 (&d0)[FB], const float4 (&dn)[FB]) __attribute__((always_inline)) {
+        float dot = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4 * FB; ++e) tp[team * NF + 64 * (e >> 2) + 4 * q + (e & 3)] = 0.f;
+        for (int b = 0; b < FB; ++b) {
+            u[b].x = fmaf(cl, d0[b].x, u[b].x);
+            u[b].y = fmaf(cl, d0[b].y, u[b].y);
+            u[b].z = fmaf(cl, d0[b].z, u[b].z);
+            u[b].w = fmaf(cl, d0[b].w, u[b].w);
+            dot = fmaf(u[b].x, dn[b].x, dot);
+            dot = fmaf(u[b].y, dn[b].y, dot);
+            dot = fmaf(u[b].z, dn[b].z, dot);
+            dot = fmaf(u[b].w, dn[b].w, dot);
         }
-        for (int li = lbeg + team; li < lend; li += NT) {
-            const int g = glist[li];
-            const int sl = gslot[g];
-            const unsigned pi = (unsigned)(g - ((1 << t) - 1 - t)) + 1u;
-            float4 u[FB];
-            if (sl >= 0) {
-                const float* src = QC + (size_t)sl * (NF + B);
+        dot = bk_row16_sum(dot);
 #pragma unroll
-                for (int b = 0; b < FB; ++b) u[b] = *reinterpret_cast<const float4*>(src + 64 * b + 4 * q);
-            } else {
+        for (int b = 0; b < FB; ++b) {
+            u[b].x = fmaf(-dn[b].x, dot, u[b].x);
+            u[b].y = fmaf(-dn[b].y, dot, u[b].y);
+            u[b].z = fmaf(-dn[b].z, dot, u[b].z);
+            u[b].w = fmaf(-dn[b].w, dot, u[b].w);
+        }
+    };
+    const int nstaged = min(gfirst[B], MAXG);
+    if (tid >= 64) {
+        // ---- helper teams.  A team must never WAIT inside divergent code: the four teams of a wave run in lock-step, and a team
+        // parked in a spin loop for atom l would hold back a wave-mate whose finished entry the main wave needs BEFORE it can
+        // publish atom l (sparse early targets put targets 1 and 3 into one wave: deadlock).  So every team is a small state
+        // machine and the wave polls: a step is taken when its atom is there, the loop ends when all four teams are done.
+        const int h = (tid - 64) >> 4;
+        int li = h, tt = 1;
+        unsigned rest = 0;
+        bool have = false, touched = false;
+        float4 u[FB];
+#pragma unroll
+        for (int b = 0; b < FB; ++b) u[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (;;) {
+            if (!have && li < nstaged) {  // next list entry of this team
+                const int g = glist[li];
+                tt = 1;
+                while (tt < B - 1 && li >= gfirst[tt + 1]) ++tt;  // the entry's target (targets start at 1)
+                const unsigned pi = (unsigned)(g - ((1 << tt) - 1 - tt)) + 1u;
+                rest = pi & ~(1u << (tt - 1));  // every prefix atom but t - 1
+                have = true;
+                touched = false;
+                if (rest) {
+                    const float* slot = QC + (size_t)li * (NF + B);
+#pragma unroll
+                    for (int b = 0; b < FB; ++b) u[b] = *reinterpret_cast<const float4*>(slot + 64 * b + 4 * q);
+                }
+            }
+            if (__ballot(have) == 0ull) break;  // wave-uniform
+            const int nd = __hip_atomic_load(&s_ndone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool progressed = false;
+            if (have) {
+                if (rest == 0u) {  // all early steps taken: result into the slot, entry counted
+                    if (touched) {
+                        float* slot = QC + (size_t)li * (NF + B);
+#pragma unroll
+                        for (int b = 0; b < FB; ++b) *reinterpret_cast<float4*>(slot + 64 * b + 4 * q) = u[b];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (q == 0) __hip_atomic_fetch_add(&s_hdone[tt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    have = false;
+                    li += NHT;
+                    progressed = true;
+                } else {
+                    const int l = __ffs(rest) - 1;
+                    if (nd > l) {  // atom l is final
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const float cl = QC[(size_t)li * (NF + B) + NF + l];
+                        float4 d0[FB], dn[FB];
+#pragma unroll
+                        for (int b = 0; b < FB; ++b) {
+                            d0[b] = *reinterpret_cast<const float4*>(dold + l * NF + 64 * b + 4 * q);
+                            dn[b] = *reinterpret_cast<const float4*>(dnew + l * NF + 64 * b + 4 * q);
+                        }
+                        project(u, cl, d0, dn);
+                        rest &= rest - 1u;
+                        touched = true;
+                        progressed = true;
+                    }
+                }
+            }
+            if (__ballot(progressed) == 0ull) __builtin_amdgcn_s_sleep(2);  // everybody waits for the main wave
+        }
+    } else {
+        // ---- main wave
+        constexpr int NT = 4;                   // teams of the main wave
+        constexpr int NGM = (FB == 1) ? 4 : 2;  // list entries a team loads together
+        const int gfv = gfirst[(lane <= B) ? lane : B];  // lane i holds gfirst[i]
+        const int gmv = gmid[(lane < B) ? lane : B - 1];
+        unsigned used = 0;
+#pragma unroll
+        for (int t = 0; t < B; ++t) used |= (c * B + t < K && s_cnt[t] != 0.f) ? (1u << t) : 0u;  // unused atoms keep their column (ksvd.py:112-115)
+        used = (unsigned)__builtin_amdgcn_readfirstlane((int)used);
+        auto xteam_sum = [&](float x) -> float {  // sum over the four rows, same lane position; identical bits in all rows
+            float va = x, vb = x;
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(va), "+v"(vb));
+            const float s2 = va + vb;
+            float vc = s2, vd = s2;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(vc), "+v"(vd));
+            return vc + vd;
+        };
+        auto publish = [&](int nd) __attribute__((always_inline)) {  // atoms below nd are final: d_new[..] written above by this wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&s_ndone, nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        float4 dcur[FB];
+#pragma unroll
+        for (int b = 0; b < FB; ++b) dcur[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = used ? (__ffs(used) - 1) : B;
+        publish(t);  // the atoms below the first used one keep their columns
+        while (t < B) {
+            const int lb = __builtin_amdgcn_readlane(gfv, t), le = __builtin_amdgcn_readlane(gfv, t + 1);
+            const int lm = __builtin_amdgcn_readlane(gmv, t);
+            const int lstop = (le < MAXG) ? le : MAXG;  // staged entries end here
+            const int tl = (t > 0) ? t - 1 : 0;
+            float4 bs[FB], dl[FB];
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                bs[b] = *reinterpret_cast<const float4*>(base + t * NF + 64 * b + 4 * q);
+                dl[b] = *reinterpret_cast<const float4*>(dold + tl * NF + 64 * b + 4 * q);
+            }
+            if (lstop > lb) {  // uniform: the helpers' part of this target
+                const int need = lstop - lb;
+                while (__hip_atomic_load(&s_hdone[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                    __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            float4 loc[FB];
+#pragma unroll
+            for (int b = 0; b < FB; ++b) loc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int l0 = lb; l0 < lstop; l0 += NT * NGM) {  // uniform trip count
+                float4 uu[NGM][FB];
+                float cc[NGM];
+#pragma unroll
+                for (int i = 0; i < NGM; ++i) {  // all loads first, from clamped addresses
+                    const int li = l0 + team + NT * i;
+                    const float* slot = QC + (size_t)((li < lstop) ? li : lb) * (NF + B);
+#pragma unroll
+                    for (int b = 0; b < FB; ++b) uu[i][b] = *reinterpret_cast<const float4*>(slot + 64 * b + 4 * q);
+                    cc[i] = slot[NF + tl];
+                }
+#pragma unroll
+                for (int i = 0; i < NGM; ++i) {
+                    const int li = l0 + team + NT * i;
+                    if (li < lstop) {
+                        if (li >= lm) project(uu[i], cc[i], dl, dcur);  // the step of atom t - 1
+#pragma unroll
+                        for (int b = 0; b < FB; ++b) {
+                            loc[b].x += uu[i][b].x;
+                            loc[b].y += uu[i][b].y;
+                            loc[b].z += uu[i][b].z;
+                            loc[b].w += uu[i][b].w;
+                        }
+                    }
+                }
+            }
+            for (int li = ((lb > lstop) ? lb : lstop) + team; li < le; li += NT) {  // beyond the staging capacity: from the slab, every step through LDS
+                const int g = glist[li];
+                const unsigned pi = (unsigned)(g - ((1 << t) - 1 - t)) + 1u;
+                float4 u[FB];
 #pragma unroll
                 for (int b = 0; b < FB; ++b) {
                     const int f = 64 * b + 4 * q;
@@ -296,112 +455,57 @@ __device__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D,
                     u[b].z = (f + 2 < n) ? (float)bb[lay.offQ + (int64_t)g * n + f + 2] : 0.f;
                     u[b].w = (f + 3 < n) ? (float)bb[lay.offQ + (int64_t)g * n + f + 3] : 0.f;
                 }
-            }
-            // Horner: u = P_l (u + c_l d_l^old), l ascending over the prefix set.  The loop runs over the SET bits (a
-            // wave's four teams hold different prefix sets: a loop over all l < t would execute the body for the union)
-            for (unsigned rest = pi; rest; rest &= rest - 1) {
-                const int l = __ffs(rest) - 1;
-                const float cl = (sl >= 0) ? QC[(size_t)sl * (NF + B) + NF + l] : (float)bb[lay.offC + (int64_t)g * B + l];
-                float4 dn[FB];
-                float dot = 0.f;
+                for (unsigned rest = pi; rest; rest &= rest - 1) {
+                    const int l = __ffs(rest) - 1;
+                    const float cl = (float)bb[lay.offC + (int64_t)g * B + l];
+                    float4 d0[FB], dn[FB];
+#pragma unroll
+                    for (int b = 0; b < FB; ++b) {
+                        d0[b] = *reinterpret_cast<const float4*>(dold + l * NF + 64 * b + 4 * q);
+                        dn[b] = *reinterpret_cast<const float4*>(dnew + l * NF + 64 * b + 4 * q);  // written by this wave
+                    }
+                    project(u, cl, d0, dn);
+                }
 #pragma unroll
                 for (int b = 0; b < FB; ++b) {
-                    const float4 d0 = *reinterpret_cast<const float4*>(dold + l * NF + 64 * b + 4 * q);
-                    dn[b] = *reinterpret_cast<const float4*>(dnew + l * NF + 64 * b + 4 * q);
-                    u[b].x = fmaf(cl, d0.x, u[b].x);
-                    u[b].y = fmaf(cl, d0.y, u[b].y);
-                    u[b].z = fmaf(cl, d0.z, u[b].z);
-                    u[b].w = fmaf(cl, d0.w, u[b].w);
-                    dot = fmaf(u[b].x, dn[b].x, dot);
-                    dot = fmaf(u[b].y, dn[b].y, dot);
-                    dot = fmaf(u[b].z, dn[b].z, dot);
-                    dot = fmaf(u[b].w, dn[b].w, dot);
-                }
-                dot = bk_row16_sum(dot);
-#pragma unroll
-                for (int b = 0; b < FB; ++b) {
-                    u[b].x = fmaf(-dn[b].x, dot, u[b].x);
-                    u[b].y = fmaf(-dn[b].y, dot, u[b].y);
-                    u[b].z = fmaf(-dn[b].z, dot, u[b].z);
-                    u[b].w = fmaf(-dn[b].w, dot, u[b].w);
+                    loc[b].x += u[b].x;
+                    loc[b].y += u[b].y;
+                    loc[b].z += u[b].z;
+                    loc[b].w += u[b].w;
                 }
             }
-            // the result replaces the group's moments in its staged slot; the slots are summed below in LIST ORDER, so
-            // the narrow step is deterministic given the slab (replicas on several GPUs must stay bit-identical)
-            if (sl >= 0) {
-                float* dst = QC + (size_t)sl * (NF + B);
+            // s = S_t + d_old sum x^2 + groups, d_new = s / (||s|| + eps)  (utils/math.py:61-62; eps only matters for s = 0,
+            // where the result is the zero vector either way)
+            float v2 = 0.f;
+            float4 sv[FB];
 #pragma unroll
-                for (int b = 0; b < FB; ++b) *reinterpret_cast<float4*>(dst + 64 * b + 4 * q) = u[b];
-            } else {
-                // group beyond the staging capacity (small dictionaries with many signals: K = 48 has > 64 occupied groups
-                // per block): into this team's private sum -- list order inside a team, team order below.  (Unordered LDS
-                // atomics here made the replicas of a 2-rank run differ in the last bit of a block's LAST atom, the target
-                // with the most groups.)
+            for (int b = 0; b < FB; ++b) {
+                sv[b].x = bs[b].x + xteam_sum(loc[b].x);
+                sv[b].y = bs[b].y + xteam_sum(loc[b].y);
+                sv[b].z = bs[b].z + xteam_sum(loc[b].z);
+                sv[b].w = bs[b].w + xteam_sum(loc[b].w);
+                v2 = fmaf(sv[b].x, sv[b].x, v2);
+                v2 = fmaf(sv[b].y, sv[b].y, v2);
+                v2 = fmaf(sv[b].z, sv[b].z, v2);
+                v2 = fmaf(sv[b].w, sv[b].w, v2);
+            }
+            v2 = bk_row16_sum(v2);
+            float scale = 0.f;
+            if (v2 > 0.f) {
+                const float y = __builtin_amdgcn_rsqf(v2);
+                scale = y * fmaf(-0.5f * v2 * y, y, 1.5f);  // one Newton step on the 1-ulp hardware estimate
+            }
 #pragma unroll
-                for (int b = 0; b < FB; ++b) {
-                    float* row = tp + team * NF + 64 * b + 4 * q;  // (scalar accesses: a float4 temporary here went to scratch)
-                    row[0] += u[b].x;
-                    row[1] += u[b].y;
-                    row[2] += u[b].z;
-                    row[3] += u[b].w;
-                }
+            for (int b = 0; b < FB; ++b) {
+                dcur[b] = make_float4(sv[b].x * scale, sv[b].y * scale, sv[b].z * scale, sv[b].w * scale);
+                if (team == 0) *reinterpret_cast<float4*>(dnew + t * NF + 64 * b + 4 * q) = dcur[b];
             }
+            const unsigned above = used & ~((2u << t) - 1u);
+            const int tn = above ? (__ffs(above) - 1) : B;  // next used atom: the ones in between keep their columns
+            publish(tn);
+            if (t == 0) BK_NSTAMP(3);
+            t = tn;
         }
-        if (lend > lbeg) {  // uniform over the active waves: every team's slots are written before any team sums them
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            arrivals += NT / 4;
-            if ((tid & 63) == 0) {
-                atomicAdd(s_arrive, 1);
-                while (__hip_atomic_load(s_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < arrivals)
-                    __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        // every team: s = S_t + d_old sum x^2 + groups, d_new = s / (||s|| + eps)  (utils/math.py:61-62; eps only matters
-        // for s = 0, where the result is the zero vector either way)
-        float4 sv[FB];
-        float v2 = 0.f;
-#pragma unroll
-        for (int b = 0; b < FB; ++b) {
-            const float4 b4 = *reinterpret_cast<const float4*>(base + t * NF + 64 * b + 4 * q);
-            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (overflow) {
-#pragma unroll 4
-                for (int j = 0; j < NT; ++j) {
-                    const float* pr = tp + j * NF + 64 * b + 4 * q;
-                    s4.x += pr[0];
-                    s4.y += pr[1];
-                    s4.z += pr[2];
-                    s4.w += pr[3];
-                }
-            }
-            // the list position IS the staging slot (both count the non-empty groups in ascending order): no indirection
-            const int lstop = (lend < MAXG) ? lend : MAXG;
-#pragma unroll 4
-            for (int li = lbeg; li < lstop; ++li) {
-                const float4 g4 = *reinterpret_cast<const float4*>(QC + (size_t)li * (NF + B) + 64 * b + 4 * q);
-                s4.x += g4.x;
-                s4.y += g4.y;
-                s4.z += g4.z;
-                s4.w += g4.w;
-            }
-            sv[b] = make_float4(b4.x + s4.x, b4.y + s4.y, b4.z + s4.z, b4.w + s4.w);
-            v2 = fmaf(sv[b].x, sv[b].x, v2);
-            v2 = fmaf(sv[b].y, sv[b].y, v2);
-            v2 = fmaf(sv[b].z, sv[b].z, v2);
-            v2 = fmaf(sv[b].w, sv[b].w, v2);
-        }
-        v2 = bk_row16_sum(v2);
-        float scale = 0.f;
-        if (v2 > 0.f) {
-            const float y = __builtin_amdgcn_rsqf(v2);
-            scale = y * fmaf(-0.5f * v2 * y, y, 1.5f);  // one Newton step on the 1-ulp hardware estimate
-        }
-#pragma unroll
-        for (int b = 0; b < FB; ++b)
-            *reinterpret_cast<float4*>(dnew + t * NF + 64 * b + 4 * q) =
-                make_float4(sv[b].x * scale, sv[b].y * scale, sv[b].z * scale, sv[b].w * scale);
-        if (t == 0) BK_NSTAMP(3);
     }
     BK_NSTAMP(4);
     __syncthreads();
@@ -492,8 +596,8 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
     bool walks = true;
     if (mode == 0 && have_c) {
         const int kb0 = c << B;
-        const int ngw = (cg_ptr[kb0 + (1 << B)] - cg_ptr[kb0] + 2 * TEAMS - 1) / (2 * TEAMS);
-        if (ngw * 4 <= nwg) {
+        const int ngw = (cg_ptr[kb0 + (1 << B)] - cg_ptr[kb0] + BK_GPT * TEAMS - 1) / (BK_GPT * TEAMS);
+        if (ngw * 2 <= nwg) {
             walks = bx >= ngw;
             gteam = (bx - ngw) * TEAMS + team;
             nteams = (nwg - ngw) * TEAMS;
@@ -744,27 +848,25 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
     constexpr int ROLE_ACC = 0, ROLE_COLLECT = 1, ROLE_APPLY = 2;
     auto run_fast = [&](int role, int ent, int emt, float ecf, float epc, int j0, int e_base) __attribute__((always_inline)) {
         float4 rr[U][FB];
-        unsigned sg[U];
         int mt[U];  // slot, bit 31 = nothing to do, bit 30 = queue
-        float xe[U];
         int pa[U];  // lazy: pending atom of the signal (-1: none), its slot in bits 24-29
-        float xp[U];
+        // (the signal id and the two coefficients of an entry are broadcast again where they are used: as arrays they cost 24
+        // VGPRs of a kernel that sits at its 128-register limit)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned sig = (unsigned)bk_row_bcast_dyn(ent, j0 + u);
             int m = bk_row_bcast_dyn(emt, j0 + u);
-            xe[u] = __builtin_bit_cast(float, bk_row_bcast_dyn(__builtin_bit_cast(int, ecf), j0 + u));
-            xp[u] = __builtin_bit_cast(float, bk_row_bcast_dyn(__builtin_bit_cast(int, epc), j0 + u));
             pa[u] = -1;
             bool skip, slow;
             if (role == ROLE_ACC) {
                 if (lazy) {
                     // coupled signals (any entry) belong to the group phase, which has the support and applies the pending
-                    // block itself; a single pending atom is applied right here, several go to the slow path
-                    skip = ((m & F_PREV) && p >= 0) || (m & F_COUPLED);
+                    // block itself; a single pending atom is applied right here
+                    // ... and so do the entries with several pending atoms (bit 31; lys_bksvd_index lists them with the coupled leaders)
                     const int ps = (m >> 12) & 63;
-                    slow = (ps != 63) && (m < 0);
-                    pa[u] = (ps != 63 && !slow) ? (((m >> 18) & 0x1fff) | (ps << 24)) : -1;
+                    skip = ((m & F_PREV) && p >= 0) || (m & F_COUPLED) || ((ps != 63) && (m < 0));
+                    slow = false;
+                    pa[u] = (ps != 63) ? (((m >> 18) & 0x1fff) | (ps << 24)) : -1;
                 } else {
                     skip = ((m & F_PREV) && p >= 0) || ((m & F_COUPLED) && !(m & F_LEADER));
                     slow = false;
@@ -778,7 +880,6 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
             }
             skip = skip || (e_base + u >= tend);
             m = (m & 63) | (skip ? (int)0x80000000 : 0) | ((slow && !skip) ? 0x40000000 : 0);
-            sg[u] = sig;
             mt[u] = m;
 #pragma unroll
             for (int b = 0; b < FB; ++b) {
@@ -797,32 +898,35 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
                 rp_next = s_rp[which][tpos + 1];
             }
             if (mt[u] < 0) continue;  // nothing to do
+            const unsigned sg_u = (unsigned)bk_row_bcast_dyn(ent, j0 + u);
+            const float xe_u = __builtin_bit_cast(float, bk_row_bcast_dyn(__builtin_bit_cast(int, ecf), j0 + u));
+            const float xp_u = __builtin_bit_cast(float, bk_row_bcast_dyn(__builtin_bit_cast(int, epc), j0 + u));
             if (mt[u] & 0x40000000) {
                 if (q == 0) {
                     const int slot = atomicAdd(&s_qn, 1);  // < NTH: at most 16 entries per team and batch
-                    s_q[slot][0] = (int)sg[u];
+                    s_q[slot][0] = (int)sg_u;
                     s_q[slot][1] = tpos;
-                    s_q[slot][2] = __builtin_bit_cast(int, xe[u]);
-                    s_q[slot][3] = (role == ROLE_APPLY) ? 1 : (role == ROLE_ACC) ? 2 : 0;
+                    s_q[slot][2] = __builtin_bit_cast(int, xe_u);
+                    s_q[slot][3] = (role == ROLE_APPLY) ? 1 : 0;
                 }
                 continue;
             }
             if (role == ROLE_APPLY) {
-                const float xn = apply_atom(rr[u], tpos, xe[u]);
-                store_row(rr[u], sg[u]);
+                const float xn = apply_atom(rr[u], tpos, xe_u);
+                store_row(rr[u], sg_u);
                 if (q == 0)
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(coef) + (sg[u] * ksz + 4u * (unsigned)(mt[u] & 63))) = xn;
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(coef) + (sg_u * ksz + 4u * (unsigned)(mt[u] & 63))) = xn;
             } else {
                 if (pa[u] >= 0) {  // lazy: the pending atom first (uniform per team)
                     float4 d0[FB], dn[FB];
                     load_atom(D, pa[u] & 0x1fff, d0);
                     load_atom(Dnext, pa[u] & 0x1fff, dn);
-                    const float xn = apply_atom_rows(rr[u], d0, dn, xp[u]);
-                    store_row(rr[u], sg[u]);
+                    const float xn = apply_atom_rows(rr[u], d0, dn, xp_u);
+                    store_row(rr[u], sg_u);
                     if (q == 0)
-                        *reinterpret_cast<float*>(reinterpret_cast<char*>(coef) + (sg[u] * ksz + 4u * (unsigned)((pa[u] >> 24) & 63))) = xn;
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(coef) + (sg_u * ksz + 4u * (unsigned)((pa[u] >> 24) & 63))) = xn;
                 }
-                accumulate_one(rr[u], xe[u], tpos);
+                accumulate_one(rr[u], xe_u, tpos);
             }
         }
     };
@@ -855,11 +959,7 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
         }
         m = bk_row16_or(m);  // masks of block p (bits 0-7) and block c (8-15)
         const unsigned mp = m & 0xffu, mc = m >> 8;
-        if (kind == 2) {
-            // X(c), lazy: an uncoupled entry whose pending block holds several atoms of the signal
-            apply_pending(r, a, x, sig);
-            accumulate_one(r, x1, tp);
-        } else if (is_apply) {
+        if (is_apply) {
             if (__ffs(mp) - 1 != tp) return;  // not the signal's leader entry in block p
             if (mc) return;                   // also in block c: its list-c entry was collected as PREV
             apply_block(r, a, x, sig, mp);
@@ -910,7 +1010,7 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
                     if (left > j0) run_fast(role, ent, emt, ecf, epc, j0, e0 + j0);
             }
             if (bo == 0 && role != ROLE_COLLECT) BK_WSTAMP(6);
-            if (role == ROLE_ACC && !lazy) continue;  // X(c) queues nothing (lazy: entries with several pending atoms)
+            if (role == ROLE_ACC) continue;  // X(c) queues nothing
             const bool last = bo + 16 >= chunk;
             if (!(defer && last)) {
                 drain();
@@ -926,12 +1026,11 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
     if (mode == 0) {
         if (walks) {  // uniform per workgroup
             walk(ROLE_ACC, c, 1, true);
-            if (lazy) drain();
         }
         BK_WSTAMP(3);
         // ---- group phase: tuple moments of the coupled signals of block c (their leaders, sorted by in-block mask).
         // Workgroup w takes the entries [w * GCH, (w + 1) * GCH) of the block's range, 2 per team (loaded together).
-        constexpr int GPT = 2;
+        constexpr int GPT = BK_GPT;
         constexpr int GCH = GPT * TEAMS;
         constexpr int NS = 24;                   // LDS slots of (NF + B + 1) doubles each, in the dynamic LDS
         constexpr int SW = FB * 64 + B + 1;
@@ -1021,6 +1120,12 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
                             accumulate_one(r[u], x1, t1);
                         }
                         coupled_grouped(r[u], a[u], x[u], t1, x1, m2, gq, s_gslot);
+                    } else if (lazy && mk[u]) {
+                        // an uncoupled entry whose pending block holds several atoms of the signal (single-bit key)
+                        const int t1 = __ffs(mk[u]) - 1;
+                        const float x1 = value_of(a[u], x[u], c * B + t1);
+                        apply_pending(r[u], a[u], x[u], (unsigned)cg_entry[lo + team * GPT + u]);
+                        accumulate_one(r[u], x1, t1);
                     }
                 }
             }
@@ -1089,16 +1194,26 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
     // leaves one waiting, and the serial narrow step -- the launch's critical path -- must not be the one that waits.
     int nwg = (int)gridDim.x, bx = (int)blockIdx.x;
 #define BK_PHASE_ARGS nwg, bx, sm, nb, K, R, ldr, n, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, ldd, bbuf, lay, lazy_rt
+#ifdef LYS_BK_WGEND
+    if (threadIdx.x == 0) g_bk_wg[2 * blockIdx.x] = (unsigned long long)wall_clock64();
+#endif
     if (mode == 0 && c >= 1) {
         --nwg;
         --bx;
         if (bx < 0) {
             bk_narrow_body<LOGB, FB, NTH>(c - 1, K, n, D, Dnext, ldd, bbuf, lay, sm);
+#ifdef LYS_BK_WGEND
+            if (threadIdx.x == 0) g_bk_wg[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+#endif
             return;
         }
     }
     if (mode == 0 && c >= nb) return;  // X(nb): only the narrow step of the last block
     bksvd_phase<FB, LOGB, SL, TEAMS, FULL>(mode, c, BK_PHASE_ARGS);
+#ifdef LYS_BK_WGEND
+    __syncthreads();
+    if (threadIdx.x == 0) g_bk_wg[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+#endif
 #undef BK_PHASE_ARGS
 }
 
@@ -1241,7 +1356,7 @@ static size_t group_lds_bytes(int n, int B) {  // LDS slots of X(c)'s group phas
 static size_t narrow_lds_bytes(int n, int B) {
     const size_t nf = (size_t)((n + 63) / 64) * 64;
     (void)n;
-    return ((size_t)4 * B * nf + (size_t)bk_maxg(B) * (nf + B) + (size_t)2 * 16 * nf) * sizeof(float);
+    return ((size_t)3 * B * nf + (size_t)bk_maxg(B) * (nf + B)) * sizeof(float);
 }
 
 // The lazy schedule needs the predecessor fields of the index records, which only the k <= 16 index builder writes
@@ -1365,6 +1480,9 @@ int bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, const in
 
 int bk_debug_timestamps(unsigned long long* out64) {
     LYS_CHECK_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_bk_stamp), 64 * sizeof(unsigned long long)));
+#ifdef LYS_BK_WGEND
+    LYS_CHECK_HIP(hipMemcpyFromSymbol(out64 + 64, HIP_SYMBOL(g_bk_wg), 520 * sizeof(unsigned long long)));
+#endif
     return LYS_OK;
 }
 

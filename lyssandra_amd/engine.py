@@ -473,7 +473,7 @@ class HipBlockKsvdOps(object):
             buffers["brow_ptr"] = torch.empty((dd.K + 1,), dtype=torch.int32, device=dd.device)
             buffers["berec"] = torch.empty((max(1, self.N * self.k), 4), dtype=torch.int32, device=dd.device)  # 16-B records
             buffers["bcg_ptr"] = torch.empty((self.nb * (1 << self.B) + 1,), dtype=torch.int32, device=dd.device)
-            buffers["bcg_entry"] = torch.empty((self.N * self.k // 2 + 1,), dtype=torch.int32, device=dd.device)
+            buffers["bcg_entry"] = torch.empty((self.N * self.k + 1,), dtype=torch.int32, device=dd.device)
             # the library's size: the slabs of all blocks + the arrival counters of the fused launches behind them
             nd = int(lib.lys_bksvd_stats_bytes(dd.n, dd.K, self.B)) // 8
             assert nd >= self.nb * self.stride
