@@ -431,29 +431,83 @@ __global__ __launch_bounds__(1024) void csr_scan_apply_kernel(int32_t* __restric
     }
 }
 
-// row_ptr = exclusive scan of the K atom totals (single block, K <= 16384)
+// row_ptr = exclusive scan of the K totals (single workgroup; K atoms, or the (block, mask) keys of the coupled-leader index:
+// 32 768 at configs[1]).  Every thread owns a contiguous run of `per` elements.  Round 5b: the run is loaded ONCE with 16-byte
+// loads and kept in registers (per <= 32, 16-byte aligned: both callers at configs[1]), the thread sums are scanned per wave
+// with shuffles and across the 16 waves through LDS (two barriers instead of the twenty of a 1024-wide Hillis-Steele scan) --
+// the old form read every element twice with 4-byte loads a cache line apart per lane: 50 us for the 32 768 keys.
 __global__ __launch_bounds__(1024) void csr_scan_totals_kernel(const int32_t* __restrict__ totals, int K,
                                                                int32_t* __restrict__ row_ptr) {
-    __shared__ int s_part[1024];
-    const int t = threadIdx.x;
+    __shared__ int s_wave[16];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int per = (K + 1023) / 1024;
     const int b = t * per, e = (b + per < K) ? b + per : K;
+    const bool fast = (per <= 32) && ((per & 3) == 0) && ((reinterpret_cast<uintptr_t>(totals) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(row_ptr) & 15) == 0);  // uniform
+    int4 v[8];
     int sum = 0;
-    for (int i = b; i < e; ++i) sum += totals[i];
-    s_part[t] = sum;
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int at = b + 4 * i;
+            v[i] = make_int4(0, 0, 0, 0);
+            if (4 * i < per && at + 3 < K) {
+                v[i] = *reinterpret_cast<const int4*>(totals + at);
+            } else if (4 * i < per && at < K) {  // the last, ragged quad of the array
+                v[i].x = totals[at];
+                v[i].y = (at + 1 < K) ? totals[at + 1] : 0;
+                v[i].z = (at + 2 < K) ? totals[at + 2] : 0;
+            }
+            sum += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    } else {
+        for (int i = b; i < e; ++i) sum += totals[i];
+    }
+    // inclusive scan of the thread sums: shuffles inside a wave, the 16 wave totals through LDS
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        inc += (lane >= off) ? o : 0;
+    }
+    if (lane == 63) s_wave[wid] = inc;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = (t >= off) ? s_part[t - off] : 0;
-        __syncthreads();
-        s_part[t] += v;
-        __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int x = s_wave[w];
+        wbase += (w < wid) ? x : 0;
+        total += x;
     }
-    int run = (t == 0) ? 0 : s_part[t - 1];
-    for (int i = b; i < e; ++i) {
-        row_ptr[i] = run;
-        run += totals[i];
+    int run = wbase + inc - sum;  // exclusive prefix of this thread's run
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int at = b + 4 * i;
+            if (4 * i < per && at < K) {
+                int4 o;
+                o.x = run;
+                o.y = o.x + v[i].x;
+                o.z = o.y + v[i].y;
+                o.w = o.z + v[i].z;
+                run = o.w + v[i].w;
+                if (at + 3 < K) {
+                    *reinterpret_cast<int4*>(row_ptr + at) = o;
+                } else {
+                    row_ptr[at] = o.x;
+                    if (at + 1 < K) row_ptr[at + 1] = o.y;
+                    if (at + 2 < K) row_ptr[at + 2] = o.z;
+                }
+            }
+        }
+    } else {
+        for (int i = b; i < e; ++i) {
+            const int x = totals[i];
+            row_ptr[i] = run;
+            run += x;
+        }
     }
-    if (t == 1023) row_ptr[K] = s_part[1023];
+    if (t == 1023) row_ptr[K] = total;
 }
 
 // One wave walks a chunk of signals in order; the number of chunks T sets the parallelism of the build (the per-signal
