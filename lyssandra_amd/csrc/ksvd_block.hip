@@ -155,7 +155,7 @@ __host__ __device__ constexpr int bk_maxg(int B) { return ((1 << B) - 1 - B) < 6
 // v_permlane16/32_swap) while the other waves prepare the groups beside it: every Horner step that does not need the atom the
 // main wave is working on.  See the atom loop for the protocol and for what it replaced.
 // ---------------------------------------------------------------------------------------------
-template <int LOGB, int FB, int NTH>
+template <int LOGB, int FB, int NTH, bool WT = false>
 __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float* __restrict__ D, float* __restrict__ Dnext, int ldd,
                                const double* __restrict__ bbuf, const BkLayout lay, double* sm) {
     constexpr int B = 1 << LOGB;
@@ -244,29 +244,32 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
     BK_NSTAMP(1);
     // round 2: moments of the staged groups, flat over (slot, element) so that all loads are in flight together; the
     // padding columns n..NF of a staged row are zero-filled
-    {
+    // (waves 1.. only: the main wave meanwhile updates the first used atom, which has no groups -- see the atom loop)
+    if (tid >= 64) {
+        constexpr int NST = NTH - 64;
+        const int stid = tid - 64;
         const int nst = min(gfirst[B], MAXG), per = NF + B, total = nst * per;
-        constexpr int RU = (MAXG * (NF + B) + NTH - 1) / NTH;  // one pass: every load of the staging is in flight at once
-        for (int i0 = 0; i0 < total; i0 += RU * NTH) {
+        constexpr int RU = (MAXG * (NF + B) + NST - 1) / NST;  // one pass: every load of the staging is in flight at once
+        for (int i0 = 0; i0 < total; i0 += RU * NST) {
             // unconditional loads from clamped addresses (a load under a branch is waited for before the next one issues)
             double v[RU];
 #pragma unroll
             for (int r = 0; r < RU; ++r) {
-                const int i = min(i0 + r * NTH + tid, total - 1);
+                const int i = min(i0 + r * NST + stid, total - 1);
                 const int sl = i / per, e = i % per, g = glist[sl];
                 const int64_t at = (e >= NF) ? lay.offC + (int64_t)g * B + (e - NF) : lay.offQ + (int64_t)g * n + min(e, n - 1);
                 v[r] = bb[at];
             }
 #pragma unroll
             for (int r = 0; r < RU; ++r) {
-                const int i = i0 + r * NTH + tid;
+                const int i = i0 + r * NST + stid;
                 const int e = i % per;
                 if (i < total) QC[i] = (e < n || e >= NF) ? (float)v[r] : 0.f;
             }
         }
     }
-    __syncthreads();
-    BK_NSTAMP(2);
+    // (the barrier that publishes the staged moments is taken inside the two branches of the atom loop: the main wave passes it
+    // after its first atom)
     // ---- the atom loop (round 5b): ONE main wave on the chain, the other waves as helpers beside it.
     // In-kernel core-clock stamps of the 16-team loop this replaces: 2500-2700 cycles per atom = 1250 evaluating the target's
     // groups (the four teams of a wave run the Horner steps of their groups in lock-step: up to three dependent steps of ~350
@@ -309,6 +312,7 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
     };
     const int nstaged = min(gfirst[B], MAXG);
     if (tid >= 64) {
+        __syncthreads();  // moments staged (pairs with the main wave's barrier below)
         // ---- helper teams.  A team must never WAIT inside divergent code: the four teams of a wave run in lock-step, and a team
         // parked in a spin loop for atom l would hold back a wave-mate whose finished entry the main wave needs BEFORE it can
         // publish atom l (sparse early targets put targets 1 and 3 into one wave: deadlock).  So every team is a small state
@@ -397,7 +401,16 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
         for (int b = 0; b < FB; ++b) dcur[b] = make_float4(0.f, 0.f, 0.f, 0.f);
         int t = used ? (__ffs(used) - 1) : B;
         publish(t);  // the atoms below the first used one keep their columns
+        // The first used atom has no groups (a prefix holds used atoms only): it is updated while the other waves stage the
+        // moments; the barrier that makes them visible is taken before the second atom.
+        bool synced = false;
+        const int t_first = t;
         while (t < B) {
+            if (!synced && t != t_first) {
+                __syncthreads();
+                BK_NSTAMP(2);
+                synced = true;
+            }
             const int lb = __builtin_amdgcn_readlane(gfv, t), le = __builtin_amdgcn_readlane(gfv, t + 1);
             const int lm = __builtin_amdgcn_readlane(gmv, t);
             const int lstop = (le < MAXG) ? le : MAXG;  // staged entries end here
@@ -506,6 +519,10 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
             if (t == 0) BK_NSTAMP(3);
             t = tn;
         }
+        if (!synced) {
+            __syncthreads();
+            BK_NSTAMP(2);
+        }
     }
     BK_NSTAMP(4);
     __syncthreads();
@@ -513,7 +530,13 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
     // (the fence of __syncthreads) on every atom's critical path
     for (int i = tid; i < B * ldd; i += NTH) {
         const int t = i / ldd, f = i % ldd, a = c * B + t;
-        if (a < K) Dnext[(int64_t)a * ldd + f] = (f < n) ? dnew[t * NF + f] : 0.f;
+        const float v = (f < n) ? dnew[t * NF + f] : 0.f;
+        if (a < K) {
+            if (WT)  // merged launch: the other workgroups of THIS launch read the new atoms (write-through, device scope)
+                __hip_atomic_store(&Dnext[(int64_t)a * ldd + f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                Dnext[(int64_t)a * ldd + f] = v;
+        }
     }
     BK_NSTAMP(5);
     if (tid == 0)
@@ -538,7 +561,7 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
                                             const int32_t* __restrict__ cg_entry, const int32_t* __restrict__ idx,
                                             float* __restrict__ coef, const float* __restrict__ D,
                                             float* __restrict__ Dnext, int ldd, double* __restrict__ bbuf, BkLayout lay,
-                                            int lazy_rt) {
+                                            int lazy_rt, const int* flag = nullptr) {
     // lazy != 0 (k <= 16, see bksvd_lazy): the update of a finished block is NOT applied by a pass of its own (the
     // ROLE_APPLY walk of Y) but by whoever touches the signal next -- the entry of the signal's next atom, whose index
     // record names the pending atom (predecessor), or bksvd_final_kernel for the signal's last block.  Every visit then
@@ -569,7 +592,12 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
     }
     if (tid == 0) s_qn = 0;
     for (int i = tid; i < B * (FB * 64 + 2); i += NTH) (&s_acc[0][0])[i] = 0.0;
-    if (have_p) {
+    // merged launch (flag != nullptr): the new atoms of block c-1 come from the narrow workgroup of THIS launch -- they are
+    // staged by the first drain, behind the flag, so that the collect walk (entry records, queue) runs while that workgroup
+    // may still be busy
+    const bool merged = flag != nullptr;
+    bool atoms_staged = !merged;
+    if (have_p && !merged) {
         for (int i = tid; i < B * FB * 64; i += NTH) {
             const int t = i / (FB * 64), f = i % (FB * 64), a = p * B + t;
             const bool in = (a < K) && (f < ldd);
@@ -975,6 +1003,24 @@ __device__ __forceinline__ void bksvd_phase(int mode, int c, int nwg, int bx, do
     // chunk size, teams past the end of the list idle) because the queued entries of a batch are drained by ALL teams
     // between two workgroup barriers
     auto drain = [&]() __attribute__((always_inline)) {  // all teams take queued slow-path entries between two workgroup barriers
+        if (!atoms_staged) {  // uniform: merged launch, first drain of Y(c)
+            // No acquire fence: the only data of THIS launch that Y(c) reads are the new atoms of block c-1, stored write-through
+            // by the narrow workgroup and loaded here with device-scope loads; everything else was written by earlier launches.
+            // (An agent-scope acquire is an L1 invalidation of ~1.7 us per wave that executes it: with all 16 waves of every
+            // workgroup fencing, a merged launch took 50 us instead of 21.)
+            if (tid == 0)
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __syncthreads();
+            if (have_p) {
+                for (int i = tid; i < B * FB * 64; i += NTH) {
+                    const int t = i / (FB * 64), f = i % (FB * 64), a = p * B + t;
+                    const bool in = (a < K) && (f < ldd);
+                    s_d[0][t][f] = in ? D[(int64_t)a * ldd + f] : 0.f;
+                    s_d[1][t][f] = in ? __hip_atomic_load(&Dnext[(int64_t)a * ldd + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                }
+            }
+            atoms_staged = true;
+        }
         __syncthreads();
         const int nq = s_qn;
         for (int i = team; i < nq; i += TEAMS)  // uniform per team
@@ -1187,7 +1233,8 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
                                                                 const int32_t* __restrict__ idx,
                                                                 float* __restrict__ coef, const float* __restrict__ D,
                                                                 float* __restrict__ Dnext, int ldd,
-                                                                double* __restrict__ bbuf, BkLayout lay, int lazy_rt) {
+                                                                double* __restrict__ bbuf, BkLayout lay, int lazy_rt,
+                                                                int* __restrict__ done) {
     constexpr int NTH = 16 * TEAMS;
     extern __shared__ double sm[];  // narrow step / group phase
     // The narrow step is workgroup 0: with ~100 KB of dynamic LDS only one workgroup fits a CU, a launch of 257 on 256 CUs
@@ -1197,6 +1244,39 @@ __global__ __launch_bounds__(16 * TEAMS) void bksvd_step_kernel(int mode, int c,
 #ifdef LYS_BK_WGEND
     if (threadIdx.x == 0) g_bk_wg[2 * blockIdx.x] = (unsigned long long)wall_clock64();
 #endif
+    if (mode == 3) {
+        // MERGED launch of the single-GPU lazy schedule (round 5b), c in [1, nb]:
+        //     [narrow step of block c-1 on workgroup 0]  ||  [X(c): walk + group phase]   ->   flag   ->   [Y(c)]
+        // Y(c) -- the ~8 % of block c's entries whose pending block is c-1 -- needs nothing but the new atoms of block c-1, which
+        // the narrow workgroup of this very launch produces: it stores them write-through and raises a device-scope flag, the
+        // other workgroups poll it once their X part is done (they never wait for each other, the narrow workgroup never waits:
+        // no residency requirement), acquire, and run Y(c) on rows no X(c) workgroup touched (PREV entries are skipped by the
+        // walk and by the group phase).  One kernel boundary per block instead of two, and the statistics of block c are
+        // complete when the launch ends -- exactly what the next launch's narrow step needs.  The two phases are two inlined
+        // copies of bksvd_phase (as iterations of one loop over mutable state the kernel spilled 123 VGPRs in round 3).
+        --nwg;
+        --bx;
+        int* flag = done + c * 16;
+        if (bx < 0) {
+            bk_narrow_body<LOGB, FB, NTH, true>(c - 1, K, n, D, Dnext, ldd, bbuf, lay, sm);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave has the acknowledgements of its write-through stores
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef LYS_BK_WGEND
+            if (threadIdx.x == 0) g_bk_wg[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+#endif
+            return;
+        }
+        if (c >= nb) return;  // X(nb): only the narrow step of the last block (Y(nb) has nothing to do in the lazy schedule)
+        bksvd_phase<FB, LOGB, SL, TEAMS, FULL>(0, c, BK_PHASE_ARGS);
+        __syncthreads();  // the phase's LDS state is reused below
+        bksvd_phase<FB, LOGB, SL, TEAMS, FULL>(1, c, BK_PHASE_ARGS, flag);  // waits for the flag before its first drain
+#ifdef LYS_BK_WGEND
+        __syncthreads();
+        if (threadIdx.x == 0) g_bk_wg[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+#endif
+        return;
+    }
     if (mode == 0 && c >= 1) {
         --nwg;
         --bx;
@@ -1244,27 +1324,45 @@ __global__ __launch_bounds__(256) void bksvd_final_kernel(int64_t N, float* __re
         }
         esum += (double)bk_row16_sum(sq);
     };
-    for (int64_t sig = (int64_t)blockIdx.x * 16 + team; sig < N; sig += nteams) {
+    // the row and the support of the NEXT signal of this team are requested before the current one is processed (round 5b: the
+    // pass was a chain row / support -> atoms' columns -> store per signal, 3.4 TB/s of its 0.54 GB)
+    float4 rN[FB];
+    int aN[SL];
+    float xN[SL];
+    auto fetch = [&](int64_t sg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int f = 64 * b + 4 * q;
+            rN[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL || f < n) rN[b] = *reinterpret_cast<const float4*>(R + sg * ldr + f);
+        }
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            const int j = q + 16 * s;
+            const int64_t off = sg * k + ((j < k) ? j : k - 1);
+            aN[s] = idx[off];
+            xN[s] = coef[off];
+        }
+    };
+    const int64_t sig0 = (int64_t)blockIdx.x * 16 + team;
+    if (sig0 < N) fetch(sig0);
+    for (int64_t sig = sig0; sig < N; sig += nteams) {
         float4 r[FB];
         int a[SL];
         float x[SL];
 #pragma unroll
-        for (int b = 0; b < FB; ++b) {
-            const int f = 64 * b + 4 * q;
-            r[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (FULL || f < n) r[b] = *reinterpret_cast<const float4*>(R + sig * ldr + f);
-        }
+        for (int b = 0; b < FB; ++b) r[b] = rN[b];
         int lb = -1;
 #pragma unroll
         for (int s = 0; s < SL; ++s) {
             const int j = q + 16 * s;
-            const int64_t off = sig * k + ((j < k) ? j : k - 1);
-            const int av = idx[off];
-            x[s] = coef[off];
+            const int av = aN[s];
+            x[s] = xN[s];
             const bool live = (j < k) && (x[s] != 0.f) && av >= 0;
             a[s] = live ? av : -1;
             lb = (a[s] >= 0 && (a[s] >> LOGB) > lb) ? (a[s] >> LOGB) : lb;
         }
+        fetch((sig + nteams < N) ? sig + nteams : sig);  // (the last one re-reads its own: harmless, never used)
         lb = max(lb, bk_dpp_i<0xB1>(lb));
         lb = max(lb, bk_dpp_i<0x4E>(lb));
         lb = max(lb, bk_dpp_i<0x124>(lb));
@@ -1366,12 +1464,19 @@ int bksvd_lazy(int k, int K) {
     return (!(e && e[0] == '0') && k <= 16 && K <= 8192) ? 1 : 0;
 }
 
+// The merged launches (one per block, see mode 3 of bksvd_step_kernel): the single-GPU lazy sweep, unless LYS_BKSVD_MERGED=0
+// (read per call: tests run both schedules in one process).
+int bksvd_merged(int k, int K) {
+    const char* e = getenv("LYS_BKSVD_MERGED");
+    return (!(e && e[0] == '0') && bksvd_lazy(k, K)) ? 1 : 0;
+}
+
 template <int FB, int LOGB, int SL, int TEAMS, bool FULL>
 static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ldr, int n, int k, const BkIndex& ix,
                             const int32_t* idx, float* coef, const float* D, float* Dnext, double* bbuf,
                             const BkLayout& lay, hipStream_t stream) {
     // only X(c >= 1) runs the narrow step and needs its LDS (up to ~100 KB of the 160 KB of a gfx950 workgroup)
-    const bool narrow = (mode == 0 && c >= 1);
+    const bool narrow = ((mode == 0 || mode == 3) && c >= 1);
     const size_t lds = (mode == 1) ? 0 : std::max(narrow ? narrow_lds_bytes(n, 1 << LOGB) : 0, group_lds_bytes(n, 1 << LOGB));
     static bool attr_set[64] = {};
     int dev = 0;
@@ -1384,10 +1489,12 @@ static int launch_step_full(int mode, int c, int nb, int K, float* R, int64_t ld
     }
     // X(c >= 1): the narrow workgroup + 255 wide ones = one per CU, all resident at once (the LDS of the narrow step
     // limits a CU to one workgroup of this launch)
-    const int grid = (mode == 0 && c >= nb) ? 1 : BK_WBLOCKS;
+    const int grid = ((mode == 0 || mode == 3) && c >= nb) ? 1 : BK_WBLOCKS;
+    // the flags of the merged launches: 16 ints per block behind the slabs (bksvd_stats_doubles), zeroed with them
+    int* done = reinterpret_cast<int*>(bbuf + (size_t)nb * lay.stride);
     hipLaunchKernelGGL((bksvd_step_kernel<FB, LOGB, SL, TEAMS, FULL>), dim3(grid), dim3(16 * TEAMS), lds, stream, mode,
                        c, nb, K, R, ldr, n, k, ix.row_ptr, ix.erec, ix.cg_ptr, ix.cg_entry, idx, coef, D, Dnext,
-                       padded_features(n), bbuf, lay, bksvd_lazy(k, K));
+                       padded_features(n), bbuf, lay, bksvd_lazy(k, K), done);
     LYS_LAUNCH_CHECK();
     return LYS_OK;
 }
@@ -1422,7 +1529,7 @@ int bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, int 
         return LYS_ENOSUP;
     }
     const int nb = (K + B - 1) / B;
-    if ((mode != 0 && mode != 1) || c < (mode ? 1 : 0) || c > nb) {
+    if ((mode != 0 && mode != 1 && mode != 3) || c < (mode ? 1 : 0) || c > nb || (mode == 3 && !bksvd_lazy(k, K))) {
         set_error("bksvd_step: mode %d, block %d of %d", mode, c, nb);
         return LYS_EINVAL;
     }
@@ -1519,12 +1626,20 @@ int bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int
     const int nb = (K + B - 1) / B;
     // 2 K/B + 1 dependent launches.  (Replaying them as one hipGraph, LYS_BKSVD_GRAPH=1 in rounds 2-4, measured 5.40 against
     // 5.23 ms eager: the launches are back to back already -- rocprofv3 shows no gaps between them; removed in round 5.)
-    for (int c = 0; c <= nb; ++c) {
-        rc = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
-        if (rc) return rc;
-        if (c >= 1) {
-            rc = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
+    if (bksvd_merged(k, K)) {
+        // X(0), then ONE launch per block: [narrow(c-1)] || [X(c)] -> flag -> [Y(c)]  (mode 3 of bksvd_step_kernel)
+        for (int c = 0; c <= nb; ++c) {
+            rc = bksvd_step(c == 0 ? 0 : 3, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
             if (rc) return rc;
+        }
+    } else {
+        for (int c = 0; c <= nb; ++c) {
+            rc = bksvd_step(0, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
+            if (rc) return rc;
+            if (c >= 1) {
+                rc = bksvd_step(1, c, B, R, ldr, n, K, k, row_ptr, erec, cg_ptr, cg_entry, idx, coef, D, Dnext, bbuf, stream);
+                if (rc) return rc;
+            }
         }
     }
     rc = bksvd_finish(R, ldr, n, K, k, N, idx, coef, D, Dnext, B, stream, bbuf + bksvd_error_offset_doubles(n, K, B));

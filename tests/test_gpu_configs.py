@@ -70,7 +70,7 @@ def test_approx_ksvd_sweep_config2_size(eng, N, cycles):
 def test_approx_ksvd_sweep_dense_coupling_many_signals(eng, n, K, k, N, monkeypatch):
     """Small dictionaries with many signals: most signals use SEVERAL atoms of a block of 8 (1.2e5 coupled signals per block
     at K = 64), more than one round of the group phase holds (a round is 255 workgroups x 128 entries; the entries past it
-    were dropped before round 3: atoms off by 1e-2, residual no longer X - DZ).  Both schedules, against the float64 C
+    were dropped before round 3: atoms off by 1e-2, residual no longer X - DZ).  All three schedules, against the float64 C
     restatement (lyssa/dict_learning/ksvd.py:98-126)."""
     import torch
     from oracle import c_oracle
@@ -80,9 +80,11 @@ def test_approx_ksvd_sweep_dense_coupling_many_signals(eng, n, K, k, N, monkeypa
     Xs = torch.randn((N, n), device="cuda", generator=gen)
     X = Xs.t().contiguous().double().cpu().numpy()
     ref = None
-    # the two schedules: lazy apply (default), eager (round 2; what k > 16 runs)
-    for lazy in ("1", "0"):
+    # the three schedules: lazy apply with ONE merged launch per block (default, round 5), lazy with X(c) and Y(c) as launches of
+    # their own (what the sharded sweep runs: the slab is all-reduced between them), eager (round 2; what k > 16 runs)
+    for lazy, merged in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("LYS_BKSVD_LAZY", lazy)
+        monkeypatch.setenv("LYS_BKSVD_MERGED", merged)
         dd = eng.DeviceDictionary(n, K)
         dd.set(Dt)
         idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
@@ -97,7 +99,7 @@ def test_approx_ksvd_sweep_dense_coupling_many_signals(eng, n, K, k, N, monkeypa
         drift = (R[:, :n] - R2[:, :n]).abs().max().item()
         ae = _atom_err(dd.to_host(), Do)
         ce = np.max(np.abs(coef.double().cpu().numpy() - co)) / np.abs(co).max()
-        print("lazy=%s n=%d K=%d N=%d: atom err %.3g, code err %.3g, drift %.3g" % (lazy, n, K, N, ae, ce, drift))
+        print("lazy=%s merged=%s n=%d K=%d N=%d: atom err %.3g, code err %.3g, drift %.3g" % (lazy, merged, n, K, N, ae, ce, drift))
         assert unused == uo
         assert drift < 2e-5 * Xs.abs().max().item(), drift
         assert ae < 1e-5 and ce < 1e-5 and abs(err_dev - err_o) / err_o < 1e-5

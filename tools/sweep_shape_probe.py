@@ -1,4 +1,4 @@
-"""One block K-SVD sweep (both schedules) against the float64 C restatement over shapes that stress the kernel's capacity
+"""One block K-SVD sweep (three schedules: merged lazy = the default, lazy with two launches per block, eager) against the float64 C restatement over shapes that stress the kernel's capacity
 limits: dense in-block coupling, single-block dictionaries, K not a multiple of the block, wide supports, wide signals.
 usage: python tools/sweep_shape_probe.py"""
 import os
@@ -14,7 +14,8 @@ SHAPES = [(16, 16, 4, 200000), (8, 8, 3, 100000), (128, 128, 20, 100000), (200, 
 
 
 def run(n, K, k, N, lazy):
-    os.environ["LYS_BKSVD_LAZY"] = lazy
+    os.environ["LYS_BKSVD_LAZY"] = "0" if lazy == "0" else "1"
+    os.environ["LYS_BKSVD_MERGED"] = "0" if lazy == "1u" else "1"   # "1u": lazy, X and Y as launches of their own
     gen = torch.Generator(device="cuda").manual_seed(11)
     Dt = torch.randn((n, K), device="cuda", generator=gen)
     Dt = Dt / Dt.norm(dim=0, keepdim=True)
@@ -41,7 +42,7 @@ def run(n, K, k, N, lazy):
 
 bad = 0
 for sh in SHAPES:
-    for lazy in ("1", "0"):
+    for lazy in ("1", "1u", "0"):
         try:
             bad += 0 if run(*sh, lazy) else 1
         except Exception as e:  # noqa: BLE001
