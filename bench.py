@@ -595,11 +595,16 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
     sweep_gbs = 8 * n * nnz_tot / (ms["sweep"] * 1e-3) / 1e9
     B = int(engine._lib.load().lys_bksvd_block_size(n))
     nb = (K + B - 1) // B
+    # single GPU, lazy schedule: ONE merged launch per block (round 5); shards: X(c) and Y(c) with the slab all-reduce between them
+    merged = ws == 1 and k <= 16 and K <= 8192 and os.environ.get("LYS_BKSVD_MERGED", "1") != "0" \
+        and os.environ.get("LYS_BKSVD_LAZY", "1") != "0"
+    n_launch = nb + 1 if merged else 2 * nb + 1
     res = {"workload": "approx K-SVD alternation, %d patches per GPU on %d GPU(s), K=%d, k=%d (configs[1]); mean of %d "
                        "iterations" % (Xs.shape[0], ws, K, k, iters),
            "ms": ms, "ms_total": ms["encode"] + ms["residual"] + ms["sweep"] + ms["error"],
            "sweep_roofline": {"bound": "hbm", "kernel": "bksvd_step_kernel (block Gauss-Seidel sweep, %d launches of %d "
-                                                        "atoms)" % (2 * nb + 1, B),
+                                                        "atoms%s)" % (n_launch, B, ": [narrow step of block c-1 || X(c)] -> "
+                                                        "device-scope flag -> [Y(c)] in one launch" if merged else ""),
                               "achieved": sweep_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                               "frac": sweep_gbs / PEAK_HBM_GBS,
                               "bytes_model": "SURVEY 8(d): 8*n bytes per (atom, signal) non-zero = %.3g GB per sweep per GPU"
@@ -609,7 +614,7 @@ def ksvd_iteration(Xs, dd0, k, iters=3, group=None):
                               "schedule": "lazy: a finished block's update is applied by the signal's next visit (one row "
                                           "read + one row write per non-zero = the 8(d) bytes); LYS_BKSVD_LAZY=0 = the "
                                           "eager round-2 schedule (12*n bytes per non-zero)",
-                              "includes": "index build (csr + block index), 257 step launches, final pass, D copy"},
+                              "includes": "index build (csr + block index), %d step launches, final pass, D copy" % n_launch},
            "sclk_mhz_encode": sclk_enc,
            "final_error": err}
     # configs[1] as BASELINE.md states it: 50 alternations (encode, residual, sweep, error -- what ksvd_dict_learn runs per

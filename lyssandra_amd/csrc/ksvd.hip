@@ -400,17 +400,29 @@ __global__ __launch_bounds__(1024) void csr_scan_partial_kernel(const int32_t* _
         part[(int64_t)(z * CSR_SSEG + seg) * K + a] = sum;
     }
 }
+// one WAVE per atom: lane l owns the sub-segments 4 l .. 4 l + 3 (round 5b; one thread per atom walked its 256 sums one
+// after the other on K / 256 = 4 workgroups: 36 us of dependent load / store pairs at configs[1])
 __global__ __launch_bounds__(256) void csr_scan_bases_kernel(int32_t* __restrict__ part, int K, int32_t* __restrict__ totals) {
-    const int a = blockIdx.x * 256 + threadIdx.x;
+    static_assert(CSR_ZSEG * CSR_SSEG == 256, "four sub-segment sums per lane");
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (a >= K) return;
-    int run = 0;
-#pragma unroll 8
-    for (int s = 0; s < CSR_ZSEG * CSR_SSEG; ++s) {
-        const int v = part[(int64_t)s * K + a];
-        part[(int64_t)s * K + a] = run;
-        run += v;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = part[(int64_t)(4 * lane + i) * K + a];
+    const int sum = v[0] + v[1] + v[2] + v[3];
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        inc += (lane >= off) ? o : 0;
     }
-    totals[a] = run;
+    int run = inc - sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        part[(int64_t)(4 * lane + i) * K + a] = run;
+        run += v[i];
+    }
+    if (lane == 63) totals[a] = inc;
 }
 __global__ __launch_bounds__(1024) void csr_scan_apply_kernel(int32_t* __restrict__ counts, int T, int K,
                                                               const int32_t* __restrict__ part) {
@@ -581,7 +593,7 @@ int csr_by_atom(const int32_t* idx, const float* coef, const int32_t* nnz, int K
     LYS_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_scan_partial_kernel, dim3((K + 63) / 64, CSR_ZSEG), dim3(1024), 0, stream, counts, T, K, part);
     LYS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(csr_scan_bases_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, part, K, totals);
+    hipLaunchKernelGGL(csr_scan_bases_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, part, K, totals);
     LYS_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_scan_apply_kernel, dim3((K + 63) / 64, CSR_ZSEG), dim3(1024), 0, stream, counts, T, K, part);
     LYS_LAUNCH_CHECK();
