@@ -24,6 +24,9 @@
 //       Y(c):  [apply block c-1]  +  [accumulate block c over the signals that also use block c-1, after applying it]
 //   so the serial narrow step hides behind 92 % of the accumulation.  In a multi-GPU run the exchange is ONE all-reduce
 //   of block c's statistics slab between Y(c) and X(c+1) instead of one per atom (dist.ksvd_cycle_blocks).
+//   Single GPU, lazy schedule (round 5): X(c) and Y(c) are ONE launch -- Y(c) needs nothing but the new atoms of block c-1,
+//   which the narrow workgroup of the same launch stores write-through behind a device-scope flag (mode 3 of
+//   bksvd_step_kernel): K/B + 1 = 129 launches per sweep.
 //
 // The kernels are bound by the BYTES of scattered accesses (every 40-byte support read costs a 128-byte line), so the
 // by-atom index carries, per entry, the signal id, the entry's coefficient, its slot and three flags (the signal uses

@@ -15,12 +15,12 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_w
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc -- $CMD > /dev/null 2> $OUT/pmc_sq.err
 cd $ROOT
 {
-  echo "# command: $CMD  (3 alternations; the sweep = ${STEPS:-257} launches of bksvd_step_kernel per alternation + the index build + the final pass)"
+  echo "# command: $CMD  (3 alternations; the sweep = ${STEPS:-129} launches of bksvd_step_kernel per alternation + the index build + the final pass)"
   tail -3 $OUT/trace_cmd.out
   python $ROOT/tools/summarize_profile.py $OUT
   echo
-  echo "== per-launch durations of the last sweep: X(0), then X(c), Y(c) for c = 1 .. nb =="
-  python $ROOT/tools/step_durations.py $OUT/trace ${STEPS:-257}
+  echo "== per-launch durations of the last sweep: X(0), then the merged launches c = 1 .. nb (STEPS=257 with LYS_BKSVD_MERGED=0: X(c), Y(c)) =="
+  python $ROOT/tools/step_durations.py $OUT/trace ${STEPS:-129}
 } > $ROOT/gpurun_out/prof_ksvd_${TAG}_summary.txt 2>&1
 find $OUT -name "*.db" -delete
 tail -40 $ROOT/gpurun_out/prof_ksvd_${TAG}_summary.txt

@@ -11,5 +11,5 @@ python $ROOT/tools/ksvd_bench.py 1048576 4 2>/dev/null | tail -2
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/tools/ksvd_bench.py 1048576 3 > /dev/null 2> $OUT/trace.err
 cd $ROOT
-python $ROOT/tools/step_durations.py $OUT/trace ${STEPS:-257}
+python $ROOT/tools/step_durations.py $OUT/trace ${STEPS:-129}
 find $OUT -name "*.db" -delete
