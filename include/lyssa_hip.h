@@ -362,7 +362,11 @@ int lys_bksvd_step(int mode, int c, int B, float* R, int64_t ldr, int n, int K, 
 int lys_bksvd_is_lazy(int k, int K);
 int lys_bksvd_finish(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
                      const float* D_packed, const float* D_next, int B, void* stream);
-/* one whole cycle on one GPU: index (workspace: lys_bksvd_index_workspace_bytes) + all launches + D_packed <- D_next */
+/* one whole cycle on one GPU: index (workspace: lys_bksvd_index_workspace_bytes) + all launches + D_packed <- D_next.
+ * With the lazy schedule the launches are MERGED, one per block: [narrow step of block c-1] || [X(c)] -> device-scope flag ->
+ * [Y(c)] (the new atoms of block c-1 leave the narrow workgroup write-through; nobody waits for anybody who waits);
+ * LYS_BKSVD_MERGED=0 runs X(c) and Y(c) as the two launches of lys_bksvd_step, which is what a sharded sweep needs (the
+ * statistics slab of block c is all-reduced between them). */
 int lys_bksvd_sweep(float* R, int64_t ldr, int n, int K, int k, int64_t N, const int32_t* idx, float* coef,
                     const int32_t* nnz, int B, int32_t* row_ptr, void* entry_records, int32_t* cg_ptr,
                     int32_t* cg_entry, void* workspace, size_t workspace_bytes, double* stats, float* D_packed,
