@@ -274,30 +274,44 @@ struct CsrPred {
     int pb, pa, ps, pn;
     float pc;
 };
+// Round 5b: the J loop only finds the LEADER slot of the pending block -- the maximum of a packed key (block << 3 | 7 - atom's
+// position in its block: largest block below this entry's, then its smallest atom) with the slot that holds it -- and the
+// leader's atom, coefficient and "its block holds several atoms of the signal" (= the leader lane's own in-block mask has two
+// bits) are fetched from that lane afterwards (ds_bpermute).  The five per-slot selects of the tracked form (pn, pa, ps, pc, pb)
+// were a quarter of the 340 VALU instructions both index passes spend per four signals.
 template <int J>
-__device__ __forceinline__ void csr_flag_step(int a, float cv, int blk, int k, int logb, unsigned& msk, int& meta,
-                                              CsrPred& pr) {
+__device__ __forceinline__ void csr_flag_step(int a, int blk, int k, int logb, unsigned& msk, int& meta, int& best, int& ps) {
     if constexpr (J < 16) {
         if (J < k) {  // uniform
             const int aj = csr_row_bcast<J>(a);
-            const float cj = __builtin_bit_cast(float, csr_row_bcast<J>(__builtin_bit_cast(int, cv)));
             const int bj = aj >> logb;
+            const int lo = aj & ((1 << logb) - 1);
             const bool on = aj >= 0;
-            msk |= (on && bj == blk) ? (1u << (aj & ((1 << logb) - 1))) : 0u;
+            msk |= (on && bj == blk) ? (1u << lo) : 0u;
             meta |= (on && bj == blk - 1) ? 0x200 : 0;
             meta |= (on && bj == blk + 1) ? 0x400 : 0;
-            const bool before = on && bj < blk;
-            const bool newer = before && bj > pr.pb;
-            const bool same = before && bj == pr.pb;
-            const bool first = newer || (same && aj < pr.pa);   // the block's smallest atom leads (any one would do)
-            pr.pn = newer ? 1 : (same ? pr.pn + 1 : pr.pn);
-            pr.pa = first ? aj : pr.pa;
-            pr.ps = first ? J : pr.ps;
-            pr.pc = first ? cj : pr.pc;
-            pr.pb = newer ? bj : pr.pb;
-            csr_flag_step<J + 1>(a, cv, blk, k, logb, msk, meta, pr);
+            const int cand = (on && bj < blk) ? ((bj << 3) | (7 - lo)) : -1;
+            ps = (cand > best) ? J : ps;
+            best = (cand > best) ? cand : best;
+            csr_flag_step<J + 1>(a, blk, k, logb, msk, meta, best, ps);
         }
     }
+}
+// flags of one entry (lane = slot of a 16-lane row): in-block mask, PREV / NEXT bits and the predecessor (see CsrPred)
+__device__ __forceinline__ void csr_entry_flags(int a, float cv, int blk, int k, int logb, int lane, unsigned& msk, int& meta,
+                                                CsrPred& pr) {
+    int best = -1, ps = 63;
+    csr_flag_step<0>(a, blk, k, logb, msk, meta, best, ps);
+    // the leader lane of the pending block (same 16-lane row): its atom, coefficient and in-block mask
+    const int src = ((lane & 48) | (ps & 15)) << 2;
+    const int pa = __builtin_amdgcn_ds_bpermute(src, a);
+    const float pc = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, cv)));
+    const unsigned pm = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)msk);
+    pr.pb = (best >= 0) ? (best >> 3) : -1;
+    pr.ps = ps;
+    pr.pa = pa;
+    pr.pc = pc;
+    pr.pn = (best >= 0) ? (((pm & (pm - 1u)) != 0u) ? 2 : 1) : 0;  // only "one" / "several" is used
 }
 
 template <bool FILL>
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(64) void bksvd_index_kernel(const int32_t* __restri
             unsigned msk = 0;
             int meta = j;
             CsrPred pr{-1, -1, 63, 0, 0.f};
-            csr_flag_step<0>(a, live ? cv[u] : 0.f, blk, k, logb, msk, meta, pr);
+            csr_entry_flags(a, live ? cv[u] : 0.f, blk, k, logb, lane, msk, meta, pr);
             // bits 12-17: predecessor slot (63 = none), 18-30: predecessor atom (K <= 8192), 31: the predecessor block holds
             // several atoms of the signal (slow path); word 3 of the record: the predecessor's coefficient
             if (pr.pb >= 0 && K <= 8192) {
