@@ -247,7 +247,16 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
     BK_NSTAMP(1);
     // round 2: moments of the staged groups, flat over (slot, element) so that all loads are in flight together; the
     // padding columns n..NF of a staged row are zero-filled
-    // (waves 1.. only: the main wave meanwhile updates the first used atom, which has no groups -- see the atom loop)
+    // (waves 1.. only: the main wave meanwhile updates the first used atom, which has no groups: a prefix holds used atoms only)
+    unsigned used = 0;   // main wave: the block's used atoms (unused ones keep their column, ksvd.py:112-115)
+    int t_main = B;      // main wave: the next atom of its loop
+    float4 dcur[FB];     // main wave: d_new of atom t - 1 when that atom was updated
+#pragma unroll
+    for (int b = 0; b < FB; ++b) dcur[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto publish = [&](int nd) __attribute__((always_inline)) {  // atoms below nd are final: d_new[..] written above by the main wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&s_ndone, nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     if (tid >= 64) {
         constexpr int NST = NTH - 64;
         const int stid = tid - 64;
@@ -270,9 +279,48 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
                 if (i < total) QC[i] = (e < n || e >= NF) ? (float)v[r] : 0.f;
             }
         }
+    } else {
+#pragma unroll
+        for (int t = 0; t < B; ++t) used |= (c * B + t < K && s_cnt[t] != 0.f) ? (1u << t) : 0u;
+        used = (unsigned)__builtin_amdgcn_readfirstlane((int)used);
+        t_main = used ? (__ffs(used) - 1) : B;
+        publish(t_main);  // the atoms below the first used one keep their columns
+        if (t_main < B) {  // s = S_t + d_old sum x^2 (no groups), d_new = s / (||s|| + eps): the general step below with an empty list
+            const int t = t_main;
+            float v2 = 0.f;
+            float4 sv[FB];
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                sv[b] = *reinterpret_cast<const float4*>(base + t * NF + 64 * b + 4 * q);
+                v2 = fmaf(sv[b].x, sv[b].x, v2);
+                v2 = fmaf(sv[b].y, sv[b].y, v2);
+                v2 = fmaf(sv[b].z, sv[b].z, v2);
+                v2 = fmaf(sv[b].w, sv[b].w, v2);
+            }
+            v2 = bk_row16_sum(v2);
+            float scale = 0.f;
+            if (v2 > 0.f) {
+                const float y = __builtin_amdgcn_rsqf(v2);
+                scale = y * fmaf(-0.5f * v2 * y, y, 1.5f);
+            }
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                dcur[b] = make_float4(sv[b].x * scale, sv[b].y * scale, sv[b].z * scale, sv[b].w * scale);
+                if (team == 0) *reinterpret_cast<float4*>(dnew + t * NF + 64 * b + 4 * q) = dcur[b];
+            }
+            const unsigned above = used & ~((2u << t) - 1u);
+            const int tn = above ? (__ffs(above) - 1) : B;
+            if (tn != t + 1) {
+#pragma unroll
+                for (int b = 0; b < FB; ++b) dcur[b] = make_float4(0.f, 0.f, 0.f, 0.f);  // (never read: no group holds an unused atom)
+            }
+            publish(tn);
+            if (t == 0) BK_NSTAMP(3);
+            t_main = tn;
+        }
     }
-    // (the barrier that publishes the staged moments is taken inside the two branches of the atom loop: the main wave passes it
-    // after its first atom)
+    __syncthreads();  // the staged moments (and the first atom) are in
+    BK_NSTAMP(2);
     // ---- the atom loop (round 5b): ONE main wave on the chain, the other waves as helpers beside it.
     // In-kernel core-clock stamps of the 16-team loop this replaces: 2500-2700 cycles per atom = 1250 evaluating the target's
     // groups (the four teams of a wave run the Horner steps of their groups in lock-step: up to three dependent steps of ~350
@@ -315,7 +363,6 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
     };
     const int nstaged = min(gfirst[B], MAXG);
     if (tid >= 64) {
-        __syncthreads();  // moments staged (pairs with the main wave's barrier below)
         // ---- helper teams.  A team must never WAIT inside divergent code: the four teams of a wave run in lock-step, and a team
         // parked in a spin loop for atom l would hold back a wave-mate whose finished entry the main wave needs BEFORE it can
         // publish atom l (sparse early targets put targets 1 and 3 into one wave: deadlock).  So every team is a small state
@@ -383,10 +430,6 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
         constexpr int NGM = (FB == 1) ? 4 : 2;  // list entries a team loads together
         const int gfv = gfirst[(lane <= B) ? lane : B];  // lane i holds gfirst[i]
         const int gmv = gmid[(lane < B) ? lane : B - 1];
-        unsigned used = 0;
-#pragma unroll
-        for (int t = 0; t < B; ++t) used |= (c * B + t < K && s_cnt[t] != 0.f) ? (1u << t) : 0u;  // unused atoms keep their column (ksvd.py:112-115)
-        used = (unsigned)__builtin_amdgcn_readfirstlane((int)used);
         auto xteam_sum = [&](float x) -> float {  // sum over the four rows, same lane position; identical bits in all rows
             float va = x, vb = x;
             asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(va), "+v"(vb));
@@ -395,25 +438,8 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(vc), "+v"(vd));
             return vc + vd;
         };
-        auto publish = [&](int nd) __attribute__((always_inline)) {  // atoms below nd are final: d_new[..] written above by this wave
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(&s_ndone, nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        float4 dcur[FB];
-#pragma unroll
-        for (int b = 0; b < FB; ++b) dcur[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-        int t = used ? (__ffs(used) - 1) : B;
-        publish(t);  // the atoms below the first used one keep their columns
-        // The first used atom has no groups (a prefix holds used atoms only): it is updated while the other waves stage the
-        // moments; the barrier that makes them visible is taken before the second atom.
-        bool synced = false;
-        const int t_first = t;
+        int t = t_main;  // the first used atom was updated beside the staging of the moments
         while (t < B) {
-            if (!synced && t != t_first) {
-                __syncthreads();
-                BK_NSTAMP(2);
-                synced = true;
-            }
             const int lb = __builtin_amdgcn_readlane(gfv, t), le = __builtin_amdgcn_readlane(gfv, t + 1);
             const int lm = __builtin_amdgcn_readlane(gmv, t);
             const int lstop = (le < MAXG) ? le : MAXG;  // staged entries end here
@@ -521,10 +547,6 @@ __device__ __forceinline__ void bk_narrow_body(int c, int K, int n, const float*
             publish(tn);
             if (t == 0) BK_NSTAMP(3);
             t = tn;
-        }
-        if (!synced) {
-            __syncthreads();
-            BK_NSTAMP(2);
         }
     }
     BK_NSTAMP(4);
