@@ -22,6 +22,28 @@ __device__ __forceinline__ float row16_sum(float x) {  // sum over the 16 lanes 
     return x;
 }
 
+// lane j (a constant after unrolling) of every 16-lane row, in all lanes of that row
+__device__ __forceinline__ int csr_row_bcast_res(int x, int j) {
+    switch (j & 15) {
+        case 0: return __builtin_amdgcn_update_dpp(0, x, 0x150, 0xf, 0xf, true);
+        case 1: return __builtin_amdgcn_update_dpp(0, x, 0x151, 0xf, 0xf, true);
+        case 2: return __builtin_amdgcn_update_dpp(0, x, 0x152, 0xf, 0xf, true);
+        case 3: return __builtin_amdgcn_update_dpp(0, x, 0x153, 0xf, 0xf, true);
+        case 4: return __builtin_amdgcn_update_dpp(0, x, 0x154, 0xf, 0xf, true);
+        case 5: return __builtin_amdgcn_update_dpp(0, x, 0x155, 0xf, 0xf, true);
+        case 6: return __builtin_amdgcn_update_dpp(0, x, 0x156, 0xf, 0xf, true);
+        case 7: return __builtin_amdgcn_update_dpp(0, x, 0x157, 0xf, 0xf, true);
+        case 8: return __builtin_amdgcn_update_dpp(0, x, 0x158, 0xf, 0xf, true);
+        case 9: return __builtin_amdgcn_update_dpp(0, x, 0x159, 0xf, 0xf, true);
+        case 10: return __builtin_amdgcn_update_dpp(0, x, 0x15A, 0xf, 0xf, true);
+        case 11: return __builtin_amdgcn_update_dpp(0, x, 0x15B, 0xf, 0xf, true);
+        case 12: return __builtin_amdgcn_update_dpp(0, x, 0x15C, 0xf, 0xf, true);
+        case 13: return __builtin_amdgcn_update_dpp(0, x, 0x15D, 0xf, 0xf, true);
+        case 14: return __builtin_amdgcn_update_dpp(0, x, 0x15E, 0xf, 0xf, true);
+        default: return __builtin_amdgcn_update_dpp(0, x, 0x15F, 0xf, 0xf, true);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // R = X - D Z  and  err += ||R||^2      (ksvd.py:103, dict_learning/utils.py:14-19)
 // A 16-lane DPP row ("team") owns a signal: lane q moves features 64b + 4q .. +3 with one dwordx4 per 64 features
@@ -98,6 +120,88 @@ __global__ __launch_bounds__(256) void residual_team_kernel(const float* __restr
     }
 }
 
+// The same for n <= 64, k <= 16 (the block sweep's shapes), one signal per team and iteration with NOTHING dependent inside the
+// iteration but the dictionary rows: lane q of the team holds slot q of the support (one load per lane instead of k broadcast
+// loads one after the other), the row, the support and the count of the team's NEXT signal are requested before the current
+// one is processed, and the k dictionary rows of a signal are requested together (slots past the count read atom 0 with a zero
+// coefficient).  residual_team_kernel walks idx[j] -> D[idx[j]] k times per signal, 32 signals per team one after the other.
+__global__ __launch_bounds__(256) void residual_team16_kernel(const float* __restrict__ X, int64_t ldx,
+                                                              const float* __restrict__ D, int ldd, int n, int k,
+                                                              int64_t N, const int32_t* __restrict__ idx,
+                                                              const float* __restrict__ coef,
+                                                              const int32_t* __restrict__ nnz, float* __restrict__ R,
+                                                              int64_t ldr, double* __restrict__ err) {
+    __shared__ double s_part[16];
+    const int team = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int64_t gteam = (int64_t)blockIdx.x * 16 + team, nteams = (int64_t)gridDim.x * 16;
+    const int f = 4 * q;
+    double acc = 0.0;
+    float4 rN = make_float4(0.f, 0.f, 0.f, 0.f);
+    int aN = 0, mN = 0;
+    float cN = 0.f;
+    auto fetch = [&](int64_t s) __attribute__((always_inline)) {
+        mN = nnz[s];
+        const int64_t off = s * k + ((q < k) ? q : k - 1);
+        aN = idx[off];
+        cN = coef[off];
+        rN = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f + 3 < n) {
+            rN = *reinterpret_cast<const float4*>(X + s * ldx + f);
+        } else if (f < n) {  // ragged tail of an n that is not a multiple of 4
+            const float* p = X + s * ldx + f;
+            rN.x = p[0];
+            if (f + 1 < n) rN.y = p[1];
+            if (f + 2 < n) rN.z = p[2];
+        }
+    };
+    if (gteam < N) fetch(gteam);
+    for (int64_t s = gteam; s < N; s += nteams) {
+        float4 r = rN;
+        const int m = mN;
+        const int a = (q < m && q < k) ? aN : 0;
+        const float c = (q < m && q < k) ? cN : 0.f;
+        fetch((s + nteams < N) ? s + nteams : s);
+        float4 d[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            d[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < k) {  // uniform
+                const int aj = csr_row_bcast_res(a, j);
+                if (f < ldd) d[j] = *reinterpret_cast<const float4*>(D + (int64_t)aj * ldd + f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < k) {
+                const float cj = __builtin_bit_cast(float, csr_row_bcast_res(__builtin_bit_cast(int, c), j));
+                r.x = fmaf(-cj, d[j].x, r.x);
+                r.y = fmaf(-cj, d[j].y, r.y);
+                r.z = fmaf(-cj, d[j].z, r.z);
+                r.w = fmaf(-cj, d[j].w, r.w);
+            }
+        }
+        float e2 = 0.f;
+        if (f < n) {
+            if (R) *reinterpret_cast<float4*>(R + s * ldr + f) = r;  // padded columns of R receive zeros
+            e2 = fmaf(r.x, r.x, e2);
+            e2 = fmaf(r.y, r.y, e2);
+            e2 = fmaf(r.z, r.z, e2);
+            e2 = fmaf(r.w, r.w, e2);
+        }
+        acc += (double)row16_sum(e2);
+    }
+    if (err) {
+        if (q == 0) s_part[team] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) tot += s_part[t];
+            atomicAdd(err, tot);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__ X, int64_t ldx,
                                                        const float* __restrict__ D, int ldd, int n, int k, int64_t N,
                                                        const int32_t* __restrict__ idx,
@@ -140,7 +244,9 @@ int residual(const float* X, int64_t ldx, const float* D, int n, int K, int k, i
         int64_t blocks = (N + 15) / 16;
         if (blocks > cap) blocks = cap;
         const dim3 g((unsigned)blocks), b(256);
-        if (n <= 64)
+        if (n <= 64 && k <= 16)
+            hipLaunchKernelGGL(residual_team16_kernel, g, b, 0, stream, X, ldx, D, ldd, n, k, N, idx, coef, nnz, R, ldr, err);
+        else if (n <= 64)
             hipLaunchKernelGGL(residual_team_kernel<1>, g, b, 0, stream, X, ldx, D, ldd, n, k, N, idx, coef, nnz, R, ldr, err);
         else if (n <= 128)
             hipLaunchKernelGGL(residual_team_kernel<2>, g, b, 0, stream, X, ldx, D, ldd, n, k, N, idx, coef, nnz, R, ldr, err);
