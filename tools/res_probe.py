@@ -1,4 +1,5 @@
-"""What bounds the residual kernel (R = X - D Z, 2^20 64-dim patches, 1024 atoms): a device copy of the same bytes, then the kernel\nat k = 1, 2, 5, 10 -- the slope is the price of one gathered dictionary row per signal.  usage: python tools/res_probe.py"""
+"""What bounds the residual kernel (R = X - D Z, 2^20 64-dim patches, 1024 atoms): a device copy of the same bytes, then the kernel
+at k = 1, 2, 5, 10 -- the slope is the price of one gathered dictionary row per signal.  usage: python tools/res_probe.py"""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
