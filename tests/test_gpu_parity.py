@@ -265,6 +265,35 @@ def test_sparse_encoder_dropin(eng):
 
 
 # ------------------------------------------------------------------------------------------------ residual / CSR
+@pytest.mark.parametrize("n,K,k,N", [(64, 256, 10, 5000), (13, 40, 3, 777), (50, 128, 16, 3001), (32, 64, 8, 1), (64, 300, 20, 2000),
+                                     (100, 200, 10, 1500)])
+def test_residual_kernels_against_dense(eng, n, K, k, N):
+    """R = X - D Z and ||R||^2 (lyssa/dict_learning/ksvd.py:103, dict_learning/utils.py:14-19) from the sparse triplet: the
+    n <= 64, k <= 16 kernel (support one slot per lane, next signal prefetched; ragged feature counts, a single signal, signals
+    that stopped early), the general team kernel (k = 20, n = 100) -- against the dense float64 product of the same codes."""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(n * 1000 + k)
+    Dt = torch.randn((n, K), device="cuda", generator=gen)
+    Dt = Dt / Dt.norm(dim=0, keepdim=True)
+    Xs = torch.randn((N, n), device="cuda", generator=gen)
+    if N > 10:
+        Xs[3] = 2.5 * Dt[:, 7]            # exactly representable: the encoder stops after one atom (nnz < k)
+        Xs[5] = 0.0                       # zero signal: no atom at all
+    dd = eng.DeviceDictionary(n, K)
+    dd.set(Dt)
+    idx, coef, nnz = eng.bomp_encode(Xs, dd, k)
+    R, err = eng.residual(Xs, dd, idx, coef, nnz)
+    Z = eng.densify(idx, coef, nnz, K)                                    # (K, N) float64 on the host
+    D = dd.D[:K, :n].t().contiguous().double().cpu().numpy()
+    Rref = Xs.double().cpu().numpy().T - D @ Z
+    got = R[:, :n].double().cpu().numpy().T
+    scale = max(1.0, float(np.abs(Rref).max()))
+    assert np.max(np.abs(got - Rref)) < 2e-5 * scale
+    assert abs(err - np.sum(Rref ** 2)) <= 1e-5 * max(np.sum(Rref ** 2), 1e-12)
+    if R.shape[1] > n:
+        assert float(R[:, n:].abs().max()) == 0.0                         # padded columns receive zeros
+
+
 def test_residual_error_and_csr(eng):
     import torch
     from oracle import lyssa_oracle as orc
