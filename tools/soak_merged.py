@@ -7,7 +7,9 @@ import torch
 from lyssandra_amd import engine as eng
 
 SHAPES = [(64, 1024, 10, 1 << 18), (16, 16, 4, 200000), (8, 8, 3, 100000), (128, 128, 12, 100000), (64, 100, 5, 300000),
-          (64, 1030, 10, 100000), (256, 40, 6, 150000), (100, 24, 12, 120000), (32, 64, 8, 400000), (64, 2048, 10, 1 << 19)]
+          (64, 1030, 10, 100000), (256, 40, 6, 150000), (100, 24, 12, 120000), (32, 64, 8, 400000), (64, 2048, 10, 1 << 19),
+          # k > 16 runs the eager schedule whatever the switch says: a run-to-run determinism check of that path
+          (128, 128, 20, 100000), (64, 1024, 32, 50000), (200, 64, 8, 100000)]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 worst, bad = 0.0, 0
 for (n, K, k, N) in SHAPES:
